@@ -1,0 +1,251 @@
+"""Generate `tests/golden/*.npz` from the REAL reference (aask1357/hilcodec) — build container only.
+
+Run:  python oracle/make_golden.py            (needs /root/reference; CPU, ~1 min)
+
+Every expected output below is produced by the reference's own PyTorch modules
+(`models/hilcodec/models.py`, `models/hilcodec/streaming.py`, `models/hilcodec/modules/*.py`,
+`models/hilcodec/vector_quantize.py`, `modules/vector_quantize.py`,
+`modules/weight_standardization.py`) on deterministic synthetic weights/inputs that are
+*regenerated from seeds* (`hilcodec_amd/synth.py`) by the tests; only expected outputs (and tiny
+op-level inputs) are stored.  The fixtures are data: nothing of the reference's source is kept.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hilcodec_amd import synth  # noqa: E402
+from oracle import refimport as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 7
+CLIP_SEED = 1234
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def offline_golden(ref, name: str, n_clips: int, partial_n: int):
+    mk = synth.model_kwargs(name)
+    sd = synth.synth_state_dict(name, seed=WEIGHT_SEED)
+    model = R.build_offline(ref, mk, sd)
+    x = synth.synth_clips(n_clips, 24000, seed=CLIP_SEED)
+    out = {}
+    with torch.no_grad():
+        z = model.encoder(x.clone())
+        q, num_replaces, loss, idx = model.quantizer(z, None, return_indices=True)
+        wav = model.decoder(q)
+        wav2, nr2, loss2 = model(x.clone(), None)
+        assert torch.equal(wav, wav2)
+        qn, _, lossn, idxn = model.quantizer(z, partial_n, return_indices=True)
+        wavn = model.decoder(qn)
+        # a non-multiple-of-320 length exercises the "extra padding" branch (conv.py:61-68)
+        xr = x[:1, :, :5000].clone()
+        zr = model.encoder(xr.clone())
+        qr, _, _, idxr = model.quantizer(zr, None, return_indices=True)
+        wavr = model.decoder(qr)
+    out.update(z=t2n(z), indices=t2n(idx).astype(np.int16), wav=t2n(wav), loss=t2n(loss),
+               num_replaces=np.asarray(num_replaces),
+               q_probe=t2n(q[:, :, ::15]),
+               partial_n=np.int64(partial_n), indices_n=t2n(idxn).astype(np.int16),
+               wav_n_probe=t2n(wavn[:, :, ::16]), loss_n=t2n(lossn),
+               ragged_len=np.int64(5000), z_ragged=t2n(zr), indices_ragged=t2n(idxr).astype(np.int16),
+               wav_ragged=t2n(wavr),
+               weight_seed=np.int64(WEIGHT_SEED), clip_seed=np.int64(CLIP_SEED))
+    np.savez_compressed(os.path.join(OUT, f"offline_{name}.npz"), **out)
+    print(name, "offline: z", z.shape, "idx", idx.shape, "wav", wav.shape, "ragged z", zr.shape, "wav", wavr.shape)
+    return model, mk, sd
+
+
+def streaming_golden(ref, model, mk, sd, name: str):
+    sm = R.build_streaming(ref, mk, model)
+    hops = 10
+    x = synth.synth_clips(1, 320 * hops, seed=CLIP_SEED + 500)
+    ce, cd = sm.initialize_cache(x)
+    zs, idxs, wavs = [], [], []
+    snap = {}
+    n = mk["vq_kwargs"]["num_quantizers"]
+    with torch.no_grad():
+        for h in range(hops):
+            xin = x[:, :, 320 * h: 320 * (h + 1)]
+            z, ce = sm.encoder(xin, *ce)
+            idx = sm.quantizer(z, n)
+            q = sm.dequantizer(idx, n)
+            w, cd = sm.decoder(q, *cd)
+            zs.append(z); idxs.append(idx); wavs.append(w)
+            if h in (0, hops - 1):
+                snap[h] = ([c.clone() for c in ce], [c.clone() for c in cd])
+        # chunked call (3 frames at once) must equal frame-by-frame
+        ce2, cd2 = sm.initialize_cache(x)
+        z3, ce2 = sm.encoder(x[:, :, :960], *ce2)
+    out = dict(z=t2n(torch.cat(zs, 1)), indices=t2n(torch.cat(idxs, 2)).astype(np.int16),
+               wav=t2n(torch.cat(wavs, 2)), hops=np.int64(hops), clip_seed=np.int64(CLIP_SEED + 500),
+               weight_seed=np.int64(WEIGHT_SEED), z_chunk3=t2n(z3))
+    for i, c in enumerate(snap[hops - 1][0]):
+        out[f"e_out{i}"] = t2n(c)
+    for i, c in enumerate(snap[hops - 1][1]):
+        out[f"d_out{i}"] = t2n(c)
+    out["e_first_sums"] = np.array([c.double().sum().item() for c in snap[0][0]])
+    out["d_first_sums"] = np.array([c.double().sum().item() for c in snap[0][1]])
+    np.savez_compressed(os.path.join(OUT, f"stream_{name}.npz"), **out)
+    print(name, "stream: z", out["z"].shape, "idx", out["indices"].shape, "wav", out["wav"].shape)
+
+
+def ops_golden(ref):
+    """One tiny known-answer vector per kernel kind, from the reference's own layer classes."""
+    saved = list(sys.path)
+    sys.path.insert(0, R.REFERENCE_ROOT)
+    try:
+        from models.hilcodec.modules import SConv1d, SConvTranspose1d, CausalSTFT
+        from models.hilcodec.modules.seanet import SEANetResnetBlock, SpecBlock, L2Norm
+        from models.hilcodec import causal_layers as CL
+    finally:
+        sys.path[:] = saved
+    out = {}
+
+    def fill(mod, seed):
+        with torch.no_grad():
+            for i, (k, p) in enumerate(sorted(mod.state_dict().items())):
+                if k.endswith("spec.weight") or k == "weight" and isinstance(mod, CausalSTFT):
+                    continue
+                n = p.numel()
+                if k.endswith("weight_g"):
+                    v = synth.uniform(seed + i, n, 0.8, 1.2)
+                elif k.endswith("scale_param"):
+                    v = synth.uniform(seed + i, n, 0.5, 1.0)
+                elif k.endswith("bias"):
+                    v = synth.uniform(seed + i, n, -0.2, 0.2)
+                else:
+                    v = synth.uniform(seed + i, n, -1.0, 1.0)
+                p.copy_(torch.from_numpy(v).view(p.shape))
+
+    def dump(tag, mod):
+        for k, p in mod.state_dict().items():
+            out[f"{tag}.{k}"] = t2n(p)
+
+    def inp(seed, *shape):
+        return torch.from_numpy(synth.normalish(seed, int(np.prod(shape)))).view(*shape)
+
+    with torch.no_grad():
+        # pointwise conv after ELU, with bias (decoder up-pointwise style), odd Cin like the spec convs
+        m = SConv1d(33, 40, 1, norm="weight_norm", bias=True); fill(m, 11)
+        x = inp(1, 2, 33, 50)
+        out["pw.x"] = t2n(x); dump("pw", m); out["pw.y"] = t2n(m(torch.nn.functional.elu(x)))
+        # depthwise causal k5 (residual conv)
+        m = SConv1d(24, 24, 5, groups=24, causal=True, norm="weight_norm", bias=True); fill(m, 21)
+        x = inp(2, 2, 24, 37)
+        out["dw5.x"] = t2n(x); dump("dw5", m); out["dw5.y"] = t2n(m(x))
+        # strided depthwise (downsample), every ratio, ragged length
+        for r in (2, 4, 5, 8):
+            m = SConv1d(16, 16, 2 * r, stride=r, groups=16, causal=True, norm="weight_norm", bias=True)
+            fill(m, 30 + r)
+            x = inp(3 + r, 2, 16, 8 * r + 3)
+            out[f"dws{r}.x"] = t2n(x); dump(f"dws{r}", m); out[f"dws{r}.y"] = t2n(m(x))
+            mt = SConvTranspose1d(16, 16, 2 * r, stride=r, groups=16, causal=True, norm="weight_norm", bias=False)
+            fill(mt, 40 + r)
+            x = inp(13 + r, 2, 16, 9)
+            out[f"dwt{r}.x"] = t2n(x); dump(f"dwt{r}", mt); out[f"dwt{r}.y"] = t2n(mt(x))
+        # conv_pre (1 -> C, k5) and conv_post (C -> 1, k5)
+        m = SConv1d(1, 16, 5, causal=True, norm="weight_norm", bias=True); fill(m, 51)
+        x = inp(51, 2, 1, 100)
+        out["pre.x"] = t2n(x); dump("pre", m); out["pre.y"] = t2n(m(x))
+        m = SConv1d(12, 1, 5, causal=True, norm="weight_norm", bias=True); fill(m, 52)
+        x = inp(52, 2, 12, 64)
+        out["post.x"] = t2n(x); dump("post", m); out["post.y"] = t2n(m(x))
+        # SpecBlock for a small n_fft (hop 1 and hop>1)
+        for n_fft, hop in ((16, 1), (32, 4)):
+            T = 96
+            m = SpecBlock("stft", "log", n_fft, 8, hop, "weight_norm", {}, bias=False, pad_mode="constant",
+                          learnable=False, causal=True, mean=-4.0, std=2.8, res_scale=0.5773502691896258,
+                          zero_init=True, inout_norm=True)
+            fill(m, 60 + hop)
+            wav = inp(60 + hop, 2, 1, T) * 0.1
+            xin = inp(61 + hop, 2, 8, (T - 1) // hop + 1)
+            tag = f"spec{n_fft}"
+            out[f"{tag}.wav"] = t2n(wav); out[f"{tag}.x"] = t2n(xin); dump(tag, m)
+            out[f"{tag}.mag"] = t2n(m.spec(wav))
+            out[f"{tag}.y"] = t2n(m(xin.clone(), wav))
+        # residual block, idx 0/1/2
+        for idx in (0, 1, 2):
+            m = SEANetResnetBlock(16, kernel_size=5, dilations=[1, 1], norm="weight_norm", causal=True,
+                                  skip="identity", res_scale=0.5773502691896258, idx=idx, zero_init=True)
+            fill(m, 70 + idx)
+            x = inp(70 + idx, 2, 16, 45)
+            out[f"res{idx}.x"] = t2n(x); dump(f"res{idx}", m); out[f"res{idx}.y"] = t2n(m(x.clone()))
+        # L2Norm
+        x = inp(80, 2, 128, 9)
+        x[0, :, 3] = 0.0
+        out["l2.x"] = t2n(x); out["l2.y"] = t2n(L2Norm(128)(x))
+        # weight-standardisation fold (available norm option, conv.py:36-37)
+        conv = torch.nn.Conv1d(6, 10, 3)
+        with torch.no_grad():
+            conv.weight.copy_(inp(90, 10, 6, 3))
+        out["ws.v"] = t2n(conv.weight)
+        wsconv = ref.ws.weight_standardization(conv, scale=1.7)
+        with torch.no_grad():
+            wsconv.weight_g.copy_(torch.from_numpy(synth.uniform(91, 10, 0.5, 1.5)).view(10, 1, 1))
+        wsconv(torch.zeros(1, 6, 8))   # pre-hook recomputes .weight
+        out["ws.g"] = t2n(wsconv.weight_g); out["ws.scale"] = np.float32(1.7); out["ws.w"] = t2n(wsconv.weight)
+        # streaming cache-carrying layers (causal_layers.py)
+        c = CL.CausalConv1d(8, 8, 10, 5, groups=8, bias=True)
+        x = inp(95, 2, 8, 15); cache = inp(96, 2, 8, c.causal_padding)
+        y, nc = c(x, cache)
+        out["cconv.x"] = t2n(x); out["cconv.cache"] = t2n(cache); out["cconv.w"] = t2n(c.weight)
+        out["cconv.b"] = t2n(c.bias); out["cconv.y"] = t2n(y); out["cconv.cache_out"] = t2n(nc)
+        ct = CL.CausalConvTranspose1d(8, 8, 10, 5, groups=8, bias=False)
+        x = inp(97, 2, 8, 3); cache = inp(98, 2, 8, ct.causal_padding)
+        y, nc = ct(x, cache)
+        out["cconvtr.x"] = t2n(x); out["cconvtr.cache"] = t2n(cache); out["cconvtr.w"] = t2n(ct.weight)
+        out["cconvtr.y"] = t2n(y); out["cconvtr.cache_out"] = t2n(nc)
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops:", len(out), "arrays")
+
+
+def rvq_golden(ref):
+    """RVQ known-answer test: both distance forms (SURVEY §8 a8 vs a9/a16), n < Nq, indices + q."""
+    nq, K, D = 12, 1024, 128
+    z = torch.from_numpy(synth.normalish(4242, 2 * D * 75)).view(2, D, 75)
+    z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+    new = ref.vq_new.ResidualVQ(num_quantizers=nq, dropout=False, channel_last=False, dim=D,
+                                codebook_size=K, kmeans_init=False).eval()
+    old = ref.vq_old.ResidualVQ(num_quantizers=nq, dropout=False, dim=D, codebook_size=K,
+                                kmeans_init=False).eval()
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(synth.key_seed(99, f"rvq{i}"), K * D) * np.float32(0.3 * 0.95 ** i)).view(K, D)
+        new.layers[i].embed.copy_(e)
+        old.layers[i]._codebook.embed.copy_(e)
+    out = dict(codebook_seed=np.int64(99), z_seed=np.int64(4242))
+    with torch.no_grad():
+        q, nr, loss, idx = new(z, None, return_indices=True)
+        out.update(indices=t2n(idx).astype(np.int16), q=t2n(q), loss=t2n(loss))
+        q5, _, loss5, idx5 = new(z, 5, return_indices=True)
+        out.update(indices_n5=t2n(idx5).astype(np.int16), q_n5_probe=t2n(q5[:, :, ::5]), loss_n5=t2n(loss5))
+        qo, nro, losso = old(z, None)
+        out.update(q_legacy=t2n(qo), loss_legacy=t2n(losso), num_replaces=np.asarray(nro))
+    np.savez_compressed(os.path.join(OUT, "rvq.npz"), **out)
+    print("rvq: idx", idx.shape, "legacy q diff", (q - qo).abs().max().item())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = R.load_reference()
+    ops_golden(ref)
+    rvq_golden(ref)
+    model, mk, sd = offline_golden(ref, "hil_speech", n_clips=2, partial_n=4)
+    streaming_golden(ref, model, mk, sd, "hil_speech")
+    offline_golden(ref, "hil_music", n_clips=1, partial_n=2)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+"""CPU: the oracle (oracle/hilcodec_oracle.py) against the golden vectors that
+oracle/make_golden.py produced from the REAL reference.  Bit-exact (same torch CPU kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from hilcodec_amd import synth
+from oracle import hilcodec_oracle as O
+
+torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def speech():
+    return synth.model_kwargs("hil_speech"), synth.synth_state_dict("hil_speech", seed=7)
+
+
+@pytest.mark.parametrize("name", ["hil_speech", "hil_music"])
+def test_offline_end_to_end(golden, name):
+    g = golden(f"offline_{name}")
+    mk = synth.model_kwargs(name)
+    sd = synth.synth_state_dict(name, seed=int(g["weight_seed"]))
+    x = synth.synth_clips(g["z"].shape[0], 24000, seed=int(g["clip_seed"]))
+    with torch.no_grad():
+        wav, num_replaces, loss, aux = O.codec_forward(sd, x, mk)
+        assert torch.equal(aux["z"], T(g["z"]))
+        assert torch.equal(aux["indices"], T(g["indices"]).long())
+        assert torch.equal(wav, T(g["wav"]))
+        assert torch.equal(aux["q"][:, :, ::15], T(g["q_probe"]))
+        assert float(loss) == float(g["loss"])
+        assert (num_replaces == g["num_replaces"]).all() and num_replaces.dtype == np.int64
+        n = int(g["partial_n"])
+        wav_n, _, loss_n, aux_n = O.codec_forward(sd, x, mk, n=n)
+        assert torch.equal(aux_n["indices"], T(g["indices_n"]).long())
+        assert torch.equal(wav_n[:, :, ::16], T(g["wav_n_probe"]))
+        assert float(loss_n) == float(g["loss_n"])
+        xr = x[:1, :, : int(g["ragged_len"])]
+        wav_r, _, _, aux_r = O.codec_forward(sd, xr, mk)
+        assert torch.equal(aux_r["z"], T(g["z_ragged"]))
+        assert torch.equal(aux_r["indices"], T(g["indices_ragged"]).long())
+        assert torch.equal(wav_r, T(g["wav_ragged"]))
+
+
+def test_rvq_n_out_of_range(speech):
+    mk, sd = speech
+    z = torch.zeros(1, 128, 3)
+    for bad in (0, 9):
+        with pytest.raises(AssertionError):
+            O.rvq_forward(sd, z, bad, 8)
+
+
+def test_streaming(golden, speech):
+    g = golden("stream_hil_speech")
+    mk, sd = speech
+    p = O.stream_prepare(sd, mk)
+    hops = int(g["hops"])
+    x = synth.synth_clips(1, 320 * hops, seed=int(g["clip_seed"]))
+    ce, cd = O.stream_init_cache(mk, 1)
+    zs, ids, ws = [], [], []
+    with torch.no_grad():
+        for h in range(hops):
+            z, ce = O.stream_encoder(p, mk, x[:, :, 320 * h: 320 * (h + 1)], ce)
+            idx = O.stream_quantize(p, z, 8)
+            w, cd = O.stream_decoder(p, mk, O.stream_dequantize(p, idx, 8), cd)
+            zs.append(z); ids.append(idx); ws.append(w)
+            if h == 0:
+                assert np.array_equal(np.array([c.double().sum().item() for c in ce]), g["e_first_sums"])
+                assert np.array_equal(np.array([c.double().sum().item() for c in cd]), g["d_first_sums"])
+        assert torch.equal(torch.cat(zs, 1), T(g["z"]))
+        assert torch.equal(torch.cat(ids, 2), T(g["indices"]).long())
+        assert torch.equal(torch.cat(ws, 2), T(g["wav"]))
+        for i, c in enumerate(ce):
+            assert torch.equal(c, T(g[f"e_out{i}"])), i
+        for i, c in enumerate(cd):
+            assert torch.equal(c, T(g[f"d_out{i}"])), i
+        ce2, _ = O.stream_init_cache(mk, 1)
+        z3, _ = O.stream_encoder(p, mk, x[:, :, :960], ce2)
+        assert torch.equal(z3, T(g["z_chunk3"]))
+
+
+def test_cache_template_shapes(speech):
+    """Shapes documented for onnx/hil_speech_cache_{enc,dec}.npz."""
+    mk, _ = speech
+    enc, dec = O.stream_cache_shapes(mk)
+    assert len(enc) == 22 and len(dec) == 30
+    assert enc[0] == (1, 1023) and enc[1] == (64, 4) and enc[5] == (128, 2)
+    assert enc[20] == (1024, 8) and enc[21] == (1024, 4)
+    assert dec[0] == (1536, 4) and dec[1] == (1536, 1) and dec[2] == (768, 4) and dec[29] == (96, 4)
+    assert sum(c * l for c, l in enc) == 32511 and sum(c * l for c, l in dec) == 43968
+
+
+def test_rvq_kat(golden):
+    g = golden("rvq")
+    nq, K, D = 12, 1024, 128
+    z = torch.from_numpy(synth.normalish(int(g["z_seed"]), 2 * D * 75)).view(2, D, 75)
+    z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+    sd = {}
+    for i in range(nq):
+        sd[f"quantizer.layers.{i}.embed"] = torch.from_numpy(
+            synth.normalish(synth.key_seed(int(g["codebook_seed"]), f"rvq{i}"), K * D) * np.float32(0.3 * 0.95 ** i)).view(K, D)
+    q, nr, loss, idx = O.rvq_forward(sd, z, None, nq)
+    assert torch.equal(idx, T(g["indices"]).long()) and torch.equal(q, T(g["q"]))
+    assert float(loss) == float(g["loss"])
+    q5, _, loss5, idx5 = O.rvq_forward(sd, z, 5, nq)
+    assert torch.equal(idx5, T(g["indices_n5"]).long()) and float(loss5) == float(g["loss_n5"])
+    ql, _, lossl, idxl = O.rvq_forward(sd, z, None, nq, variant="legacy")
+    assert torch.equal(ql, T(g["q_legacy"]))
+    # streaming layout: [B,T,C] -> [n,B,T]
+    p = {f"vq.{i}.embed": sd[f"quantizer.layers.{i}.embed"] for i in range(nq)}
+    ids = O.stream_quantize(p, z.transpose(1, 2), nq)
+    assert torch.equal(ids.permute(1, 0, 2), T(g["indices"]).long())
+    assert torch.allclose(O.stream_dequantize(p, ids, nq).transpose(1, 2), T(g["q"]), atol=1e-6)
+    gaps = O.rvq_gaps_fp64(sd, z, idx)
+    assert gaps.min() >= 0 and gaps.shape == idx.shape
+
+
+def test_ops_kat(golden):
+    g = golden("ops")
+    F = torch.nn.functional
+
+    def sub(tag):
+        pre = tag + "."
+        return {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+
+    d = sub("pw")
+    w, b = O.conv_weight(d, "conv.conv")
+    assert torch.equal(F.conv1d(O.elu(d["x"]), w, b), d["y"])
+    d = sub("dw5")
+    w, b = O.conv_weight(d, "conv.conv")
+    assert torch.equal(O.sconv1d(d["x"], w, b, groups=w.shape[0]), d["y"])
+    for r in (2, 4, 5, 8):
+        d = sub(f"dws{r}")
+        w, b = O.conv_weight(d, "conv.conv")
+        assert torch.equal(O.sconv1d(d["x"], w, b, stride=r, groups=w.shape[0]), d["y"])
+        d = sub(f"dwt{r}")
+        w, b = O.conv_weight(d, "convtr.convtr")
+        assert torch.equal(O.sconvtr1d(d["x"], w, b, stride=r, groups=w.shape[0]), d["y"])
+    for tag in ("pre", "post"):
+        d = sub(tag)
+        w, b = O.conv_weight(d, "conv.conv")
+        assert torch.equal(O.sconv1d(d["x"], w, b), d["y"])
+    for n_fft, hop in ((16, 1), (32, 4)):
+        d = sub(f"spec{n_fft}")
+        assert torch.equal(d["spec.weight"], synth.stft_basis(n_fft))
+        assert torch.equal(O.causal_stft_mag(d["wav"], d["spec.weight"], hop, True, True), d["mag"])
+        y = O.spec_block(d, "", d["x"], d["wav"], hop, -4.0, 2.8, 0.5773502691896258) if False else None
+        sd = {"p." + k: v for k, v in d.items()}
+        y = O.spec_block(sd, "p", d["x"], d["wav"], hop, -4.0, 2.8, 0.5773502691896258)
+        assert torch.equal(y, d["y"])
+    for idx in (0, 1, 2):
+        d = sub(f"res{idx}")
+        sd = {"p." + k: v for k, v in d.items()}
+        assert torch.equal(O.resblock(sd, "p", d["x"], 0.5773502691896258, idx), d["y"])
+    d = sub("l2")
+    assert torch.equal(F.normalize(d["x"], p=2.0, dim=1, eps=1e-12) * 128 ** 0.5, d["y"])
+    d = sub("ws")
+    assert torch.equal(O.fold_weight_standardization(d["v"], d["g"], d["scale"]), d["w"])
+    d = sub("cconv")
+    y, c = O.causal_conv1d(d["x"], d["cache"], d["w"], d["b"], 5, 8)
+    assert torch.equal(y, d["y"]) and torch.equal(c, d["cache_out"])
+    d = sub("cconvtr")
+    y, c = O.causal_convtr1d(d["x"], d["cache"], d["w"], None, 5, 8)
+    assert torch.equal(y, d["y"]) and torch.equal(c, d["cache_out"])
