@@ -1,0 +1,64 @@
+"""ctypes binding of `libhilcodec_amd.so` (the C ABI declared in `include/hilcodec_amd.h`).
+
+The HIP library IS the product: there is no PyTorch/CPU fallback.  If the shared object is missing
+or a symbol cannot be resolved this module raises at import time, and every op raises
+`RuntimeError` when handed a non-GPU tensor."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhilcodec_amd.so")
+
+_f, _i, _p, _d = C.c_float, C.c_int, C.c_void_p, C.c_double
+
+# name -> argtypes, in the order of include/hilcodec_amd.h
+SIGNATURES = {
+    "hilc_pw_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p],
+    "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
+    "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
+    "hilc_conv_pre": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "hilc_conv_post": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
+    "hilc_stft_logmag": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
+    "hilc_tail": [_p, _p, _p, C.c_long, _i, _i, _i, _p],
+    "hilc_l2norm": [_p, _p, _i, _i, _i, _f, _f, _i, _p],
+    "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_mse_finalize": [_p, _p, _i, _d, _p],
+    "hilc_rvq_decode": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+}
+
+ABI_VERSION = 1
+
+
+class HilcodecLibraryError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.isfile(LIB_PATH):
+        raise HilcodecLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.hilc_abi_version.restype = _i
+    lib.hilc_error_string.restype = C.c_char_p
+    lib.hilc_error_string.argtypes = [_i]
+    if lib.hilc_abi_version() != ABI_VERSION:
+        raise HilcodecLibraryError(f"ABI mismatch: library {lib.hilc_abi_version()} != binding {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib.hilc_error_string(code).decode()
+        if code == -5:
+            raise AssertionError(msg)      # reference: `assert 1 <= n <= len(self.layers)`
+        raise RuntimeError(f"{what}: {msg} (code {code})")

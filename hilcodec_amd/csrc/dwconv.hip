@@ -1,0 +1,296 @@
+// HBM-bound kernels of the HILCodec hot path (gfx950): depthwise causal conv (k5 s1 and the
+// strided down-sampling k=2r), depthwise transposed conv (up-sampling), the Cin=1 / Cout=1 edge
+// convs and L2Norm.  Layout `[B][C][T]`, time contiguous: consecutive lanes walk consecutive
+// samples (coalesced), the k5 path moves float4 per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 16;
+
+struct DwArgs {
+  const float* x;
+  const float* hist;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  int C, Cin, T, To, ksize, stride, pad, hist_len;
+  float in_scale;
+  int in_elu;
+  float out_scale;
+  int out_elu;
+};
+
+// extended input: history for t < 0 (zero if none), prologue'd x for 0 <= t < T, zero beyond.
+__device__ __forceinline__ float xe(const DwArgs& a, const float* xrow, const float* hrow, int t) {
+  if (t >= 0) return t < a.T ? prologue(xrow[t], a.in_scale, a.in_elu) : 0.f;
+  if (hrow != nullptr) return hrow[a.hist_len + t];
+  return 0.f;
+}
+
+__device__ __forceinline__ float dw_post(const DwArgs& a, float acc, int c, long off) {
+  // separate roundings, like `y.mul_(scale).add_(shortcut)` (seanet.py:148) — no FMA contraction
+  if (a.bias != nullptr) acc = __fadd_rn(acc, a.bias[c]);
+  acc = __fmul_rn(acc, a.out_scale);
+  if (a.res != nullptr) acc = __fadd_rn(acc, a.res[off]);
+  if (a.out_elu) acc = elu1(acc);
+  return acc;
+}
+
+// generic: one thread per output sample. grid.x = rows (b*C + c), grid.y = time chunks of 256.
+__global__ __launch_bounds__(256) void dw_generic_kernel(DwArgs a) {
+  long row = blockIdx.x;
+  int c = (int)(row % a.C);
+  long b = row / a.C;
+  int o = blockIdx.y * 256 + threadIdx.x;
+  if (o >= a.To) return;
+  long inrow = a.Cin == 1 ? b : row;
+  const float* xrow = a.x + inrow * (long)a.T;
+  const float* hrow = a.hist ? a.hist + inrow * (long)a.hist_len : nullptr;
+  const float* wr = a.w + (long)c * a.ksize;
+  float acc = 0.f;
+  int t0 = o * a.stride - a.pad;
+  for (int j = 0; j < a.ksize; ++j) acc = fmaf(wr[j], xe(a, xrow, hrow, t0 + j), acc);
+  long off = row * (long)a.To + o;
+  a.y[off] = dw_post(a, acc, c, off);
+}
+
+// k == 5, stride 1, T % 4 == 0, 16-B aligned rows: 4 outputs per thread from two float4 loads.
+__global__ __launch_bounds__(256) void dw_k5_vec_kernel(DwArgs a) {
+  long row = blockIdx.x;
+  int c = (int)(row % a.C);
+  long b = row / a.C;
+  int t = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (t >= a.T) return;
+  long inrow = a.Cin == 1 ? b : row;
+  const float* xrow = a.x + inrow * (long)a.T;
+  const float* hrow = a.hist ? a.hist + inrow * (long)a.hist_len : nullptr;
+  float v[8];
+  float4 cur = prologue4(*reinterpret_cast<const float4*>(xrow + t), a.in_scale, a.in_elu);
+  v[4] = cur.x; v[5] = cur.y; v[6] = cur.z; v[7] = cur.w;
+  if (t >= 4) {
+    float4 prev = prologue4(*reinterpret_cast<const float4*>(xrow + t - 4), a.in_scale, a.in_elu);
+    v[0] = prev.x; v[1] = prev.y; v[2] = prev.z; v[3] = prev.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = hrow ? hrow[a.hist_len - 4 + j] : 0.f;
+  }
+  float wk[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) wk[j] = a.w[(long)c * 5 + j];
+  float out[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.f;
+    // output t+i reads inputs t+i-4 .. t+i  -> v[i+j], taps in order j = 0..4
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc = fmaf(wk[j], v[i + j], acc);
+    long off = row * (long)a.T + t + i;
+    out[i] = dw_post(a, acc, c, off);
+  }
+  *reinterpret_cast<float4*>(a.y + row * (long)a.T + t) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// new cache = last `pad` samples of [hist | pro(x)]; one thread per (row, i)
+__global__ void hist_out_kernel(const float* x, const float* hist, float* hist_out, long rows, int T, int pad,
+                                int hist_len, float in_scale, int in_elu) {
+  long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * pad) return;
+  long row = g / pad;
+  int i = (int)(g - row * pad);
+  int t = T - pad + i;
+  float v;
+  if (t >= 0) v = prologue(x[row * (long)T + t], in_scale, in_elu);
+  else v = hist ? hist[row * (long)hist_len + hist_len + t] : 0.f;
+  hist_out[row * (long)pad + i] = v;
+}
+
+struct TrArgs {
+  const float* x;
+  const float* hist;
+  const float* w;
+  float* y;
+  int C, T, r;
+  float in_scale;
+  int in_elu;
+};
+
+__global__ __launch_bounds__(256) void dw_convtr_kernel(TrArgs a) {
+  long row = blockIdx.x;
+  int c = (int)(row % a.C);
+  int n = blockIdx.y * 256 + threadIdx.x;
+  int To = a.T * a.r;
+  if (n >= To) return;
+  int q = n / a.r, p = n - q * a.r;
+  const float* xrow = a.x + row * (long)a.T;
+  float cur = prologue(xrow[q], a.in_scale, a.in_elu);
+  float prev = q > 0 ? prologue(xrow[q - 1], a.in_scale, a.in_elu) : (a.hist ? a.hist[row] : 0.f);
+  const float* wr = a.w + (long)c * 2 * a.r;
+  a.y[row * (long)To + n] = fmaf(wr[p], cur, wr[p + a.r] * prev);
+}
+
+struct PostArgs {
+  const float* x;
+  const float* hist;
+  const float* w;
+  const float* bias;
+  float* y;
+  int C, T, ksize;
+  float in_scale;
+  int in_elu;
+  float out_scale;
+  int do_tanh;
+};
+
+// Cout = 1: one thread per output sample, channels reduced sequentially (c = 0..C-1, then taps).
+__global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
+  long b = blockIdx.x;
+  int t = blockIdx.y * 256 + threadIdx.x;
+  if (t >= a.T) return;
+  const int pad = a.ksize - 1;
+  float acc = 0.f;
+  for (int c = 0; c < a.C; ++c) {
+    const float* xrow = a.x + (b * a.C + c) * (long)a.T;
+    const float* hrow = a.hist ? a.hist + (b * a.C + c) * (long)pad : nullptr;
+    const float* wr = a.w + (long)c * a.ksize;
+    for (int j = 0; j < a.ksize; ++j) {
+      int ti = t - pad + j;
+      float v;
+      if (ti >= 0) v = prologue(xrow[ti], a.in_scale, a.in_elu);
+      else v = hrow ? hrow[pad + ti] : 0.f;
+      acc = fmaf(wr[j], v, acc);
+    }
+  }
+  if (a.bias) acc = __fadd_rn(acc, a.bias[0]);
+  acc = __fmul_rn(acc, a.out_scale);
+  if (a.do_tanh) acc = tanhf(acc);
+  a.y[b * (long)a.T + t] = acc;
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* x, float* y, int C, int T, float eps,
+                                                     float scale, int channel_last_out) {
+  long b = blockIdx.x;
+  int t = blockIdx.y * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float* xb = x + b * (long)C * T + t;
+  float ss = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float v = xb[(long)c * T];
+    ss = fmaf(v, v, ss);
+  }
+  float denom = fmaxf(sqrtf(ss), eps);  // F.normalize: x / max(||x||, eps)
+  for (int c = 0; c < C; ++c) {
+    float v = __fmul_rn(__fdiv_rn(xb[(long)c * T], denom), scale);
+    if (channel_last_out) y[(b * T + t) * (long)C + c] = v;
+    else y[b * (long)C * T + (long)c * T + t] = v;
+  }
+}
+
+int launch_hist_out(const float* x, const float* hist, float* hist_out, long rows, int T, int pad, int hist_len,
+                    float in_scale, int in_elu, hipStream_t s) {
+  if (pad <= 0) return HILC_OK;
+  long n = rows * pad;
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(hist_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, hist, hist_out, rows, T,
+                     pad, hist_len, in_scale, in_elu);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+int launch_dw(DwArgs a, int B, hipStream_t s) {
+  long rows = (long)B * a.C;
+  if (rows > 0x7fffffffL) return HILC_ERR_SHAPE;
+  bool vec = a.stride == 1 && a.ksize == 5 && a.T % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+             (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (a.hist == nullptr || a.hist_len >= 4);
+  if (vec) {
+    dim3 grid((unsigned)rows, (unsigned)ceil_div(a.T / 4, 256));
+    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_k5_vec_kernel, grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((unsigned)rows, (unsigned)ceil_div(a.To, 256));
+    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_generic_kernel, grid, dim3(256), 0, s, a);
+  }
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+}  // namespace
+
+extern "C" int hilc_dw_conv(const float* x, const float* hist, const float* w, const float* bias, const float* res,
+                            float* y, float* hist_out, int B, int C, int T, int ksize, int stride, float in_scale,
+                            int in_elu, float out_scale, int out_elu, void* stream) {
+  if (!x || !w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || ksize <= 0 || stride <= 0) return HILC_ERR_SHAPE;
+  if (ksize > MAXK || ksize < stride) return HILC_ERR_UNSUPPORTED;
+  DwArgs a;
+  a.x = x; a.hist = hist; a.w = w; a.bias = bias; a.res = res; a.y = y;
+  a.C = C; a.Cin = C; a.T = T; a.To = (T + stride - 1) / stride; a.ksize = ksize; a.stride = stride;
+  a.pad = (ksize - 1) - (stride - 1); a.hist_len = a.pad;
+  a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.out_elu = out_elu;
+  int rc = launch_dw(a, B, (hipStream_t)stream);
+  if (rc != HILC_OK) return rc;
+  if (hist_out) return launch_hist_out(x, hist, hist_out, (long)B * C, T, a.pad, a.pad, in_scale, in_elu, (hipStream_t)stream);
+  return HILC_OK;
+}
+
+extern "C" int hilc_conv_pre(const float* wav, const float* hist, int hist_len, const float* w, const float* bias,
+                             float* y, int B, int C, int T, int ksize, float in_scale, void* stream) {
+  if (!wav || !w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || ksize <= 0) return HILC_ERR_SHAPE;
+  if (ksize > MAXK) return HILC_ERR_UNSUPPORTED;
+  if (hist && hist_len < ksize - 1) return HILC_ERR_SHAPE;
+  DwArgs a;
+  a.x = wav; a.hist = hist; a.w = w; a.bias = bias; a.res = nullptr; a.y = y;
+  a.C = C; a.Cin = 1; a.T = T; a.To = T; a.ksize = ksize; a.stride = 1; a.pad = ksize - 1;
+  a.hist_len = hist ? hist_len : a.pad;
+  a.in_scale = in_scale; a.in_elu = 0; a.out_scale = 1.f; a.out_elu = 0;
+  return launch_dw(a, B, (hipStream_t)stream);
+}
+
+extern "C" int hilc_dw_convtr(const float* x, const float* hist, const float* w, float* y, float* hist_out, int B,
+                              int C, int T, int stride, float in_scale, int in_elu, void* stream) {
+  if (!x || !w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || stride <= 0) return HILC_ERR_SHAPE;
+  long rows = (long)B * C;
+  if (rows > 0x7fffffffL) return HILC_ERR_SHAPE;
+  TrArgs a;
+  a.x = x; a.hist = hist; a.w = w; a.y = y; a.C = C; a.T = T; a.r = stride; a.in_scale = in_scale; a.in_elu = in_elu;
+  dim3 grid((unsigned)rows, (unsigned)ceil_div((long)T * stride, 256));
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_convtr_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  if (hist_out) return launch_hist_out(x, hist, hist_out, rows, T, 1, 1, in_scale, in_elu, (hipStream_t)stream);
+  return HILC_OK;
+}
+
+extern "C" int hilc_conv_post(const float* x, const float* hist, const float* w, const float* bias, float* y,
+                              float* hist_out, int B, int C, int T, int ksize, float in_scale, int in_elu,
+                              float out_scale, int do_tanh, void* stream) {
+  if (!x || !w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || ksize <= 0) return HILC_ERR_SHAPE;
+  PostArgs a;
+  a.x = x; a.hist = hist; a.w = w; a.bias = bias; a.y = y; a.C = C; a.T = T; a.ksize = ksize;
+  a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.do_tanh = do_tanh;
+  dim3 grid((unsigned)B, (unsigned)ceil_div(T, 256));
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  if (hist_out)
+    return launch_hist_out(x, hist, hist_out, (long)B * C, T, ksize - 1, ksize - 1, in_scale, in_elu, (hipStream_t)stream);
+  return HILC_OK;
+}
+
+extern "C" int hilc_tail(const float* x, const float* hist, float* out, long rows, int T, int pad, int hist_len,
+                         void* stream) {
+  if (!x || !out) return HILC_ERR_NULL;
+  if (rows <= 0 || T <= 0 || pad <= 0) return HILC_ERR_SHAPE;
+  if (hist && hist_len < pad - T) return HILC_ERR_SHAPE;
+  return launch_hist_out(x, hist, out, rows, T, pad, hist_len, 1.0f, 0, (hipStream_t)stream);
+}
+
+extern "C" int hilc_l2norm(const float* x, float* y, int B, int C, int T, float eps, float scale,
+                           int channel_last_out, void* stream) {
+  if (!x || !y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  dim3 grid((unsigned)B, (unsigned)ceil_div(T, 256));
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, T, eps, scale, channel_last_out);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}

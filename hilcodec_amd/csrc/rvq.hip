@@ -1,0 +1,258 @@
+// Residual vector quantiser for the HILCodec hot path (gfx950).
+//
+// hilc_rvq_encode: one workgroup (256 threads) owns FR=16 consecutive frames and walks the n
+// stages in order, keeping the running residual and the running quantised sum in LDS.  Per stage
+// every thread scores 4 of the K=1024 code vectors against all 16 frames with fp32 FMA chains in
+// fixed channel order (c = 0..C-1), reading the codebook through its transposed copy `[C][K]`
+// (consecutive lanes = consecutive codes = coalesced) and the residual as broadcast
+// ds_read_b128 rows `[c][16 frames]`.  The distance is `|e|^2 - 2<r,e>` (same ordering of
+// candidates as `-2 r@e^T + |e|^2`, models/hilcodec/vector_quantize.py:146-152); the arg-min keeps
+// the LOWEST index among equal distances (torch CPU `min(dim)` behaviour) through a
+// lexicographic (distance, index) wave64 shuffle reduction followed by a 4-wave LDS reduction.
+#include "common.h"
+
+namespace {
+
+constexpr int FR = 16;   // frames per workgroup
+constexpr int RS = 20;   // LDS row stride (floats) of the [c][frame] tiles: 16-B aligned, spreads banks
+constexpr int CPT = 4;   // codes per thread (K / 256 for K = 1024)
+
+struct RvqArgs {
+  const float* z;
+  const float* cb;    // [Nq][K][C]
+  const float* cbt;   // [Nq][C][K]
+  const float* norms; // [Nq][K]
+  int64_t* indices;
+  float* q;
+  float* frame_err;
+  int B, C, T, K, n;
+  int channel_last, stage_major;
+};
+
+__device__ __forceinline__ long zoff(const RvqArgs& a, long g, int c) {
+  if (a.channel_last) return g * a.C + c;
+  long b = g / a.T;
+  long t = g - b * a.T;
+  return (b * a.C + c) * (long)a.T + t;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
+  __shared__ __attribute__((aligned(16))) float res[C][RS];
+  __shared__ __attribute__((aligned(16))) float qsum[C][RS];
+  __shared__ float wbest[4][FR];
+  __shared__ int widx[4][FR];
+  __shared__ int sel[FR];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const long nframes = (long)a.B * a.T;
+  const long g0 = (long)blockIdx.x * FR;
+
+  for (int e = tid; e < FR * C; e += 256) {
+    int f = e % FR, c = e / FR;
+    long g = g0 + f;
+    res[c][f] = g < nframes ? a.z[zoff(a, g, c)] : 0.f;
+    qsum[c][f] = 0.f;
+  }
+  __syncthreads();
+
+  for (int s = 0; s < a.n; ++s) {
+    const float* cbt = a.cbt + (long)s * C * a.K;
+    const float* cb = a.cb + (long)s * a.K * C;
+    const float* nrm = a.norms + (long)s * a.K;
+
+    float acc[CPT][FR];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+      for (int f = 0; f < FR; ++f) acc[j][f] = 0.f;
+
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+      float e[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) e[j] = cbt[(long)c * a.K + tid + 256 * j];
+      float r[FR];
+#pragma unroll
+      for (int f4 = 0; f4 < FR; f4 += 4) {
+        float4 v = *reinterpret_cast<const float4*>(&res[c][f4]);
+        r[f4] = v.x; r[f4 + 1] = v.y; r[f4 + 2] = v.z; r[f4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j)
+#pragma unroll
+        for (int f = 0; f < FR; ++f) acc[j][f] = fmaf(r[f], e[j], acc[j][f]);
+    }
+
+    float nk[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) nk[j] = nrm[tid + 256 * j];
+
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+      float best = fmaf(-2.f, acc[0][f], nk[0]);
+      int bi = tid;
+#pragma unroll
+      for (int j = 1; j < CPT; ++j) {
+        float d = fmaf(-2.f, acc[j][f], nk[j]);
+        if (d < best) { best = d; bi = tid + 256 * j; }   // ascending index order, strict <
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        float od = __shfl_xor(best, m, 64);
+        int oi = __shfl_xor(bi, m, 64);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+      }
+      if (lane == 0) { wbest[wave][f] = best; widx[wave][f] = bi; }
+    }
+    __syncthreads();
+    if (tid < FR) {
+      float best = wbest[0][tid];
+      int bi = widx[0][tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        float od = wbest[w][tid];
+        int oi = widx[w][tid];
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+      }
+      sel[tid] = bi;
+      long g = g0 + tid;
+      if (g < nframes) {
+        long b = g / a.T, t = g - b * a.T;
+        long off = a.stage_major ? ((long)s * a.B + b) * a.T + t : (b * a.n + s) * (long)a.T + t;
+        a.indices[off] = bi;
+      }
+    }
+    __syncthreads();
+    // residual -= E[idx]; quantized_out += E[idx]   (vector_quantize.py:225-229)
+    for (int e = tid; e < FR * C; e += 256) {
+      int c = e % C, f = e / C;
+      float qv = cb[(long)sel[f] * C + c];
+      res[c][f] = res[c][f] - qv;
+      qsum[c][f] = qsum[c][f] + qv;
+    }
+    __syncthreads();
+  }
+
+  for (int e = tid; e < FR * C; e += 256) {
+    int f = e % FR, c = e / FR;
+    long g = g0 + f;
+    if (g < nframes && a.q != nullptr) a.q[zoff(a, g, c)] = qsum[c][f];
+  }
+  if (a.frame_err != nullptr && tid < FR) {
+    long g = g0 + tid;
+    if (g < nframes) {
+      float err = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float d = a.z[zoff(a, g, c)] - qsum[c][tid];
+        err = fmaf(d, d, err);
+      }
+      a.frame_err[g] = err;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_finalize_kernel(const float* frame_err, float* loss, int frames,
+                                                           double count) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < frames; i += 256) s += (double)frame_err[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if (threadIdx.x < m) part[threadIdx.x] += part[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(part[0] / count);
+}
+
+struct DeqArgs {
+  const int64_t* indices;
+  const float* cb;
+  float* q;
+  int B, C, T, K, n;
+  int channel_last, stage_major;
+};
+
+__global__ __launch_bounds__(256) void rvq_decode_kernel(DeqArgs a) {
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)a.B * a.T * a.C;
+  if (e >= total) return;
+  long b, t;
+  int c;
+  if (a.channel_last) {  // e = (b*T + t)*C + c
+    c = (int)(e % a.C);
+    long g = e / a.C;
+    b = g / a.T; t = g - b * a.T;
+  } else {               // e = (b*C + c)*T + t
+    t = e % a.T;
+    long bc = e / a.T;
+    c = (int)(bc % a.C);
+    b = bc / a.C;
+  }
+  float acc = 0.f;
+  for (int s = 0; s < a.n; ++s) {
+    long ioff = a.stage_major ? ((long)s * a.B + b) * a.T + t : (b * a.n + s) * (long)a.T + t;
+    long k = a.indices[ioff];
+    k = k < 0 ? 0 : (k >= a.K ? a.K - 1 : k);
+    acc = acc + a.cb[((long)s * a.K + k) * a.C + c];
+  }
+  a.q[e] = acc;
+}
+
+}  // namespace
+
+extern "C" int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t,
+                               const float* norms, int64_t* indices, float* q, float* frame_err, int B, int C,
+                               int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream) {
+  if (!z || !codebooks || !codebooks_t || !norms || !indices) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || Nq <= 0) return HILC_ERR_SHAPE;
+  if (n < 1 || n > Nq) return HILC_ERR_RANGE;
+  if (C != 128 || K != 256 * CPT) return HILC_ERR_UNSUPPORTED;
+  RvqArgs a;
+  a.z = z; a.cb = codebooks; a.cbt = codebooks_t; a.norms = norms; a.indices = indices; a.q = q;
+  a.frame_err = frame_err; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
+  a.channel_last = channel_last; a.stage_major = stage_major;
+  long nframes = (long)B * T;
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(rvq_encode_kernel<128>, dim3((unsigned)((nframes + FR - 1) / FR)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream) {
+  if (!frame_err || !loss) return HILC_ERR_NULL;
+  if (frames <= 0 || count <= 0) return HILC_ERR_SHAPE;
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, frame_err, loss, frames, count);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T, int K,
+                               int Nq, int n, int channel_last, int stage_major, void* stream) {
+  if (!indices || !codebooks || !q) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || Nq <= 0) return HILC_ERR_SHAPE;
+  if (n < 1 || n > Nq) return HILC_ERR_RANGE;
+  DeqArgs a;
+  a.indices = indices; a.cb = codebooks; a.q = q; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
+  a.channel_last = channel_last; a.stage_major = stage_major;
+  long total = (long)B * T * C;
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_abi_version(void) { return HILC_ABI_VERSION; }
+
+extern "C" const char* hilc_error_string(int code) {
+  switch (code) {
+    case HILC_OK: return "ok";
+    case HILC_ERR_SHAPE: return "bad shape (a dimension is <= 0 or inconsistent)";
+    case HILC_ERR_NULL: return "required pointer is NULL";
+    case HILC_ERR_LAUNCH: return "HIP kernel launch failed";
+    case HILC_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+    case HILC_ERR_RANGE: return "'n' must be in range of 1 <= n <= num_quantizers";
+    default: return "unknown error";
+  }
+}

@@ -1,0 +1,232 @@
+"""Execution plans for the HILCodec hot path on MI355X.
+
+A *spec* is the folded, device-resident description of one sub-network (encoder / decoder / RVQ):
+plain fp32 weights in kernel layouts plus the handful of scalars the reference applies around them.
+`run_encoder` / `run_decoder` walk a spec and enqueue the hand-written gfx950 kernels (`ops.py` ->
+C ABI) on the current HIP stream; with `caches=None` they compute the offline causal model
+(`models/hilcodec/modules/seanet.py:368-378,477-479`), with a cache list they compute one streaming
+step with the reference's cache protocol (`models/hilcodec/streaming.py:482-517,619-648`).  Both
+behaviours of the reference's two decoders are data in the spec (per-block
+`pre_scale`, where wav_std is applied), not code forks.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+@dataclass
+class ResBlockSpec:
+    pw1_wt: Tensor
+    dw1_w: Tensor
+    dw1_b: Optional[Tensor]
+    pw2_wt: Tensor
+    dw2_w: Tensor
+    dw2_b: Optional[Tensor]
+    pre_scale: float        # (1 + idx*res_scale^2)^-1/2  (seanet.py:84), 1.0 in the streaming decoder
+    out_scale: float        # res_scale * res_scale_param (seanet.py:144-148); 1.0 when merged into dw2
+
+
+@dataclass
+class SpecBlockSpec:
+    basis_t: Tensor
+    n_fft: int
+    hop: int
+    mean: float
+    std: float
+    normalize: bool         # False when (y-mean)/std is merged into the layer (streaming.py:321-344)
+    wt: Tensor              # [n_fft/2+1, C]
+    bias: Optional[Tensor]
+    out_scale: float        # res_scale * scale_param; 1.0 when merged
+
+
+@dataclass
+class EncStageSpec:
+    spec: SpecBlockSpec
+    blocks: List[ResBlockSpec]
+    down_in_scale: float    # (1 + n_res*res_scale^2)^-1/2
+    down_pw_wt: Tensor
+    down_dw_w: Tensor
+    down_dw_b: Optional[Tensor]
+    ratio: int
+
+
+@dataclass
+class EncoderSpec:
+    pre_w: Tensor
+    pre_b: Optional[Tensor]
+    pre_in_scale: float     # 1/wav_std, or 1.0 when merged into pre_w (streaming.py:472-480)
+    stages: List[EncStageSpec]
+    spec_post: SpecBlockSpec
+    post_dw_w: Tensor
+    post_pw_wt: Tensor
+    post_pw_b: Optional[Tensor]
+    l2norm: bool
+    dim: int
+    wav_cache_len: int      # n_fft of spec_post - 1
+
+
+@dataclass
+class DecStageSpec:
+    in_scale: float         # 1.0 for the first stage, (1 + n_res*res_scale^2)^-1/2 after
+    tr_w: Tensor
+    ratio: int
+    pw_wt: Tensor
+    pw_b: Optional[Tensor]
+    blocks: List[ResBlockSpec]
+
+
+@dataclass
+class DecoderSpec:
+    pre_pw_wt: Tensor
+    pre_dw_w: Tensor
+    pre_dw_b: Optional[Tensor]
+    stages: List[DecStageSpec]
+    post_in_scale: float
+    post_w: Tensor
+    post_b: Optional[Tensor]
+    post_out_scale: float   # wav_std (offline: scales conv AND bias, seanet.py:464-466); 1.0 if merged into post_w
+    tanh: bool
+
+
+@dataclass
+class RvqSpec:
+    codebooks: Tensor       # [Nq, K, C]
+    codebooks_t: Tensor     # [Nq, C, K]
+    norms: Tensor           # [Nq, K]
+
+    @property
+    def num_quantizers(self) -> int:
+        return self.codebooks.shape[0]
+
+
+def _to(dev, *ts):
+    return [None if t is None else t.to(device=dev, dtype=torch.float32).contiguous() for t in ts]
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list]) -> Tensor:
+    """x is updated in place (the residual add writes over its own shortcut, element-wise)."""
+    h = ops.pw_conv(x, rb.pw1_wt, in_scale=rb.pre_scale, in_elu=True)
+    if caches is None:
+        g = ops.dw_conv(h, rb.dw1_w, rb.dw1_b)            # a depthwise conv must not run in place (halo reads)
+        h2 = ops.pw_conv(g, rb.pw2_wt, in_scale=1.0, in_elu=True, out=h)
+        ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x)
+    else:
+        g, c0 = ops.dw_conv(h, rb.dw1_w, rb.dw1_b, hist=caches[0], want_hist=True)
+        h2 = ops.pw_conv(g, rb.pw2_wt, in_scale=1.0, in_elu=True)
+        _, c1 = ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x,
+                            hist=caches[1], want_hist=True)
+        new_caches.extend([c0, c1])
+    return x
+
+
+def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
+    s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+    return ops.pw_conv(s, sb.wt, sb.bias, res=x, out=x, out_scale=sb.out_scale)
+
+
+def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]] = None,
+                channel_last_out: bool = False):
+    """wav `[B,1,T]` -> z `[B,dim,ceil(T/hop)]` (or `[B,T',dim]`), and the new cache list if streaming."""
+    if wav.dim() != 3 or wav.shape[1] != 1:
+        raise RuntimeError(f"expected [B,1,T] waveform, got {tuple(wav.shape)}")
+    wav = wav.contiguous().float()
+    streaming = caches is not None
+    new_caches: Optional[list] = [] if streaming else None
+    wav_hist = None
+    ci = 0
+    if streaming:
+        wav_hist = caches[0].contiguous()
+        new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len))
+        ci = 1
+    x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
+    for st in es.stages:
+        x = _spec_block(st.spec, x, wav, wav_hist)
+        for rb in st.blocks:
+            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
+            ci += 2
+        h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
+        if streaming:
+            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True)
+            new_caches.append(c)
+        else:
+            x = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio)
+        ci += 1
+    x = _spec_block(es.spec_post, x, wav, wav_hist)
+    if streaming:
+        h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True)
+        new_caches.append(c)
+    else:
+        h = ops.dw_conv(x, es.post_dw_w, None, in_elu=True)
+    h = ops.pw_conv(h, es.post_pw_wt, es.post_pw_b)
+    if es.l2norm:
+        z = ops.l2norm(h, eps=1e-12, scale=float(es.dim) ** 0.5, channel_last_out=channel_last_out)
+    else:
+        z = h.transpose(1, 2).contiguous() if channel_last_out else h
+    return (z, new_caches) if streaming else z
+
+
+def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] = None):
+    """q `[B,dim,F]` (channel-major) -> wav `[B,1,F*hop]`, and the new cache list if streaming."""
+    streaming = caches is not None
+    new_caches: Optional[list] = [] if streaming else None
+    q = q.contiguous().float()
+    h = ops.pw_conv(q, ds.pre_pw_wt)
+    ci = 0
+    if streaming:
+        x, c = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b, hist=caches[0], want_hist=True)
+        new_caches.append(c)
+    else:
+        x = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b)
+    ci = 1
+    for st in ds.stages:
+        if streaming:
+            u, c = ops.dw_convtr(x, st.tr_w, st.ratio, hist=caches[ci], want_hist=True,
+                                 in_scale=st.in_scale, in_elu=True)
+            new_caches.append(c)
+        else:
+            u = ops.dw_convtr(x, st.tr_w, st.ratio, in_scale=st.in_scale, in_elu=True)
+        ci += 1
+        x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        for rb in st.blocks:
+            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
+            ci += 2
+    if streaming:
+        wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
+                               out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True)
+        new_caches.append(c)
+        return wav, new_caches
+    return ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
+                         out_scale=ds.post_out_scale, do_tanh=ds.tanh)
+
+
+def encoder_cache_shapes(es: EncoderSpec) -> List[Tuple[int, int]]:
+    """(channels, length) per cache, order of `Encoder.initialize_cache` (streaming.py:458-470)."""
+    out = [(1, es.wav_cache_len)]
+    for st in es.stages:
+        for rb in st.blocks:
+            c = rb.dw1_w.shape[0]
+            out += [(c, rb.dw1_w.shape[1] - 1), (c, rb.dw2_w.shape[1] - 1)]
+        out.append((st.down_dw_w.shape[0], st.down_dw_w.shape[1] - st.ratio))
+    out.append((es.post_dw_w.shape[0], es.post_dw_w.shape[1] - 1))
+    return out
+
+
+def decoder_cache_shapes(ds: DecoderSpec) -> List[Tuple[int, int]]:
+    """Order of `Decoder.initialize_cache` (streaming.py:599-607)."""
+    out = [(ds.pre_dw_w.shape[0], ds.pre_dw_w.shape[1] - 1)]
+    for st in ds.stages:
+        out.append((st.tr_w.shape[0], 1))
+        for rb in st.blocks:
+            c = rb.dw1_w.shape[0]
+            out += [(c, rb.dw1_w.shape[1] - 1), (c, rb.dw2_w.shape[1] - 1)]
+    out.append((ds.post_w.shape[0], ds.post_w.shape[1] - 1))
+    return out

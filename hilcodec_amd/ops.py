@@ -1,0 +1,161 @@
+"""Thin Python wrappers: torch CUDA(HIP) tensors -> device pointers -> C ABI (`include/hilcodec_amd.h`).
+
+PyTorch is used for device memory and the current stream only; every arithmetic step runs in the
+hand-written gfx950 kernels of `csrc/`.  All tensors must be fp32 (indices int64), contiguous, on a
+GPU; anything else raises — there is deliberately no fallback path."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from ._lib import check, lib
+
+
+def _ptr(t: Optional[Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("hilcodec_amd ops need GPU tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
+            out: Optional[Tensor] = None, in_scale: float = 1.0, in_elu: bool = False,
+            out_scale: float = 1.0) -> Tensor:
+    """x `[B,K,T]`, wt `[K,M]` -> `[B,M,T]`; see hilc_pw_conv."""
+    B, K, T = x.shape
+    M = wt.shape[1]
+    assert wt.shape[0] == K
+    y = out if out is not None else torch.empty(B, M, T, device=x.device, dtype=torch.float32)
+    check(lib.hilc_pw_conv(_ptr(x), _ptr(wt), _ptr(bias), _ptr(res), _ptr(y), B, K, M, T,
+                           in_scale, int(in_elu), out_scale, _stream()), "hilc_pw_conv")
+    return y
+
+
+def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
+            stride: int = 1, hist: Optional[Tensor] = None, want_hist: bool = False,
+            in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False,
+            out: Optional[Tensor] = None):
+    """x `[B,C,T]`, w `[C,k]` -> `[B,C,ceil(T/stride)]` (+ new history `[B,C,k-stride]` if want_hist)."""
+    B, Cc, T = x.shape
+    k = w.shape[1]
+    To = (T + stride - 1) // stride
+    y = out if out is not None else torch.empty(B, Cc, To, device=x.device, dtype=torch.float32)
+    hout = torch.empty(B, Cc, k - stride, device=x.device, dtype=torch.float32) if want_hist else None
+    check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hout),
+                           B, Cc, T, k, stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()),
+          "hilc_dw_conv")
+    return (y, hout) if want_hist else y
+
+
+def dw_convtr(x: Tensor, w: Tensor, stride: int, hist: Optional[Tensor] = None, want_hist: bool = False,
+              in_scale: float = 1.0, in_elu: bool = False):
+    """x `[B,C,T]`, w `[C,2*stride]` -> `[B,C,T*stride]`."""
+    B, Cc, T = x.shape
+    assert w.shape[1] == 2 * stride
+    y = torch.empty(B, Cc, T * stride, device=x.device, dtype=torch.float32)
+    hout = torch.empty(B, Cc, 1, device=x.device, dtype=torch.float32) if want_hist else None
+    check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hout), B, Cc, T, stride,
+                             in_scale, int(in_elu), _stream()), "hilc_dw_convtr")
+    return (y, hout) if want_hist else y
+
+
+def conv_pre(wav: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0,
+             hist: Optional[Tensor] = None) -> Tensor:
+    """wav `[B,1,T]`, w `[C,k]` -> `[B,C,T]`; hist `[B,1,L]` (L >= k-1) = waveform history."""
+    B, one, T = wav.shape
+    assert one == 1
+    Cc, k = w.shape
+    y = torch.empty(B, Cc, T, device=wav.device, dtype=torch.float32)
+    hl = hist.shape[-1] if hist is not None else 0
+    check(lib.hilc_conv_pre(_ptr(wav), _ptr(hist), hl, _ptr(w), _ptr(bias), _ptr(y), B, Cc, T, k,
+                            in_scale, _stream()), "hilc_conv_pre")
+    return y
+
+
+def conv_post(x: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0, in_elu: bool = True,
+              out_scale: float = 1.0, do_tanh: bool = True, hist: Optional[Tensor] = None,
+              want_hist: bool = False):
+    """x `[B,C,T]`, w `[C,k]` -> `[B,1,T]`."""
+    B, Cc, T = x.shape
+    k = w.shape[1]
+    y = torch.empty(B, 1, T, device=x.device, dtype=torch.float32)
+    hout = torch.empty(B, Cc, k - 1, device=x.device, dtype=torch.float32) if want_hist else None
+    check(lib.hilc_conv_post(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(y), _ptr(hout), B, Cc, T, k,
+                             in_scale, int(in_elu), out_scale, int(do_tanh), _stream()), "hilc_conv_post")
+    return (y, hout) if want_hist else y
+
+
+def stft_logmag(wav: Tensor, basis_t: Tensor, n_fft: int, hop: int, mean: float = 0.0, std: float = 1.0,
+                normalize=True, hist: Optional[Tensor] = None) -> Tensor:
+    """wav `[B,1,T]` -> `[B, n_fft/2+1, (T-1)//hop+1]`; normalize: False/0 log-mag, True/1 (log-mag - mean)/std,
+    2 plain magnitude."""
+    B, one, T = wav.shape
+    Tf = (T - 1) // hop + 1
+    spec = torch.empty(B, n_fft // 2 + 1, Tf, device=wav.device, dtype=torch.float32)
+    hl = hist.shape[-1] if hist is not None else 0
+    check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
+                               mean, std, int(normalize), _stream()), "hilc_stft_logmag")
+    return spec
+
+
+def tail(x: Tensor, hist: Optional[Tensor], pad: int) -> Tensor:
+    """Last `pad` samples of cat([hist, x], -1) along time; x `[B,C,T]`, hist `[B,C,L]`."""
+    B, Cc, T = x.shape
+    out = torch.empty(B, Cc, pad, device=x.device, dtype=torch.float32)
+    hl = hist.shape[-1] if hist is not None else 0
+    check(lib.hilc_tail(_ptr(x), _ptr(hist), _ptr(out), B * Cc, T, pad, hl, _stream()), "hilc_tail")
+    return out
+
+
+def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: bool = False) -> Tensor:
+    B, Cc, T = x.shape
+    y = torch.empty((B, T, Cc) if channel_last_out else (B, Cc, T), device=x.device, dtype=torch.float32)
+    check(lib.hilc_l2norm(_ptr(x), _ptr(y), B, Cc, T, eps, scale, int(channel_last_out), _stream()), "hilc_l2norm")
+    return y
+
+
+def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor, n: int,
+               channel_last: bool = False, stage_major: bool = False, want_q: bool = True,
+               want_loss: bool = False):
+    """Returns (indices int64, q or None, loss 0-d or None)."""
+    if channel_last:
+        B, T, Cc = z.shape
+    else:
+        B, Cc, T = z.shape
+    Nq, K, _ = codebooks.shape
+    nn = max(1, min(n, Nq))
+    idx = torch.empty((nn, B, T) if stage_major else (B, nn, T), device=z.device, dtype=torch.int64)
+    q = torch.empty_like(z) if want_q else None
+    ferr = torch.empty(B * T, device=z.device, dtype=torch.float32) if want_loss else None
+    check(lib.hilc_rvq_encode(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
+                              _ptr(idx, torch.int64), _ptr(q), _ptr(ferr), B, Cc, T, K, Nq, n,
+                              int(channel_last), int(stage_major), _stream()), "hilc_rvq_encode")
+    loss = None
+    if want_loss:
+        loss = torch.empty((), device=z.device, dtype=torch.float32)
+        check(lib.hilc_mse_finalize(_ptr(ferr), _ptr(loss), B * T, float(B) * T * Cc, _stream()), "hilc_mse_finalize")
+    return idx, q, loss
+
+
+def rvq_decode(indices: Tensor, codebooks: Tensor, n: int, channel_last: bool = True,
+               stage_major: bool = True) -> Tensor:
+    if stage_major:
+        _, B, T = indices.shape
+    else:
+        B, _, T = indices.shape
+    Nq, K, Cc = codebooks.shape
+    q = torch.empty((B, T, Cc) if channel_last else (B, Cc, T), device=indices.device, dtype=torch.float32)
+    check(lib.hilc_rvq_decode(_ptr(indices, torch.int64), _ptr(codebooks), _ptr(q), B, Cc, T, K, Nq, n,
+                              int(channel_last), int(stage_major), _stream()), "hilc_rvq_decode")
+    return q

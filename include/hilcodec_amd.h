@@ -1,0 +1,132 @@
+/* hilcodec_amd.h — C ABI of the MI355X-native HILCodec encode -> RVQ -> decode hot path.
+ *
+ * The reference (aask1357/hilcodec) is pure Python/PyTorch and has NO FFI: its hot path sits behind
+ * nn.Module classes and bottoms out in ATen calls.  This header therefore declares the entry points
+ * a binding of that path would need: one per arithmetic step of the folded graph (SURVEY.md
+ * Appendix A).  Each entry cites the reference code it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes stub that binds them from the reference's modules.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in this repo);
+ *    the library allocates nothing, keeps no global state, and is re-entrant;
+ *  - tensors are dense fp32, channel-major `[B][C][T]` (time contiguous) unless stated;
+ *  - `stream` is a `hipStream_t` passed as `void*`; all work is enqueued on it, nothing syncs;
+ *  - return value: HILC_OK (0) or a negative HILC_ERR_* code; nothing is launched on error;
+ *  - "hist" arguments are the streaming caches of `models/hilcodec/causal_layers.py:147-188`
+ *    (the samples *before* t = 0 of the layer's input); NULL means zero history, which is the
+ *    causal zero padding of the offline model (`models/hilcodec/modules/conv.py:222-236`).
+ *  - prologue  pro(v) = in_elu ? ELU(v * in_scale) : v * in_scale   (Scale + ELU modules,
+ *    `models/hilcodec/modules/seanet.py:165-178`, torch.nn.ELU(alpha=1));
+ *    it is applied to `x` only — histories hold already-activated samples, as the reference's
+ *    caches do.
+ */
+#ifndef HILCODEC_AMD_H
+#define HILCODEC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HILC_OK 0
+#define HILC_ERR_SHAPE (-1)       /* a dimension is <= 0 or inconsistent            */
+#define HILC_ERR_NULL (-2)        /* a required pointer is NULL                     */
+#define HILC_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after launch   */
+#define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
+#define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
+
+#define HILC_ABI_VERSION 1
+
+int hilc_abi_version(void);
+const char* hilc_error_string(int code);
+
+/* ---- pointwise (1x1) convolution: fp32-MFMA GEMM with fused prologue / epilogue ----------------
+ * y[b,m,t] = (sum_k wt[k][m] * pro(x[b,k,t]) + bias[m]) * out_scale + res[b,m,t]
+ * Replaces: nn.Conv1d(k=1) inside SConv1d/NormConv1d (`models/hilcodec/modules/conv.py:115-134,
+ * 202-236`) plus the ELU / Scale in front of it (`seanet.py:26-52,322-340`) and, with `res`, the
+ * `x.add_(y.mul_(scale))` of SpecBlock (`seanet.py:241-246`).
+ * wt is the folded weight TRANSPOSED to `[K][M]` (k-major).  bias, res may be NULL.  res may alias y. */
+int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
+                 int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, void* stream);
+
+/* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
+ * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)
+ * y[b,c,o] = post((sum_j w[c][j] * xe[b,c,o*stride - pad + j] + bias[c]) * out_scale + res[b,c,o])
+ * xe(t) = t < 0 ? hist[b,c,pad+t] (0 if hist NULL) : t < T ? pro(x[b,c,t]) : 0 ; post = ELU if out_elu.
+ * hist_out (optional) receives the last `pad` samples of [hist | pro(x)]  -> next call's hist.
+ * Replaces: depthwise SConv1d (`conv.py:202-236`, groups=C: `seanet.py:42-51,330-339,352-355,
+ * 417-419`), CausalConv1d (`causal_layers.py:147-165`) and the residual tail of
+ * SEANetResnetBlock.forward (`seanet.py:144-148`). res may alias y. */
+int hilc_dw_conv(const float* x, const float* hist, const float* w, const float* bias, const float* res,
+                 float* y, float* hist_out, int B, int C, int T, int ksize, int stride,
+                 float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
+
+/* ---- depthwise causal transposed convolution, kernel 2*stride, stride `stride` -----------------
+ * y[b,c,q*stride+p] = w[c][p] * xe[q] + w[c][p+stride] * xe[q-1],  T_out = T*stride,
+ * xe(-1) = hist[b,c,0] (0 if NULL).  hist_out (optional) receives pro(x[b,c,T-1]).
+ * Replaces: SConvTranspose1d (`conv.py:239-282`, right-trim k-s) and CausalConvTranspose1d
+ * (`causal_layers.py:168-188`) for groups=C, k=2s, plus the Scale+ELU in front (`seanet.py:424-441`). */
+int hilc_dw_convtr(const float* x, const float* hist, const float* w, float* y, float* hist_out,
+                   int B, int C, int T, int stride, float in_scale, int in_elu, void* stream);
+
+/* ---- first encoder conv: Conv1d(1 -> C, ksize, causal, bias) on the waveform --------------------
+ * y[b,c,t] = sum_j w[c][j] * (in_scale * we[b, t-(ksize-1)+j]) + bias[c];  we(t<0) = hist[b, hist_len+t] or 0.
+ * Replaces: `seanet.py:280-286` (Scale(1/wav_std) + SConv1d) / `streaming.py:490`. */
+int hilc_conv_pre(const float* wav, const float* hist, int hist_len, const float* w, const float* bias,
+                  float* y, int B, int C, int T, int ksize, float in_scale, void* stream);
+
+/* ---- last decoder conv: [Scale, ELU,] Conv1d(C -> 1, ksize, causal, bias), * out_scale, tanh -----
+ * y[b,0,t] = act((sum_c sum_j w[c][j] * xe[b,c,t-(ksize-1)+j] + bias[0]) * out_scale), act = tanh if do_tanh.
+ * Replaces: `seanet.py:457-473` / `streaming.py:643-647`. hist/hist_out as in hilc_dw_conv. */
+int hilc_conv_post(const float* x, const float* hist, const float* w, const float* bias, float* y,
+                   float* hist_out, int B, int C, int T, int ksize, float in_scale, int in_elu,
+                   float out_scale, int do_tanh, void* stream);
+
+/* ---- causal STFT magnitude -> log -> normalise (the front half of a SpecBlock) ------------------
+ * frame f covers we[b, f*hop-(n_fft-1) .. f*hop];  T_f = (T-1)/hop + 1;
+ * mag = sqrt(max(re^2+im^2,1e-12));  spec[b,k,f] = normalize==2 ? mag : log(max(mag,1e-5)), then
+ * (. - mean)/std if normalize==1 (0: plain log-magnitude, streaming model with merged normalisation)
+ * basis_t: `[n_fft][m_pad]` fp32, row n holds (cos_0, sin_0, cos_1, sin_1, ...)*hann for sample n,
+ *          m_pad = round_up(n_fft+2, 32), zero padded (host-built from the reference's basis).
+ * Replaces: CausalSTFT (`conv.py:285-358`, `causal_layers.py:72-144`) + `seanet.py:224-236`. */
+int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const float* basis_t, float* spec,
+                     int B, int T, int n_fft, int hop, float mean, float std, int normalize, void* stream);
+
+/* ---- streaming cache update: out[row][i] = last `pad` samples of [hist[row][0..hist_len) | x[row][0..T)] ----
+ * Replaces: `cache = x[:, :, -causal_padding:]` after `torch.cat((cache, x), dim=2)`
+ * (`causal_layers.py:160-162`, waveform cache `streaming.py:486-488`). hist may be NULL (zeros). */
+int hilc_tail(const float* x, const float* hist, float* out, long rows, int T, int pad, int hist_len,
+              void* stream);
+
+/* ---- L2 normalisation over channels: y = x / max(||x||_2, eps) * scale ---------------------------
+ * x `[B][C][T]`; y `[B][C][T]` or, if channel_last_out, `[B][T][C]` (streaming encoder output).
+ * Replaces: L2Norm (`seanet.py:151-162`, `streaming.py:279-286`). */
+int hilc_l2norm(const float* x, float* y, int B, int C, int T, float eps, float scale,
+                int channel_last_out, void* stream);
+
+/* ---- residual VQ encode ------------------------------------------------------------------------
+ * for i < n:  idx_i = argmin_k(norms[i][k] - 2 * <r, E_i[k]>) (first minimum), r -= E_i[idx_i], q += E_i[idx_i]
+ * z: `[B][C][T]` (channel_last=0) or `[B][T][C]` (1).  codebooks `[Nq][K][C]`, codebooks_t `[Nq][C][K]`
+ * (the same tables transposed, for coalesced scoring), norms `[Nq][K]` = |E|^2 (host: embed.pow(2).sum).
+ * indices int64: `[B][n][T]` (stage_major=0, offline return_indices) or `[n][B][T]` (1, streaming).
+ * q (optional) same layout as z.  frame_err (optional) `[B*T]` receives sum_c (z-q)^2 per frame.
+ * Replaces: EuclideanCodebook.forward + ResidualVQ.forward eval branch
+ * (`models/hilcodec/vector_quantize.py:132-176,199-243`, `modules/vector_quantize.py:141-195,490-516`,
+ * `models/hilcodec/streaming.py:51-68,89-100`).  Returns HILC_ERR_RANGE unless 1 <= n <= Nq. */
+int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t, const float* norms,
+                    int64_t* indices, float* q, float* frame_err, int B, int C, int T, int K, int Nq, int n,
+                    int channel_last, int stage_major, void* stream);
+
+/* mean over `count` of frame_err[0..frames) in a fixed order -> loss[0]  (F.mse_loss, `vector_quantize.py:233`) */
+int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream);
+
+/* ---- residual VQ decode (Dequantizer): q = sum_{i<n} E_i[idx_i] ---------------------------------
+ * Replaces: Dequantizer.forward (`streaming.py:148-157`) / F.embedding sums in ResidualVQ. */
+int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T,
+                    int K, int Nq, int n, int channel_last, int stage_major, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HILCODEC_AMD_H */

@@ -1,0 +1,234 @@
+"""GPU parity, per kernel: every C-ABI entry point (through hilcodec_amd.ops / the module classes)
+against (a) the golden known-answer vectors produced by the REAL reference (tests/golden/ops.npz)
+and (b) the CPU oracle on seeded inputs at larger, awkward shapes.
+
+Tolerances (fp32, written per op): a conv differs from the oracle only by fp32 summation order
+(the reference uses oneDNN on CPU, the kernels an fmaf chain in k order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hilcodec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RS = 0.5773502691896258
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def env():
+    from hilcodec_amd import fold, ops
+    from oracle import hilcodec_oracle as O
+    return ops, fold, O, torch.device("cuda:0")
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(synth.normalish(seed, int(np.prod(shape)))).view(*shape)
+
+
+def close(a, b, atol, what=""):
+    a = a.detach().cpu()
+    d = (a - b).abs().max().item()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert d <= atol, f"{what}: max abs diff {d:.3e} > {atol:.1e}"
+
+
+def sub(g, tag):
+    pre = tag + "."
+    return {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+
+
+def test_golden_ops(env, golden):
+    ops, fold, O, dev = env
+    g = golden("ops")
+    d = sub(g, "pw")
+    w, b = O.conv_weight(d, "conv.conv")
+    y = ops.pw_conv(d["x"].to(dev), fold.pointwise_layout(w).to(dev), b.to(dev), in_elu=True)
+    close(y, d["y"], 2e-6, "pw")
+    d = sub(g, "dw5")
+    w, b = O.conv_weight(d, "conv.conv")
+    close(ops.dw_conv(d["x"].to(dev), fold.depthwise_layout(w).to(dev), b.to(dev)), d["y"], 2e-6, "dw5")
+    for r in (2, 4, 5, 8):
+        d = sub(g, f"dws{r}")
+        w, b = O.conv_weight(d, "conv.conv")
+        close(ops.dw_conv(d["x"].to(dev), fold.depthwise_layout(w).to(dev), b.to(dev), stride=r), d["y"], 2e-6, f"dws{r}")
+        d = sub(g, f"dwt{r}")
+        w, _ = O.conv_weight(d, "convtr.convtr")
+        close(ops.dw_convtr(d["x"].to(dev), fold.depthwise_layout(w).to(dev), r), d["y"], 2e-6, f"dwt{r}")
+    d = sub(g, "pre")
+    w, b = O.conv_weight(d, "conv.conv")
+    close(ops.conv_pre(d["x"].to(dev), w[:, 0, :].contiguous().to(dev), b.to(dev)), d["y"], 2e-6, "pre")
+    d = sub(g, "post")
+    w, b = O.conv_weight(d, "conv.conv")
+    close(ops.conv_post(d["x"].to(dev), w[0].contiguous().to(dev), b.to(dev), in_elu=False, do_tanh=False),
+          d["y"], 4e-6, "post")
+    for n_fft, hop in ((16, 1), (32, 4)):
+        d = sub(g, f"spec{n_fft}")
+        bt = fold.stft_basis_layout(d["spec.weight"]).to(dev)
+        mag = ops.stft_logmag(d["wav"].to(dev), bt, n_fft, hop, normalize=2)
+        close(mag, d["mag"], 2e-6, "stft mag")
+        w, _ = O.conv_weight(d, "layer.conv.conv")
+        s = ops.stft_logmag(d["wav"].to(dev), bt, n_fft, hop, -4.0, 2.8, True)
+        scale = float((d["scale_param"] * RS)[0])
+        y = ops.pw_conv(s, fold.pointwise_layout(w).to(dev), None, res=d["x"].to(dev), out_scale=scale)
+        # log of a tiny magnitude amplifies its fp32 rounding: compare where the reference mag is not tiny
+        close(y, d["y"], 2e-4, "specblock")
+    d = sub(g, "l2")
+    close(ops.l2norm(d["x"].to(dev), 1e-12, 128 ** 0.5), d["y"], 1e-6, "l2norm")
+    close(ops.l2norm(d["x"].to(dev), 1e-12, 128 ** 0.5, channel_last_out=True), d["y"].transpose(1, 2), 1e-6, "l2norm cl")
+    d = sub(g, "cconv")
+    y, c = ops.dw_conv(d["x"].to(dev), d["w"][:, 0].contiguous().to(dev), d["b"].to(dev), stride=5,
+                       hist=d["cache"].to(dev), want_hist=True)
+    close(y, d["y"], 2e-6, "cconv")
+    assert torch.equal(c.cpu(), d["cache_out"])
+    d = sub(g, "cconvtr")
+    y, c = ops.dw_convtr(d["x"].to(dev), d["w"][:, 0].contiguous().to(dev), 5, hist=d["cache"].to(dev), want_hist=True)
+    close(y, d["y"], 2e-6, "cconvtr")
+    assert torch.equal(c.cpu(), d["cache_out"])
+
+
+def test_golden_resblock_modules(env, golden):
+    """The module classes (reference names / state-dict keys) against the reference's own outputs."""
+    ops, fold, O, dev = env
+    from hilcodec_amd.models.hilcodec.modules import SEANetResnetBlock, SpecBlock, SConv1d
+    g = golden("ops")
+    for idx in (0, 1, 2):
+        d = sub(g, f"res{idx}")
+        m = SEANetResnetBlock(16, kernel_size=5, dilations=[1, 1], norm="weight_norm", causal=True,
+                              skip="identity", res_scale=RS, idx=idx, zero_init=True)
+        sd = {k: v for k, v in d.items() if k not in ("x", "y")}
+        m.load_state_dict(sd)
+        close(m(d["x"].to(dev)), d["y"], 5e-6, f"resblock idx{idx}")
+    for n_fft, hop in ((16, 1), (32, 4)):
+        d = sub(g, f"spec{n_fft}")
+        m = SpecBlock("stft", "log", n_fft, 8, hop, "weight_norm", {}, bias=False, pad_mode="constant",
+                      learnable=False, causal=True, mean=-4.0, std=2.8, res_scale=RS)
+        m.load_state_dict({k: v for k, v in d.items() if k not in ("x", "y", "wav", "mag")})
+        close(m(d["x"].to(dev), d["wav"].to(dev)), d["y"], 2e-4, "SpecBlock module")
+    d = sub(g, "dw5")
+    m = SConv1d(24, 24, 5, groups=24, causal=True, norm="weight_norm", bias=True)
+    m.load_state_dict({k: v for k, v in d.items() if k not in ("x", "y")})
+    close(m(d["x"].to(dev)), d["y"], 2e-6, "SConv1d dw")
+    d = sub(g, "ws")
+    m = SConv1d(6, 10, 3, groups=1, causal=True, norm="weight_standardization", norm_kwargs={"scale": 1.7}, bias=True)
+    with torch.no_grad():
+        m.conv.conv.weight_v.copy_(d["v"]); m.conv.conv.weight_g.copy_(d["g"])
+    assert torch.equal(m.conv.conv.effective_weight(), d["w"])
+
+
+@pytest.mark.parametrize("B,K,M,Tn", [(3, 64, 64, 1000), (2, 96, 96, 601), (2, 33, 64, 75), (1, 1024, 128, 75),
+                                      (2, 128, 1536, 75), (2, 257, 512, 40), (1, 768, 384, 360), (5, 192, 192, 128)])
+def test_pw_conv_vs_oracle(env, B, K, M, Tn):
+    ops, fold, O, dev = env
+    x = rnd(B * 7 + K, B, K, Tn)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    b = rnd(M, M) * 0.1
+    r = rnd(3, B, M, Tn)
+    ref = (F.conv1d(F.elu(x * 0.77), w, b) * 0.61 + r)
+    y = ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev), b.to(dev), res=r.to(dev), in_scale=0.77,
+                    in_elu=True, out_scale=0.61)
+    close(y, ref, 1e-5, "pw_conv")
+    # in-place residual (SpecBlock usage), no bias, no prologue
+    r2 = r.clone().to(dev)
+    ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev), None, res=r2, out=r2, out_scale=0.5)
+    close(r2, F.conv1d(x, w) * 0.5 + r, 1e-5, "pw_conv in-place")
+
+
+def test_pw_conv_transpose_detect(env):
+    """Asymmetric weights / identity check (a swapped C layout would pass a symmetric test)."""
+    ops, fold, O, dev = env
+    K = M = 64
+    x = rnd(1, 1, K, 256)
+    w = torch.zeros(M, K, 1)
+    for m in range(M):
+        w[m, (m * 7 + 3) % K, 0] = 1.0 + m
+    y = ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev))
+    assert torch.equal(y.cpu(), F.conv1d(x, w))
+
+
+@pytest.mark.parametrize("C,Tn,k,s", [(64, 1000, 5, 1), (24, 37, 5, 1), (128, 999, 4, 2), (256, 1203, 8, 4),
+                                      (512, 77, 10, 5), (1024, 600, 16, 8), (96, 24, 5, 1)])
+def test_dw_conv_vs_oracle(env, C, Tn, k, s):
+    ops, fold, O, dev = env
+    x = rnd(C + Tn, 2, C, Tn)
+    w = rnd(C + k, C, 1, k)
+    b = rnd(C, C) * 0.1
+    ref = O.sconv1d(x, w, b, stride=s, groups=C)
+    close(ops.dw_conv(x.to(dev), w[:, 0].contiguous().to(dev), b.to(dev), stride=s), ref, 5e-6, "dw")
+    if s == 1:
+        r = rnd(5, 2, C, Tn)
+        ref2 = F.elu(O.sconv1d(F.elu(x * 0.9), w, b, groups=C) * 0.4 + r)
+        y = ops.dw_conv(x.to(dev), w[:, 0].contiguous().to(dev), b.to(dev), res=r.to(dev), in_scale=0.9,
+                        in_elu=True, out_scale=0.4, out_elu=True)
+        close(y, ref2, 5e-6, "dw fused")
+
+
+@pytest.mark.parametrize("C,Tn,r", [(1536, 75, 8), (768, 600, 5), (384, 301, 4), (192, 1000, 2)])
+def test_dw_convtr_vs_oracle(env, C, Tn, r):
+    ops, fold, O, dev = env
+    x = rnd(C + Tn, 2, C, Tn)
+    w = rnd(C + r, C, 1, 2 * r)
+    ref = O.sconvtr1d(F.elu(x * 0.7), w, None, stride=r, groups=C)
+    close(ops.dw_convtr(x.to(dev), w[:, 0].contiguous().to(dev), r, in_scale=0.7, in_elu=True), ref, 5e-6, "convtr")
+
+
+@pytest.mark.parametrize("n_fft,hop,Tn", [(64, 1, 1000), (128, 2, 2001), (256, 8, 4000), (512, 40, 4800), (1024, 320, 4800)])
+def test_stft_vs_oracle(env, n_fft, hop, Tn):
+    ops, fold, O, dev = env
+    wav = synth.synth_clips(2, Tn, seed=n_fft)
+    basis = synth.stft_basis(n_fft)
+    mag = O.causal_stft_mag(wav, basis, hop, True, True)
+    y = ops.stft_logmag(wav.to(dev), fold.stft_basis_layout(basis).to(dev), n_fft, hop, normalize=2)
+    # |re|,|im| are sums of n_fft products of O(0.1) terms: absolute error ~ 1e-7 * sqrt(n_fft) * 0.1 * few
+    close(y, mag, 2e-5, "stft magnitude")
+    ref = (mag.clamp_min(1e-5).log() - (-4.0)) / 2.8
+    y = ops.stft_logmag(wav.to(dev), fold.stft_basis_layout(basis).to(dev), n_fft, hop, -4.0, 2.8, True).cpu()
+    ok = mag > 1e-2                      # log amplifies relative error of tiny magnitudes
+    assert (y - ref)[ok].abs().max() < 2e-4
+    # history == explicit left context
+    hist = synth.synth_clips(2, n_fft - 1 + 5, seed=77)
+    full = torch.cat([hist, wav], dim=2)
+    m2 = O.causal_stft_mag(full[:, :, 5:], basis, hop, False, False)
+    y2 = ops.stft_logmag(wav.to(dev), fold.stft_basis_layout(basis).to(dev), n_fft, hop, normalize=2, hist=hist.to(dev))
+    close(y2, m2, 2e-5, "stft with history")
+
+
+def test_conv_pre_post_vs_oracle(env):
+    ops, fold, O, dev = env
+    wav = synth.synth_clips(3, 1001, seed=5)
+    w = rnd(1, 64, 1, 5); b = rnd(2, 64) * 0.1
+    ref = O.sconv1d(wav * (1 / 0.1122080159), w, b)
+    close(ops.conv_pre(wav.to(dev), w[:, 0].contiguous().to(dev), b.to(dev), in_scale=1 / 0.1122080159), ref, 2e-5, "conv_pre")
+    x = rnd(9, 3, 96, 1001)
+    w = rnd(3, 1, 96, 5) / 20; b = rnd(4, 1) * 0.1
+    ref = torch.tanh(O.sconv1d(F.elu(x * 0.707), w, b) * 0.1122080159)
+    y = ops.conv_post(x.to(dev), w[0].contiguous().to(dev), b.to(dev), in_scale=0.707, in_elu=True,
+                      out_scale=0.1122080159, do_tanh=True)
+    close(y, ref, 2e-6, "conv_post")
+
+
+def test_tail(env):
+    ops, fold, O, dev = env
+    x = rnd(1, 2, 3, 7); h = rnd(2, 2, 3, 10)
+    for pad in (4, 7, 9, 10):
+        ref = torch.cat([h, x], dim=2)[:, :, -pad:]
+        assert torch.equal(ops.tail(x.to(dev), h.to(dev), pad).cpu(), ref)
+    assert torch.equal(ops.tail(x.to(dev), None, 9).cpu(), torch.cat([torch.zeros(2, 3, 2), x], 2))
+
+
+def test_errors(env):
+    ops, fold, O, dev = env
+    x = torch.zeros(1, 8, 16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.pw_conv(torch.zeros(1, 8, 16), torch.zeros(8, 8, device=dev))           # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.pw_conv(x, torch.zeros(8, 6, device=dev))                                # M % 4 != 0 -> unsupported
+    with pytest.raises(RuntimeError):
+        ops.dw_conv(x, torch.zeros(8, 40, device=dev))                               # k > 16
+    with pytest.raises(RuntimeError):
+        ops.pw_conv(x.double(), torch.zeros(8, 8, device=dev))
