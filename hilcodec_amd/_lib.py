@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It
+# must be in the process BEFORE our library is dlopen'ed so that the kernels, the streams and the
+# device memory all belong to ONE runtime; loaded the other way round the library binds to
+# /opt/rocm's copy and every launch fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhilcodec_amd.so")
 
@@ -48,6 +54,7 @@ def _load() -> C.CDLL:
     lib.hilc_abi_version.restype = _i
     lib.hilc_error_string.restype = C.c_char_p
     lib.hilc_error_string.argtypes = [_i]
+    lib.hilc_last_hip_error.restype = C.c_char_p
     if lib.hilc_abi_version() != ABI_VERSION:
         raise HilcodecLibraryError(f"ABI mismatch: library {lib.hilc_abi_version()} != binding {ABI_VERSION}")
     return lib
@@ -61,4 +68,6 @@ def check(code: int, what: str) -> None:
         msg = lib.hilc_error_string(code).decode()
         if code == -5:
             raise AssertionError(msg)      # reference: `assert 1 <= n <= len(self.layers)`
+        if code == -3:
+            msg += " — " + lib.hilc_last_hip_error().decode()
         raise RuntimeError(f"{what}: {msg} (code {code})")

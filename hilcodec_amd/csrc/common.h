@@ -12,10 +12,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // on this thread (e.g. the host framework's own probing), so every launcher clears it first.
 #define HILC_CLEAR_ERROR() (void)hipGetLastError()
 
+extern thread_local int hilc_last_hip_error_code;   // rvq.hip
+
 #define HILC_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \
-    if (e__ != hipSuccess) return HILC_ERR_LAUNCH;            \
+    if (e__ != hipSuccess) {                                  \
+      hilc_last_hip_error_code = (int)e__;                    \
+      return HILC_ERR_LAUNCH;                                 \
+    }                                                         \
   } while (0)
 
 // ELU(alpha=1) exactly as the reference computes it on CPU: x > 0 ? x : expm1(x)

@@ -243,6 +243,12 @@ extern "C" int hilc_rvq_decode(const int64_t* indices, const float* codebooks, f
   return HILC_OK;
 }
 
+thread_local int hilc_last_hip_error_code = 0;
+
+extern "C" const char* hilc_last_hip_error(void) {
+  return hipGetErrorString((hipError_t)hilc_last_hip_error_code);
+}
+
 extern "C" int hilc_abi_version(void) { return HILC_ABI_VERSION; }
 
 extern "C" const char* hilc_error_string(int code) {

@@ -29,6 +29,44 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing on the stream the kernels are launched on (bench.py).
+    `work` is the algorithmic work of the launch (flops for the GEMMs, bytes for the HBM-bound ops)."""
+
+    def __init__(self):
+        self.records = []          # (kind, work, start_event, end_event)
+
+    def totals(self):
+        out = {}
+        for kind, work, e0, e1 in self.records:
+            t = out.setdefault(kind, [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += float(work)
+            t[2] += e0.elapsed_time(e1) * 1e-3
+        return out                 # kind -> [launches, work, seconds]
+
+
+TIMER: Optional[LaunchTimer] = None
+
+
+class _timed:
+    def __init__(self, kind: str, work: float):
+        self.kind, self.work = kind, work
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            self.e1.record()
+            TIMER.records.append((self.kind, self.work, self.e0, self.e1))
+        return False
+
+
 def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
             out: Optional[Tensor] = None, in_scale: float = 1.0, in_elu: bool = False,
             out_scale: float = 1.0) -> Tensor:
@@ -37,8 +75,9 @@ def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[
     M = wt.shape[1]
     assert wt.shape[0] == K
     y = out if out is not None else torch.empty(B, M, T, device=x.device, dtype=torch.float32)
-    check(lib.hilc_pw_conv(_ptr(x), _ptr(wt), _ptr(bias), _ptr(res), _ptr(y), B, K, M, T,
-                           in_scale, int(in_elu), out_scale, _stream()), "hilc_pw_conv")
+    with _timed("pw_conv", 2.0 * B * T * K * M):
+        check(lib.hilc_pw_conv(_ptr(x), _ptr(wt), _ptr(bias), _ptr(res), _ptr(y), B, K, M, T,
+                               in_scale, int(in_elu), out_scale, _stream()), "hilc_pw_conv")
     return y
 
 
@@ -52,9 +91,10 @@ def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[T
     To = (T + stride - 1) // stride
     y = out if out is not None else torch.empty(B, Cc, To, device=x.device, dtype=torch.float32)
     hout = torch.empty(B, Cc, k - stride, device=x.device, dtype=torch.float32) if want_hist else None
-    check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hout),
-                           B, Cc, T, k, stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()),
-          "hilc_dw_conv")
+    with _timed("dw_conv", 4.0 * B * Cc * (T + To * (2 if res is not None else 1))):
+        check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hout),
+                               B, Cc, T, k, stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()),
+              "hilc_dw_conv")
     return (y, hout) if want_hist else y
 
 
@@ -65,8 +105,9 @@ def dw_convtr(x: Tensor, w: Tensor, stride: int, hist: Optional[Tensor] = None, 
     assert w.shape[1] == 2 * stride
     y = torch.empty(B, Cc, T * stride, device=x.device, dtype=torch.float32)
     hout = torch.empty(B, Cc, 1, device=x.device, dtype=torch.float32) if want_hist else None
-    check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hout), B, Cc, T, stride,
-                             in_scale, int(in_elu), _stream()), "hilc_dw_convtr")
+    with _timed("dw_convtr", 4.0 * B * Cc * T * (1 + stride)):
+        check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hout), B, Cc, T, stride,
+                                 in_scale, int(in_elu), _stream()), "hilc_dw_convtr")
     return (y, hout) if want_hist else y
 
 
@@ -78,8 +119,9 @@ def conv_pre(wav: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1
     Cc, k = w.shape
     y = torch.empty(B, Cc, T, device=wav.device, dtype=torch.float32)
     hl = hist.shape[-1] if hist is not None else 0
-    check(lib.hilc_conv_pre(_ptr(wav), _ptr(hist), hl, _ptr(w), _ptr(bias), _ptr(y), B, Cc, T, k,
-                            in_scale, _stream()), "hilc_conv_pre")
+    with _timed("conv_pre", 4.0 * B * T * (1 + Cc)):
+        check(lib.hilc_conv_pre(_ptr(wav), _ptr(hist), hl, _ptr(w), _ptr(bias), _ptr(y), B, Cc, T, k,
+                                in_scale, _stream()), "hilc_conv_pre")
     return y
 
 
@@ -91,8 +133,9 @@ def conv_post(x: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.
     k = w.shape[1]
     y = torch.empty(B, 1, T, device=x.device, dtype=torch.float32)
     hout = torch.empty(B, Cc, k - 1, device=x.device, dtype=torch.float32) if want_hist else None
-    check(lib.hilc_conv_post(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(y), _ptr(hout), B, Cc, T, k,
-                             in_scale, int(in_elu), out_scale, int(do_tanh), _stream()), "hilc_conv_post")
+    with _timed("conv_post", 4.0 * B * T * (1 + Cc)):
+        check(lib.hilc_conv_post(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(y), _ptr(hout), B, Cc, T, k,
+                                 in_scale, int(in_elu), out_scale, int(do_tanh), _stream()), "hilc_conv_post")
     return (y, hout) if want_hist else y
 
 
@@ -104,8 +147,9 @@ def stft_logmag(wav: Tensor, basis_t: Tensor, n_fft: int, hop: int, mean: float 
     Tf = (T - 1) // hop + 1
     spec = torch.empty(B, n_fft // 2 + 1, Tf, device=wav.device, dtype=torch.float32)
     hl = hist.shape[-1] if hist is not None else 0
-    check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
-                               mean, std, int(normalize), _stream()), "hilc_stft_logmag")
+    with _timed("stft", 2.0 * B * Tf * n_fft * (n_fft + 2)):
+        check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
+                                   mean, std, int(normalize), _stream()), "hilc_stft_logmag")
     return spec
 
 
@@ -138,9 +182,10 @@ def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor,
     idx = torch.empty((nn, B, T) if stage_major else (B, nn, T), device=z.device, dtype=torch.int64)
     q = torch.empty_like(z) if want_q else None
     ferr = torch.empty(B * T, device=z.device, dtype=torch.float32) if want_loss else None
-    check(lib.hilc_rvq_encode(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
-                              _ptr(idx, torch.int64), _ptr(q), _ptr(ferr), B, Cc, T, K, Nq, n,
-                              int(channel_last), int(stage_major), _stream()), "hilc_rvq_encode")
+    with _timed("rvq_encode", 2.0 * B * T * K * Cc * nn):
+        check(lib.hilc_rvq_encode(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
+                                  _ptr(idx, torch.int64), _ptr(q), _ptr(ferr), B, Cc, T, K, Nq, n,
+                                  int(channel_last), int(stage_major), _stream()), "hilc_rvq_encode")
     loss = None
     if want_loss:
         loss = torch.empty((), device=z.device, dtype=torch.float32)

@@ -40,6 +40,8 @@ extern "C" {
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
+/* text of the hipError_t behind the calling thread's most recent HILC_ERR_LAUNCH */
+const char* hilc_last_hip_error(void);
 
 /* ---- pointwise (1x1) convolution: fp32-MFMA GEMM with fused prologue / epilogue ----------------
  * y[b,m,t] = (sum_k wt[k][m] * pro(x[b,k,t]) + bias[m]) * out_scale + res[b,m,t]
