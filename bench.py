@@ -156,9 +156,15 @@ def main():
                 "whole_path_frac": whole_tflops / FP32_MFMA_PEAK_TFLOPS}
         if timer is not None:
             tot = timer.totals()
-            launches, flops, secs = tot["pw_conv"]
+            # dominant kernel = the fp32-MFMA GEMM core (every instantiation of hilc::gemm_kernel /
+            # the fused residual-block kernel built on it): pointwise convs with their fused epilogues
+            mfma_kinds = [k for k in ("pw_conv", "dws_conv", "resblock") if k in tot]
+            launches = sum(tot[k][0] for k in mfma_kinds)
+            flops = sum(tot[k][1] for k in mfma_kinds)
+            secs = sum(tot[k][2] for k in mfma_kinds)
             roof.update({
-                "kernel": "gemm_kernel<MB,PwLoader,PwEpilogue> (hilc_pw_conv, fp32 v_mfma_f32_32x32x2_f32)",
+                "kernel": "hilc::gemm_kernel<MB,Loader,Epilogue> family (" + "+".join(mfma_kinds) +
+                          "; fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": flops / secs / 1e12, "frac": flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "launches_per_step": launches // args.steps, "avg_launch_us": secs / launches * 1e6,
                 "flop_per_launch_avg": flops / launches,

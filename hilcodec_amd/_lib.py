@@ -22,6 +22,7 @@ _f, _i, _p, _d = C.c_float, C.c_int, C.c_void_p, C.c_double
 # name -> argtypes, in the order of include/hilcodec_amd.h
 SIGNATURES = {
     "hilc_pw_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p],
+    "hilc_dws_conv": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
     "hilc_conv_pre": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -41,4 +41,17 @@ __device__ __forceinline__ float4 prologue4(float4 v, float scale, int do_elu) {
   return v;
 }
 
+// native 4-vector flavour (selects on HIP's struct float4 go through scratch memory; these do not)
+__device__ __forceinline__ f32x4 prologue4v(f32x4 v, float scale, int do_elu) {
+  v.x = prologue(v.x, scale, do_elu);
+  v.y = prologue(v.y, scale, do_elu);
+  v.z = prologue(v.z, scale, do_elu);
+  v.w = prologue(v.w, scale, do_elu);
+  return v;
+}
+__device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return ok ? v : z;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,50 +1,34 @@
-// fp32-MFMA GEMM core for the HILCodec hot path (gfx950) and its two front-ends:
-//   * hilc_pw_conv      — pointwise (1x1) convolution with fused Scale/ELU prologue and
-//                         bias / scale / residual epilogue,
-//   * hilc_stft_logmag  — strided-window DFT (implicit im2col of the waveform) with a fused
-//                         magnitude -> log -> normalise epilogue.
-//
-// Tiling.  One workgroup = 256 threads = 4 waves computes a (32*MB) x 128 output tile; wave w
-// owns columns [32w, 32w+32) and all MB row-blocks, so its accumulators are MB f32x16 registers
-// fed by v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain in k order, k = 0..K-1).
-// K is streamed in BK=16 slices, double-buffered in LDS with register prefetch:
-//   A slice  wt[k][m]   (folded weights, pre-transposed on the host -> coalesced float4 rows)
-//   B slice  X[k][n]    produced by a Loader functor (global activations, time contiguous)
-// Operand fetch: lane l reads A[k=2j+(l>>5)][m=l&31], B[k=2j+(l>>5)][n=l&31] with ds_read_b32;
-// each 32-lane half touches 32 consecutive dwords -> conflict-free without padding.
-#include "common.h"
+// Front-ends of the fp32-MFMA GEMM core (gemm_core.h):
+//   hilc_pw_conv      pointwise conv, fused Scale/ELU prologue, bias/scale/residual epilogue
+//   hilc_dws_conv     pointwise conv -> depthwise causal conv (k5 s1, or k=2r stride r) fused through
+//                     LDS: the [C x T] intermediate of a depthwise-separable block never reaches HBM
+//   hilc_stft_logmag  strided-window DFT (implicit im2col of the waveform) -> |.| -> log -> normalise
+#include "gemm_core.h"
+
+using namespace hilc;
 
 namespace {
 
-constexpr int BN = 128;
-constexpr int BK = 16;
-constexpr int NT = 256;
+// ================================================================================================
+// B-operand loaders.  Each thread owns one 4-column group (n4 = (tid & 31) * 4) and the two k rows
+// (tid >> 5) and (tid >> 5) + 8 of every BK slice.
+// ================================================================================================
 
-template <int MB>
-struct Smem {
-  float A[2][BK][32 * MB];
-  float B[2][BK][BN];
-};
-
-// ------------------------------------------------------------------------------------------------
-// B-operand loaders.  Each thread owns one 4-column group (n4 = (tid & 31) * 4) and the two
-// k rows (tid >> 5) and (tid >> 5) + 8 of every BK slice.
-// ------------------------------------------------------------------------------------------------
-struct PwLoader {
+// columns = flattened (clip, t) axis: no halo, tiles may straddle clips (plain pointwise conv).
+struct PwFlatLoader {
   const float* x;
   int K, T;
-  long ncols;  // B*T, columns are the flattened (b, t) axis
+  long ncols;  // B*T
   float in_scale;
   int in_elu;
-  int vec;  // T % 4 == 0 -> a 4-column group never straddles two clips and is 16-B aligned
+  int vec;  // T % 4 == 0 and x 16-B aligned -> a 4-column group never straddles two clips
   struct State {
     long b0, b1, b2, b3;
     bool o0, o1, o2, o3;
   };
-
-  __device__ State init(long n0, int tid) const {
+  __device__ State init(long ntile, int tid) const {
     State s;
-    long n = n0 + (tid & 31) * 4;
+    long n = ntile * BN + (tid & 31) * 4;
     auto col = [&](long nn, long& base, bool& ok) {
       ok = nn < ncols;
       long b = nn / T;
@@ -55,24 +39,66 @@ struct PwLoader {
     if (!vec) { col(n + 1, s.b1, s.o1); col(n + 2, s.b2, s.o2); col(n + 3, s.b3, s.o3); }
     return s;
   }
-  __device__ float4 fetch(const State& s, int k) const {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K) {
-      if (vec) {
-        if (s.o0) v = prologue4(*reinterpret_cast<const float4*>(x + s.b0 + (long)k * T), in_scale, in_elu);
-      } else {
-        if (s.o0) v.x = prologue(x[s.b0 + (long)k * T], in_scale, in_elu);
-        if (s.o1) v.y = prologue(x[s.b1 + (long)k * T], in_scale, in_elu);
-        if (s.o2) v.z = prologue(x[s.b2 + (long)k * T], in_scale, in_elu);
-        if (s.o3) v.w = prologue(x[s.b3 + (long)k * T], in_scale, in_elu);
-      }
-    }
+  // branch-free: invalid columns read x[0] (always mapped) and are zeroed by a select
+  __device__ f32x4 fetch(const State& s, int k) const {
+    const long ko = (long)k * T;
+    if (vec)   // uniform over the launch
+      return *reinterpret_cast<const f32x4*>(x + (s.o0 ? s.b0 + ko : 0));
+    f32x4 v;
+    v.x = x[s.o0 ? s.b0 + ko : 0];
+    v.y = x[s.o1 ? s.b1 + ko : 0];
+    v.z = x[s.o2 ? s.b2 + ko : 0];
+    v.w = x[s.o3 ? s.b3 + ko : 0];
     return v;
+  }
+  __device__ f32x4 transform(const State& s, f32x4 v, int) const {
+    if (vec) return prologue4v(zero_unless(s.o0, v), in_scale, in_elu);   // pro(0) == 0
+    v.x = s.o0 ? v.x : 0.f; v.y = s.o1 ? v.y : 0.f; v.z = s.o2 ? v.z : 0.f; v.w = s.o3 ? v.w : 0.f;
+    return prologue4v(v, in_scale, in_elu);
   }
 };
 
-// Implicit im2col of the waveform: column = frame f of clip b, row k = sample k of the window,
-// element = we[b, f*hop - (n_fft-1) + k] (history / zero for negative times).
+// per-clip column tiles with a left halo: tile covers times [tix*step - halo, +128) of clip b;
+// samples outside [0, T) read as zero (causal zero padding / the reference's right "extra" padding).
+struct PwTileLoader {
+  const float* x;
+  int K, T, tiles, step, halo;
+  float in_scale;
+  int in_elu;
+  int vec;  // T % 4 == 0, step % 4 == 0, halo % 4 == 0, x aligned
+  struct State {
+    long base;  // (b*K)*T + t  (t may be negative; only dereferenced when valid)
+    int t;
+  };
+  __device__ State init(long ntile, int tid) const {
+    State s;
+    long b = ntile / tiles;
+    int tix = (int)(ntile - b * tiles);
+    s.t = tix * step - halo + (tid & 31) * 4;
+    s.base = b * (long)K * T + s.t;
+    return s;
+  }
+  __device__ bool ok(const State& s, int e) const { return s.t + e >= 0 && s.t + e < T; }
+  __device__ f32x4 fetch(const State& s, int k) const {
+    const long off = s.base + (long)k * T;
+    if (vec)   // uniform over the launch
+      return *reinterpret_cast<const f32x4*>(x + (ok(s, 0) ? off : 0));
+    f32x4 v;
+    v.x = x[ok(s, 0) ? off : 0];
+    v.y = x[ok(s, 1) ? off + 1 : 0];
+    v.z = x[ok(s, 2) ? off + 2 : 0];
+    v.w = x[ok(s, 3) ? off + 3 : 0];
+    return v;
+  }
+  __device__ f32x4 transform(const State& s, f32x4 v, int) const {
+    if (vec) return prologue4v(zero_unless(ok(s, 0), v), in_scale, in_elu);
+    v.x = ok(s, 0) ? v.x : 0.f; v.y = ok(s, 1) ? v.y : 0.f; v.z = ok(s, 2) ? v.z : 0.f; v.w = ok(s, 3) ? v.w : 0.f;
+    return prologue4v(v, in_scale, in_elu);
+  }
+};
+
+// Implicit im2col of the waveform: column = frame f of clip b (flattened), row k = sample k of the
+// window, element = we[b, f*hop - (n_fft-1) + k] (history / zero for negative times).
 struct StftLoader {
   const float* wav;
   const float* hist;
@@ -80,12 +106,11 @@ struct StftLoader {
   int T, Tf, n_fft, hop;
   long ncols;  // B*Tf
   struct Col {
-    long b;   // clip
-    int t0;   // f*hop - (n_fft-1)
+    long b;
+    int t0;  // f*hop - (n_fft-1)
     bool ok;
   };
   struct State { Col c0, c1, c2, c3; };
-
   __device__ Col col(long nn) const {
     Col c;
     c.ok = nn < ncols;
@@ -94,34 +119,36 @@ struct StftLoader {
     c.t0 = f * hop - (n_fft - 1);
     return c;
   }
-  __device__ State init(long n0, int tid) const {
-    long n = n0 + (tid & 31) * 4;
+  __device__ State init(long ntile, int tid) const {
+    long n = ntile * BN + (tid & 31) * 4;
     State s;
     s.c0 = col(n); s.c1 = col(n + 1); s.c2 = col(n + 2); s.c3 = col(n + 3);
     return s;
   }
+  // raw load; columns / times that do not exist read a mapped dummy address and are zeroed in `keep`
   __device__ float at(const Col& c, int k) const {
-    if (!c.ok) return 0.f;
-    int t = c.t0 + k;
-    if (t >= 0) return wav[c.b * (long)T + t];
-    if (hist != nullptr) return hist[c.b * (long)hist_len + hist_len + t];
-    return 0.f;
-  }
-  __device__ float4 fetch(const State& s, int k) const {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < n_fft) {
-      v.x = at(s.c0, k);
-      v.y = at(s.c1, k);
-      v.z = at(s.c2, k);
-      v.w = at(s.c3, k);
+    const int t = c.t0 + k;
+    if (hist != nullptr) {   // uniform over the launch (streaming): history for t < 0
+      const float* p = t >= 0 ? wav + c.b * (long)T + t : hist + c.b * (long)hist_len + hist_len + t;
+      return *(c.ok ? p : wav);
     }
+    return wav[(c.ok && t >= 0) ? c.b * (long)T + t : 0];
+  }
+  __device__ f32x4 fetch(const State& s, int k) const {
+    f32x4 v = {at(s.c0, k), at(s.c1, k), at(s.c2, k), at(s.c3, k)};
+    return v;
+  }
+  __device__ bool keep(const Col& c, int k) const { return c.ok && (hist != nullptr || c.t0 + k >= 0); }
+  __device__ f32x4 transform(const State& s, f32x4 v, int k) const {
+    v.x = keep(s.c0, k) ? v.x : 0.f; v.y = keep(s.c1, k) ? v.y : 0.f;
+    v.z = keep(s.c2, k) ? v.z : 0.f; v.w = keep(s.c3, k) ? v.w : 0.f;
     return v;
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// Epilogues.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// ------------------------------------------------------------------------------------------------
+// ================================================================================================
+// Epilogues
+// ================================================================================================
 struct PwEpilogue {
   float* y;
   const float* bias;
@@ -129,10 +156,11 @@ struct PwEpilogue {
   int M, T;
   long ncols;
   float out_scale;
+  template <int MB> static constexpr int lds_floats() { return 0; }
 
   template <int MB>
-  __device__ void run(const f32x16 (&acc)[MB], int m0, long n0, int wave, int lane) const {
-    long n = n0 + wave * 32 + (lane & 31);
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    long n = ntile * BN + wave * 32 + (lane & 31);
     if (n >= ncols) return;
     long b = n / T;
     long colbase = b * (long)M * T + (n - b * T);
@@ -140,7 +168,7 @@ struct PwEpilogue {
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int row = m0 + i * 32 + acc_row(r, lane);
         if (row < M) {
           long off = colbase + (long)row * T;
           float v = acc[i][r];
@@ -162,10 +190,11 @@ struct StftEpilogue {
   long ncols;
   float mean, stdv;
   int normalize;
+  template <int MB> static constexpr int lds_floats() { return 0; }
 
   template <int MB>
-  __device__ void run(const f32x16 (&acc)[MB], int m0, long n0, int wave, int lane) const {
-    long n = n0 + wave * 32 + (lane & 31);
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    long n = ntile * BN + wave * 32 + (lane & 31);
     if (n >= ncols) return;
     long b = n / Tf;
     long colbase = b * (long)nbins * Tf + (n - b * Tf);
@@ -173,15 +202,15 @@ struct StftEpilogue {
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        int row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int row = m0 + i * 32 + acc_row(r, lane);
         int bin = row >> 1;
         if (bin < nbins) {
           float re = acc[i][r], im = acc[i][r + 1];
           // x.square().sum(dim=1).clamp_min(1e-12).sqrt()  (conv.py:357) — no FMA contraction
           float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
           float v = sqrtf(fmaxf(p, 1e-12f));
-          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));  // seanet.py:228
-          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);  // seanet.py:236
+          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
+          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
           spec[colbase + (long)bin * Tf] = v;
         }
       }
@@ -189,120 +218,143 @@ struct StftEpilogue {
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// The kernel
-// ------------------------------------------------------------------------------------------------
-template <int MB, class Loader, class Epilogue>
-__global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, int M, int K, int ldw,
-                                                  long ntiles, int mtiles, Loader ld, Epilogue ep) {
-  constexpr int BM = 32 * MB;
-  constexpr int AG = BK * BM / 4;            // float4 groups in an A slice
-  constexpr int AP = (AG + NT - 1) / NT;     // per-thread passes
-  __shared__ Smem<MB> sm;
+constexpr int HS = 132;  // LDS row stride of the post-GEMM tile: 128 columns + 4, keeps float4 alignment
 
-  // XCD-aware tile order: the `mtiles` row-tiles that share one B column-tile get block ids that
-  // are congruent mod 8 (observed: block b runs on XCD b % 8), so the shared activations stay in
-  // one XCD's L2.  Placement only changes speed, never results.
-  long id = blockIdx.x;
-  long grp = id / (8L * mtiles);
-  int within = (int)(id - grp * 8L * mtiles);
-  long ntile = grp * 8 + (within & 7);
-  int mtile = within >> 3;
-  if (ntile >= ntiles) return;
-  const int m0 = mtile * BM;
-  const long n0 = ntile * BN;
+constexpr int CH = 2;    // the post-GEMM tile goes through LDS in chunks of CH 32-row blocks (33 KB)
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-
-  const typename Loader::State ls = ld.init(n0, tid);
-
-  f32x16 acc[MB];
+// chunk c of the accumulators -> LDS rows [0, 32*nblk)
+template <int MB>
+__device__ __forceinline__ int acc_chunk_to_lds(const f32x16 (&acc)[MB], float* smem, int c, int wave, int lane) {
+  __syncthreads();  // previous readers of the tile (staged K slices / previous chunk) are done
+  const int nblk = (MB - c * CH) < CH ? (MB - c * CH) : CH;
 #pragma unroll
-  for (int i = 0; i < MB; ++i)
+  for (int i = 0; i < MB; ++i) {
+    if (i >= c * CH && i < c * CH + CH) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  float4 ra[AP], rb[2];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      int g = tid + p * NT;
-      int k = g / (BM / 4), m4 = (g % (BM / 4)) * 4;
-      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < AG && (k0 + k) < K && (m0 + m4) < ldw)
-        ra[p] = *reinterpret_cast<const float4*>(wt + (long)(k0 + k) * ldw + m0 + m4);
+      for (int r = 0; r < 16; ++r)
+        smem[((i - c * CH) * 32 + acc_row(r, lane)) * HS + wave * 32 + (lane & 31)] = acc[i][r];
     }
-    rb[0] = ld.fetch(ls, k0 + (tid >> 5));
-    rb[1] = ld.fetch(ls, k0 + (tid >> 5) + 8);
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      int g = tid + p * NT;
-      if (g < AG) {
-        int k = g / (BM / 4), m4 = (g % (BM / 4)) * 4;
-        *reinterpret_cast<float4*>(&sm.A[buf][k][m4]) = ra[p];
-      }
-    }
-    *reinterpret_cast<float4*>(&sm.B[buf][tid >> 5][(tid & 31) * 4]) = rb[0];
-    *reinterpret_cast<float4*>(&sm.B[buf][(tid >> 5) + 8][(tid & 31) * 4]) = rb[1];
-  };
-
-  const int ktiles = (K + BK - 1) / BK;
-  const int live = min(MB, (M - m0 + 31) / 32);
-  fetch(0);
-  stage(0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < ktiles) fetch((kt + 1) * BK);
+  return nblk;
+}
+
+// depthwise causal conv, k = 5, stride 1, on the GEMM tile: column c <-> time t0 + c, t0 = tix*124 - 4;
+// output column c >= 4 reads columns c-4..c.  Thread = (row, 16-column segment).
+struct Dw5Epilogue {
+  float* y;
+  const float* dw_w;   // [M][5]
+  const float* dw_b;   // [M] or null
+  const float* res;    // [B][M][T] or null (may alias y)
+  int M, T, tiles;
+  float out_scale;
+  int out_elu;
+  int vec;  // T % 4 == 0 and y/res 16-B aligned
+  static constexpr int STEP = BN - 4;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    long b = ntile / tiles;
+    int tix = (int)(ntile - b * tiles);
+    int t0 = tix * STEP - 4;
 #pragma unroll
-    for (int j = 0; j < BK / 2; ++j) {
-      const int kk = 2 * j + (lane >> 5);
-      const float bv = sm.B[buf][kk][wave * 32 + (lane & 31)];
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+    const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
 #pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        if (i < live) {  // wave-uniform: skips the dead 32-row blocks of a partial last row tile
-          const float av = sm.A[buf][kk][i * 32 + (lane & 31)];
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+    for (int s = 0; s < CH; ++s) {
+      int seg = tid + NT * s;
+      int row = seg >> 3, c0 = (seg & 7) * 16;
+      int m = m0 + ch * CH * 32 + row;
+      if (row >= nblk * 32 || m >= M) continue;
+      float v[20];
+      const float* hrow = smem + row * HS;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        int c = c0 - 4 + 4 * g;
+        float4 q = c >= 0 ? *reinterpret_cast<const float4*>(hrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+      }
+      float w[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
+      float bias = dw_b ? dw_b[m] : 0.f;
+      long rowoff = (b * M + m) * (long)T;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int c = c0 + 4 * g;
+        int t = t0 + c;
+        if (c < 4 || t >= T) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) a = fmaf(w[j], v[4 * g + e + j], a);   // taps in order j = 0..4
+          a = __fadd_rn(a, bias);
+          a = __fmul_rn(a, out_scale);
+          o[e] = a;
+        }
+        if (vec) {
+          if (res != nullptr) {
+            float4 rr = *reinterpret_cast<const float4*>(res + rowoff + t);
+            o[0] = __fadd_rn(o[0], rr.x); o[1] = __fadd_rn(o[1], rr.y);
+            o[2] = __fadd_rn(o[2], rr.z); o[3] = __fadd_rn(o[3], rr.w);
+          }
+          if (out_elu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = elu1(o[e]);
+          }
+          *reinterpret_cast<float4*>(y + rowoff + t) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (t + e < T) {
+              float a = o[e];
+              if (res != nullptr) a = __fadd_rn(a, res[rowoff + t + e]);
+              if (out_elu) a = elu1(a);
+              y[rowoff + t + e] = a;
+            }
+          }
         }
       }
     }
-    if (kt + 1 < ktiles) {
-      stage(buf ^ 1);
-      __syncthreads();
     }
   }
-  ep.template run<MB>(acc, m0, n0, wave, lane);
-}
+};
 
-template <class Loader, class Epilogue>
-int launch_gemm(const float* wt, int M, int K, int ldw, long ncols, const Loader& ld, const Epilogue& ep,
-                hipStream_t s) {
-  // row-tile height (in 32-row MFMA blocks)
-  int m32 = (M + 31) / 32;
-  int MB;  // dead blocks of a partial last tile are skipped in the kernel, so prefer tall tiles
-  if (m32 % 4 == 0) MB = 4;
-  else if (m32 % 3 == 0) MB = 3;
-  else if (m32 < 4) MB = m32;
-  else MB = 4;
-  int mtiles = (m32 + MB - 1) / MB;
-  long ntiles = (ncols + BN - 1) / BN;
-  long groups = (ntiles + 7) / 8;
-  long blocks = groups * 8 * mtiles;
-  if (blocks <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
-  dim3 grid((unsigned)blocks), block(NT);
-  switch (MB) {
-    case 1: HILC_CLEAR_ERROR(); hipLaunchKernelGGL((gemm_kernel<1, Loader, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, ld, ep); break;
-    case 2: HILC_CLEAR_ERROR(); hipLaunchKernelGGL((gemm_kernel<2, Loader, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, ld, ep); break;
-    case 3: HILC_CLEAR_ERROR(); hipLaunchKernelGGL((gemm_kernel<3, Loader, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, ld, ep); break;
-    default: HILC_CLEAR_ERROR(); hipLaunchKernelGGL((gemm_kernel<4, Loader, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, ld, ep); break;
+// depthwise causal conv k = 2r, stride r (down-sampling): tile covers times [o0*r - H, +128) with
+// H = round_up(r, 4); output o0 + i reads columns H - r + i*r + j, j < 2r.
+struct DwStrideEpilogue {
+  float* y;
+  const float* dw_w;   // [M][2r]
+  const float* dw_b;
+  int M, To, tiles, r, H, n_out;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    long b = ntile / tiles;
+    int tix = (int)(ntile - b * tiles);
+    int o0 = tix * n_out;
+    const int k = 2 * r;
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+      for (int idx = tid; idx < 32 * nblk * n_out; idx += NT) {
+        int row = idx / n_out, i = idx - row * n_out;
+        int m = m0 + ch * CH * 32 + row, o = o0 + i;
+        if (m >= M || o >= To) continue;
+        const float* h = smem + row * HS + (H - r) + i * r;
+        const float* w = dw_w + (long)m * k;
+        float a = 0.f;
+        for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+        if (dw_b) a = __fadd_rn(a, dw_b[m]);
+        y[(b * M + m) * (long)To + o] = a;
+      }
+    }
   }
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
+};
 
 }  // namespace
 
@@ -313,12 +365,46 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   if (B <= 0 || K <= 0 || M <= 0 || T <= 0) return HILC_ERR_SHAPE;
   if (M % 4 != 0) return HILC_ERR_UNSUPPORTED;  // weight rows are read as float4
   long ncols = (long)B * T;
-  PwLoader ld;
+  PwFlatLoader ld;
   ld.x = x; ld.K = K; ld.T = T; ld.ncols = ncols; ld.in_scale = in_scale; ld.in_elu = in_elu;
   ld.vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   PwEpilogue ep;
   ep.y = y; ep.bias = bias; ep.res = res; ep.M = M; ep.T = T; ep.ncols = ncols; ep.out_scale = out_scale;
-  return launch_gemm(wt, M, K, M, ncols, ld, ep, (hipStream_t)stream);
+  return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
+}
+
+extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b,
+                             const float* res, float* y, int B, int K, int M, int T, int ksize, int stride,
+                             float in_scale, int in_elu, float out_scale, int out_elu, void* stream) {
+  if (!x || !wt || !dw_w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || K <= 0 || M <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (M % 4 != 0) return HILC_ERR_UNSUPPORTED;
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  PwTileLoader ld;
+  ld.x = x; ld.K = K; ld.T = T; ld.in_scale = in_scale; ld.in_elu = in_elu;
+  if (stride == 1) {
+    if (ksize != 5) return HILC_ERR_UNSUPPORTED;
+    Dw5Epilogue ep;
+    ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.res = res; ep.M = M; ep.T = T;
+    ep.tiles = (T + Dw5Epilogue::STEP - 1) / Dw5Epilogue::STEP;
+    ep.out_scale = out_scale; ep.out_elu = out_elu;
+    ep.vec = (T % 4 == 0) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+             (res == nullptr || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
+    ld.tiles = ep.tiles; ld.step = Dw5Epilogue::STEP; ld.halo = 4;
+    ld.vec = aligned && (T % 4 == 0);
+    return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
+  }
+  if (ksize != 2 * stride || stride > 16 || res != nullptr || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
+  DwStrideEpilogue ep;
+  ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.M = M; ep.r = stride;
+  ep.To = (T + stride - 1) / stride;
+  ep.H = (stride + 3) / 4 * 4;
+  ep.n_out = (BN - ep.H - stride) / stride + 1;
+  while ((ep.n_out * stride) % 4 != 0) --ep.n_out;   // keep tile starts 16-B aligned
+  ep.tiles = (ep.To + ep.n_out - 1) / ep.n_out;
+  ld.tiles = ep.tiles; ld.step = ep.n_out * stride; ld.halo = ep.H;
+  ld.vec = aligned && (T % 4 == 0);
+  return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
 }
 
 extern "C" int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const float* basis_t,
@@ -337,5 +423,5 @@ extern "C" int hilc_stft_logmag(const float* wav, const float* hist, int hist_le
   StftEpilogue ep;
   ep.spec = spec; ep.nbins = n_fft / 2 + 1; ep.Tf = Tf; ep.ncols = ncols; ep.mean = mean; ep.stdv = stdv;
   ep.normalize = normalize;
-  return launch_gemm(basis_t, M, n_fft, m_pad, ncols, ld, ep, (hipStream_t)stream);
+  return launch_gemm(basis_t, M, n_fft, m_pad, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }

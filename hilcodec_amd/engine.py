@@ -19,6 +19,10 @@ from torch import Tensor
 
 from . import ops
 
+# offline path: fuse every pointwise->depthwise pair into one launch (hilc_dws_conv).  The unfused
+# kernels remain the streaming path (per-hop tiles are a few samples wide) and a debugging aid.
+FUSE_DWS = True
+
 
 @dataclass
 class ResBlockSpec:
@@ -114,6 +118,11 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------------
 def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list]) -> Tensor:
     """x is updated in place (the residual add writes over its own shortcut, element-wise)."""
+    if caches is None and FUSE_DWS and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5:
+        # two launches per block: [ELU, pw, dw, ELU] and [pw, dw, *scale + shortcut]; the pointwise
+        # outputs never leave LDS
+        g = ops.dws_conv(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
+        return ops.dws_conv(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x)
     h = ops.pw_conv(x, rb.pw1_wt, in_scale=rb.pre_scale, in_elu=True)
     if caches is None:
         g = ops.dw_conv(h, rb.dw1_w, rb.dw1_b)            # a depthwise conv must not run in place (halo reads)
@@ -153,11 +162,15 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
             ci += 2
-        h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
         if streaming:
+            h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
             x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True)
             new_caches.append(c)
+        elif FUSE_DWS and st.down_dw_w.shape[1] == 2 * st.ratio:
+            x = ops.dws_conv(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, stride=st.ratio,
+                             in_scale=st.down_in_scale, in_elu=True)
         else:
+            h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
             x = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio)
         ci += 1
     x = _spec_block(es.spec_post, x, wav, wav_hist)
@@ -179,12 +192,15 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     streaming = caches is not None
     new_caches: Optional[list] = [] if streaming else None
     q = q.contiguous().float()
-    h = ops.pw_conv(q, ds.pre_pw_wt)
     ci = 0
     if streaming:
+        h = ops.pw_conv(q, ds.pre_pw_wt)
         x, c = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b, hist=caches[0], want_hist=True)
         new_caches.append(c)
+    elif FUSE_DWS and ds.pre_dw_w.shape[1] == 5:
+        x = ops.dws_conv(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b)
     else:
+        h = ops.pw_conv(q, ds.pre_pw_wt)
         x = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b)
     ci = 1
     for st in ds.stages:

@@ -34,11 +34,11 @@ class LaunchTimer:
     `work` is the algorithmic work of the launch (flops for the GEMMs, bytes for the HBM-bound ops)."""
 
     def __init__(self):
-        self.records = []          # (kind, work, start_event, end_event)
+        self.records = []          # (kind, work, start_event, end_event, tag)
 
     def totals(self):
         out = {}
-        for kind, work, e0, e1 in self.records:
+        for kind, work, e0, e1, _tag in self.records:
             t = out.setdefault(kind, [0, 0.0, 0.0])
             t[0] += 1
             t[1] += float(work)
@@ -50,8 +50,8 @@ TIMER: Optional[LaunchTimer] = None
 
 
 class _timed:
-    def __init__(self, kind: str, work: float):
-        self.kind, self.work = kind, work
+    def __init__(self, kind: str, work: float, tag: str = ""):
+        self.kind, self.work, self.tag = kind, work, tag
 
     def __enter__(self):
         if TIMER is not None:
@@ -63,7 +63,7 @@ class _timed:
     def __exit__(self, *exc):
         if TIMER is not None:
             self.e1.record()
-            TIMER.records.append((self.kind, self.work, self.e0, self.e1))
+            TIMER.records.append((self.kind, self.work, self.e0, self.e1, self.tag))
         return False
 
 
@@ -75,9 +75,25 @@ def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[
     M = wt.shape[1]
     assert wt.shape[0] == K
     y = out if out is not None else torch.empty(B, M, T, device=x.device, dtype=torch.float32)
-    with _timed("pw_conv", 2.0 * B * T * K * M):
+    with _timed("pw_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T}"):
         check(lib.hilc_pw_conv(_ptr(x), _ptr(wt), _ptr(bias), _ptr(res), _ptr(y), B, K, M, T,
                                in_scale, int(in_elu), out_scale, _stream()), "hilc_pw_conv")
+    return y
+
+
+def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None, res: Optional[Tensor] = None,
+             stride: int = 1, in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0,
+             out_elu: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Fused pointwise -> depthwise causal conv (offline): x `[B,K,T]`, wt `[K,M]`, dw_w `[M,k]` ->
+    `[B,M,ceil(T/stride)]`; see hilc_dws_conv."""
+    B, K, T = x.shape
+    M = wt.shape[1]
+    k = dw_w.shape[1]
+    To = (T + stride - 1) // stride
+    y = out if out is not None else torch.empty(B, M, To, device=x.device, dtype=torch.float32)
+    with _timed("dws_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k{k} s{stride}"):
+        check(lib.hilc_dws_conv(_ptr(x), _ptr(wt), _ptr(dw_w), _ptr(dw_b), _ptr(res), _ptr(y), B, K, M, T, k,
+                                stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()), "hilc_dws_conv")
     return y
 
 
@@ -91,7 +107,7 @@ def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[T
     To = (T + stride - 1) // stride
     y = out if out is not None else torch.empty(B, Cc, To, device=x.device, dtype=torch.float32)
     hout = torch.empty(B, Cc, k - stride, device=x.device, dtype=torch.float32) if want_hist else None
-    with _timed("dw_conv", 4.0 * B * Cc * (T + To * (2 if res is not None else 1))):
+    with _timed("dw_conv", 4.0 * B * Cc * (T + To * (2 if res is not None else 1)), f"C{Cc} T{T} k{k} s{stride}"):
         check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hout),
                                B, Cc, T, k, stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()),
               "hilc_dw_conv")
@@ -105,7 +121,7 @@ def dw_convtr(x: Tensor, w: Tensor, stride: int, hist: Optional[Tensor] = None, 
     assert w.shape[1] == 2 * stride
     y = torch.empty(B, Cc, T * stride, device=x.device, dtype=torch.float32)
     hout = torch.empty(B, Cc, 1, device=x.device, dtype=torch.float32) if want_hist else None
-    with _timed("dw_convtr", 4.0 * B * Cc * T * (1 + stride)):
+    with _timed("dw_convtr", 4.0 * B * Cc * T * (1 + stride), f"C{Cc} T{T} r{stride}"):
         check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hout), B, Cc, T, stride,
                                  in_scale, int(in_elu), _stream()), "hilc_dw_convtr")
     return (y, hout) if want_hist else y
@@ -147,7 +163,7 @@ def stft_logmag(wav: Tensor, basis_t: Tensor, n_fft: int, hop: int, mean: float 
     Tf = (T - 1) // hop + 1
     spec = torch.empty(B, n_fft // 2 + 1, Tf, device=wav.device, dtype=torch.float32)
     hl = hist.shape[-1] if hist is not None else 0
-    with _timed("stft", 2.0 * B * Tf * n_fft * (n_fft + 2)):
+    with _timed("stft", 2.0 * B * Tf * n_fft * (n_fft + 2), f"N{n_fft} hop{hop}"):
         check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
                                    mean, std, int(normalize), _stream()), "hilc_stft_logmag")
     return spec

@@ -52,6 +52,17 @@ const char* hilc_last_hip_error(void);
 int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
                  int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, void* stream);
 
+/* ---- fused depthwise-separable block: pointwise conv -> depthwise causal conv through LDS ----------
+ * h[b,m,t] = sum_k wt[k][m] * pro(x[b,k,t])                       (no bias: seanet.py:33-37)
+ * y[b,m,o] = post((sum_j dw_w[m][j] * h[b,m,o*stride - pad + j] + dw_b[m]) * out_scale + res[b,m,o])
+ * with h(t<0) = h(t>=T) = 0, pad = (ksize-1)-(stride-1), T_out = ceil(T/stride).  Supported: ksize 5 /
+ * stride 1 (residual-block halves, `seanet.py:26-52,129-148`; decoder/encoder pre/post pairs) and
+ * ksize = 2*stride (encoder down-sampling, `seanet.py:322-340`; res/out_elu/out_scale unused there).
+ * The [M x T] intermediate h lives only in LDS: one HBM read of x and one write of y per block half. */
+int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b, const float* res,
+                  float* y, int B, int K, int M, int T, int ksize, int stride, float in_scale, int in_elu,
+                  float out_scale, int out_elu, void* stream);
+
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)
  * y[b,c,o] = post((sum_j w[c][j] * xe[b,c,o*stride - pad + j] + bias[c]) * out_scale + res[b,c,o])

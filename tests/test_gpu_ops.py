@@ -232,3 +232,39 @@ def test_errors(env):
         ops.dw_conv(x, torch.zeros(8, 40, device=dev))                               # k > 16
     with pytest.raises(RuntimeError):
         ops.pw_conv(x.double(), torch.zeros(8, 8, device=dev))
+
+
+@pytest.mark.parametrize("B,K,M,Tn", [(2, 64, 64, 1000), (2, 96, 96, 372), (1, 192, 192, 601), (2, 128, 1536, 75),
+                                      (1, 768, 768, 600), (3, 256, 256, 124), (2, 384, 384, 125)])
+def test_dws_conv_k5_vs_oracle(env, B, K, M, Tn):
+    """fused pointwise -> depthwise k5 (both residual-block halves) against the two-step oracle"""
+    ops, fold, O, dev = env
+    x = rnd(B * 3 + K + Tn, B, K, Tn)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    dw = rnd(M + 5, M, 1, 5)
+    db = rnd(M, M) * 0.1
+    r = rnd(11, B, M, Tn)
+    h = F.conv1d(F.elu(x * 0.86), w)
+    ref1 = F.elu(O.sconv1d(h, dw, db, groups=M))
+    y1 = ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev),
+                      in_scale=0.86, in_elu=True, out_elu=True)
+    close(y1, ref1, 2e-5, "dws first half")
+    ref2 = O.sconv1d(F.conv1d(x, w), dw, db, groups=M) * 0.37 + r
+    r2 = r.clone().to(dev)
+    ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev), res=r2,
+                 out_scale=0.37, out=r2)
+    close(r2, ref2, 2e-5, "dws second half (in-place residual)")
+
+
+@pytest.mark.parametrize("K,M,Tn,r", [(64, 128, 1000, 2), (128, 256, 1203, 4), (256, 512, 600, 5), (512, 1024, 77, 8),
+                                      (64, 128, 124, 2), (96, 96, 250, 5)])
+def test_dws_conv_strided_vs_oracle(env, K, M, Tn, r):
+    ops, fold, O, dev = env
+    x = rnd(K + Tn, 2, K, Tn)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    dw = rnd(M + r, M, 1, 2 * r)
+    db = rnd(M, M) * 0.1
+    ref = O.sconv1d(F.conv1d(F.elu(x * 0.77), w), dw, db, stride=r, groups=M)
+    y = ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev),
+                     stride=r, in_scale=0.77, in_elu=True)
+    close(y, ref, 2e-5, "dws strided")
