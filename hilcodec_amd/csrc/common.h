@@ -7,6 +7,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // hipGetLastError() also reports (and clears) errors left behind by unrelated earlier runtime calls
 // on this thread (e.g. the host framework's own probing), so every launcher clears it first.
@@ -27,10 +28,19 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
 // (torch's CPU ELU is bit-identical to expm1, SURVEY.md §7 "Transcendentals").
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
+// Hot-path ELU: x > 0 ? x : 2^(x*log2 e) - 1 with the hardware v_exp_f32 (1 ulp).  5 VALU instead of
+// ~32 + a divergent branch for expm1f.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1,
+// i.e. one fp32 ulp of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on
+// a dense grid) — relative accuracy near 0- is given up, which a following dot product cannot see.
+__device__ __forceinline__ float elu_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f);
+  return x > 0.0f ? x : e - 1.0f;
+}
+
 // optional "scale then ELU" prologue applied to a conv input sample
 __device__ __forceinline__ float prologue(float x, float scale, int do_elu) {
   float v = x * scale;
-  return do_elu ? elu1(v) : v;
+  return do_elu ? elu_fast(v) : v;
 }
 
 __device__ __forceinline__ float4 prologue4(float4 v, float scale, int do_elu) {
@@ -52,6 +62,18 @@ __device__ __forceinline__ f32x4 prologue4v(f32x4 v, float scale, int do_elu) {
 __device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return ok ? v : z;
+}
+
+// Co-resident workgroups that run the same phase program start together and stay in lock-step:
+// their MFMA phases contend for the one matrix pipe per SIMD, then their VALU phases leave it idle
+// together.  Skewing the FIRST round of workgroups by their hardware wave slot (HW_ID.wave_id,
+// bits [3:0]) de-phases the slots; every later workgroup inherits the skew of the one it replaces.
+// Purely a scheduling aid: results do not depend on it.
+__device__ __forceinline__ void stagger_first_round(unsigned first_round_blocks, int sleeps_per_slot) {
+  if (blockIdx.x < first_round_blocks) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 7u;   // HW_REG_HW_ID[3:0]
+    for (int i = 0; i < (int)slot * sleeps_per_slot; ++i) __builtin_amdgcn_s_sleep(127);   // ~8k cycles each
+  }
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

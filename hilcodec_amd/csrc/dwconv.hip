@@ -34,7 +34,7 @@ __device__ __forceinline__ float dw_post(const DwArgs& a, float acc, int c, long
   if (a.bias != nullptr) acc = __fadd_rn(acc, a.bias[c]);
   acc = __fmul_rn(acc, a.out_scale);
   if (a.res != nullptr) acc = __fadd_rn(acc, a.res[off]);
-  if (a.out_elu) acc = elu1(acc);
+  if (a.out_elu) acc = elu_fast(acc);
   return acc;
 }
 

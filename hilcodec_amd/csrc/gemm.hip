@@ -303,7 +303,7 @@ struct Dw5Epilogue {
           }
           if (out_elu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = elu1(o[e]);
+            for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
           }
           *reinterpret_cast<float4*>(y + rowoff + t) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -312,7 +312,7 @@ struct Dw5Epilogue {
             if (t + e < T) {
               float a = o[e];
               if (res != nullptr) a = __fadd_rn(a, res[rowoff + t + e]);
-              if (out_elu) a = elu1(a);
+              if (out_elu) a = elu_fast(a);
               y[rowoff + t + e] = a;
             }
           }

@@ -22,6 +22,9 @@ from . import ops
 # offline path: fuse every pointwise->depthwise pair into one launch (hilc_dws_conv).  The unfused
 # kernels remain the streaming path (per-hop tiles are a few samples wide) and a debugging aid.
 FUSE_DWS = True
+# narrow layers (C <= 192) are HBM-bound unless the whole residual block is one launch (hilc_resblock)
+FUSE_RESBLOCK = True
+FUSE_RESBLOCK_MAX_C = 192
 
 
 @dataclass
@@ -117,7 +120,13 @@ def _to(dev, *ts):
 # building blocks
 # --------------------------------------------------------------------------------------
 def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list]) -> Tensor:
-    """x is updated in place (the residual add writes over its own shortcut, element-wise)."""
+    """Returns the block output (x itself, updated in place, on the un-fused / two-launch paths)."""
+    if (caches is None and FUSE_RESBLOCK and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
+            and rb.dw1_b is not None and rb.dw2_b is not None
+            and x.shape[1] <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(x.shape[1], x.shape[2])):
+        # one launch per block: x is read once, y written once, everything else stays in LDS
+        return ops.resblock(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, rb.pw2_wt, rb.dw2_w, rb.dw2_b,
+                            rb.pre_scale, rb.out_scale)
     if caches is None and FUSE_DWS and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5:
         # two launches per block: [ELU, pw, dw, ELU] and [pw, dw, *scale + shortcut]; the pointwise
         # outputs never leave LDS

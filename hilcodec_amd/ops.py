@@ -97,6 +97,21 @@ def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None,
     return y
 
 
+def resblock_supported(C: int, T: int) -> bool:
+    return bool(lib.hilc_resblock_supported(C, T))
+
+
+def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, dw2_w: Tensor, dw2_b: Tensor,
+             pre_scale: float, out_scale: float) -> Tensor:
+    """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`."""
+    B, Cc, T = x.shape
+    y = torch.empty_like(x)
+    with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
+        check(lib.hilc_resblock(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w), _ptr(dw2_b),
+                                _ptr(y), B, Cc, T, pre_scale, out_scale, _stream()), "hilc_resblock")
+    return y
+
+
 def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
             stride: int = 1, hist: Optional[Tensor] = None, want_hist: bool = False,
             in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False,

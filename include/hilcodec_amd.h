@@ -63,6 +63,17 @@ int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const floa
                   float* y, int B, int K, int M, int T, int ksize, int stride, float in_scale, int in_elu,
                   float out_scale, int out_elu, void* stream);
 
+/* ---- fully fused residual block (narrow, long layers: C in {64, 96, 128, 192}, T % 4 == 0) --------
+ * y = x + out_scale * (dw2(pw2(ELU(dw1(pw1(ELU(pre_scale * x))) + dw1_b))) + dw2_b)
+ * One HBM read of x and one write of y per block; both pointwise outputs and the mid activation
+ * stay in LDS.  w1t / w2t are `[C][C]` k-major, dw*_w `[C][5]`.  y must not alias x.
+ * Replaces: SEANetResnetBlock.forward (`seanet.py:129-148`) with skip='identity', kernel 5.
+ * hilc_resblock_supported(C, T) tells the caller whether this specialisation exists. */
+int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b, const float* w2t,
+                  const float* dw2_w, const float* dw2_b, float* y, int B, int C, int T, float pre_scale,
+                  float out_scale, void* stream);
+int hilc_resblock_supported(int C, int T);
+
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)
  * y[b,c,o] = post((sum_j w[c][j] * xe[b,c,o*stride - pad + j] + bias[c]) * out_scale + res[b,c,o])

@@ -268,3 +268,42 @@ def test_dws_conv_strided_vs_oracle(env, K, M, Tn, r):
     y = ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev),
                      stride=r, in_scale=0.77, in_elu=True)
     close(y, ref, 2e-5, "dws strided")
+
+
+@pytest.mark.parametrize("C,Tn,B", [(64, 1000, 2), (96, 360, 3), (128, 124, 2), (192, 600, 1), (96, 120, 1), (64, 8, 2)])
+def test_fused_resblock_vs_oracle(env, C, Tn, B):
+    """hilc_resblock (whole residual block in one launch) against the oracle's resblock()"""
+    ops, fold, O, dev = env
+    assert ops.resblock_supported(C, Tn)
+    sd = {
+        "p.block.1.conv.conv.weight": rnd(1, C, C, 1) / C ** 0.5,
+        "p.block.2.conv.conv.weight": rnd(2, C, 1, 5) * 0.5, "p.block.2.conv.conv.bias": rnd(3, C) * 0.2,
+        "p.block.4.conv.conv.weight": rnd(4, C, C, 1) / C ** 0.5,
+        "p.block.5.conv.conv.weight": rnd(5, C, 1, 5) * 0.5, "p.block.5.conv.conv.bias": rnd(6, C) * 0.2,
+        "p.res_scale_param": torch.tensor([0.8]),
+    }
+    x = rnd(C + Tn, B, C, Tn)
+    for idx in (0, 2):
+        ref = O.resblock(sd, "p", x, RS, idx)
+        y = ops.resblock(x.to(dev), fold.pointwise_layout(sd["p.block.1.conv.conv.weight"]).to(dev),
+                         sd["p.block.2.conv.conv.weight"][:, 0].contiguous().to(dev), sd["p.block.2.conv.conv.bias"].to(dev),
+                         fold.pointwise_layout(sd["p.block.4.conv.conv.weight"]).to(dev),
+                         sd["p.block.5.conv.conv.weight"][:, 0].contiguous().to(dev), sd["p.block.5.conv.conv.bias"].to(dev),
+                         (1 + idx * RS ** 2) ** -0.5, float((RS * sd["p.res_scale_param"])[0]))
+        close(y, ref, 2e-5, f"fused resblock C{C} idx{idx}")
+    assert not ops.resblock_supported(80, Tn) and not ops.resblock_supported(C, 75)
+
+
+def test_elu_fast_error(env):
+    """The hot-path ELU (2^(x log2 e) - 1 via v_exp_f32) against expm1 in fp64 on a dense grid:
+    absolute error bounded by one fp32 ulp of an O(1) activation."""
+    ops, fold, O, dev = env
+    x = torch.cat([torch.linspace(-30, 0, 200001), torch.linspace(-1e-3, 1e-3, 20001), torch.linspace(0, 8, 1001),
+                   -torch.logspace(-30, 1, 5001)]).float()
+    n = x.numel() - x.numel() % 4
+    x = x[:n].view(1, 1, n)
+    y = ops.dw_conv(x.to(dev), torch.ones(1, 1, device=dev), in_elu=True).cpu().double()
+    ref = torch.where(x.double() > 0, x.double(), torch.expm1(x.double()))
+    err = (y - ref).abs().max().item()
+    assert err <= 1.3e-7, err
+    assert torch.equal(y[x.double() > 0].float(), x[x > 0])      # identity on the positive side

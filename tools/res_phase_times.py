@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Per-phase s_memtime stamps of hilc_resblock (debug aid): median cycles per phase over all workgroups."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hilcodec_amd import ops
+from hilcodec_amd._lib import lib
+dev = torch.device("cuda:0")
+B = 256
+for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
+    x = torch.randn(B, C, T, device=dev)
+    w1 = torch.randn(C, C, device=dev) / C ** 0.5; w2 = torch.randn(C, C, device=dev) / C ** 0.5
+    d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
+    d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
+    nblk = B * ((T + 119) // 120)
+    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); torch.cuda.synchronize()
+    buf = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
+    lib.hilc_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); torch.cuda.synchronize()
+    lib.hilc_debug_set_stamp_buffer(None)
+    d = (buf[:, 1:] - buf[:, :-1]).double()
+    med = d.median(dim=0).values.tolist()
+    tot = (buf[:, 7] - buf[:, 0]).double().median().item()
+    names = ["P0 load+ELU", "G1", "P2 acc->lds", "P3 dw+ELU", "G2", "P5 acc->lds", "P6 dw+store"]
+    mf = (C // 2) * (C // 32) * 64
+    print(f"C={C}: total {tot:.0f} ticks; ideal MFMA per GEMM {mf} cyc; " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
