@@ -1,0 +1,131 @@
+"""CPU: host-side logic — the C-ABI library loads and exports every symbol of include/hilcodec_amd.h,
+module trees carry the reference's state-dict keys, weight folding is bit-exact, and nothing falls
+back to the CPU silently.  (No kernel is launched here.)"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hilcodec_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hilcodec_amd import _lib
+    header = open(os.path.join(ROOT, "include", "hilcodec_amd.h")).read()
+    declared = set(re.findall(r"\b(hilc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hilcodec_amd.h but not exported"
+    for name in _lib.SIGNATURES:
+        assert name in declared, f"{name} bound in _lib.py but not declared in the header"
+    assert _lib.lib.hilc_abi_version() == _lib.ABI_VERSION
+    assert b"num_quantizers" in _lib.lib.hilc_error_string(-5)
+
+
+def test_error_codes_without_gpu():
+    """Argument validation happens before any launch, so it can be exercised on a CPU-only box."""
+    from hilcodec_amd._lib import lib
+    assert lib.hilc_pw_conv(None, None, None, None, None, 1, 8, 8, 8, 1.0, 0, 1.0, None) == -2      # NULL
+    one = ctypes.c_void_p(16)
+    assert lib.hilc_pw_conv(one, one, None, None, one, 0, 8, 8, 8, 1.0, 0, 1.0, None) == -1          # shape
+    assert lib.hilc_pw_conv(one, one, None, None, one, 1, 8, 6, 8, 1.0, 0, 1.0, None) == -4          # unsupported
+    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 9, 0, 0, None) == -5
+    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 0, 0, 0, None) == -5
+    assert lib.hilc_resblock_supported(96, 24000) == 1 and lib.hilc_resblock_supported(768, 600) == 0
+    assert lib.hilc_resblock(one, one, one, one, one, one, one, one, 1, 96, 16, 1.0, 1.0, None) == -4  # y aliases x
+
+
+def test_cpu_tensors_raise():
+    import hilcodec_amd
+    from hilcodec_amd import ops
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.pw_conv(torch.zeros(1, 8, 8), torch.zeros(8, 8))
+    mk = synth.model_kwargs("hil_speech")
+    m = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+    with pytest.raises(RuntimeError):
+        m.encoder(torch.zeros(1, 1, 640))
+
+
+def test_offline_module_tree_matches_reference_keys():
+    import hilcodec_amd
+    for name in ("hil_speech", "hil_music"):
+        mk = synth.model_kwargs(name)
+        m = hilcodec_amd.HILCodec(24000, 1, **mk)
+        own = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith("_extra_state")}
+        assert own == synth.offline_param_shapes(mk)          # same keys, same order, same shapes
+        assert sum(p.numel() for p in m.parameters()) == 9577019
+        assert m.encoder.hop_length == 320 and m.decoder.hop_length == 320 and m.sample_rate == 24000
+        assert m.encoder.dimension == 128 and m.encoder.ratios == [2, 4, 5, 8] and m.decoder.ratios == [8, 5, 4, 2]
+        # a freshly built model has kmeans_init codebooks marked un-initialised, like the reference
+        assert not m.quantizer.layers[0].initted and m.quantizer.layers[0].get_extra_state() == {"initted": False}
+
+
+def test_unsupported_options_fail_loudly():
+    import hilcodec_amd
+    mk = synth.model_kwargs("hil_speech")
+    for bad in (dict(skip="1x1"), dict(causal=False), dict(dilation_base=2), dict(norm="spectral_norm"),
+                dict(vq="ResidualGainShapeVQ"), dict(act_all=True)):
+        with pytest.raises((NotImplementedError, ValueError, AssertionError)):
+            hilcodec_amd.HILCodec(24000, 1, **{**mk, **bad})
+    with pytest.raises(RuntimeError):
+        hilcodec_amd.HILCodec(24000, 1, **{**mk, "expansion": 2, "groups": 4})
+
+
+def test_weight_folds_bit_exact():
+    from hilcodec_amd import fold
+    from hilcodec_amd.models.hilcodec.modules import SConv1d
+    from oracle import hilcodec_oracle as O
+    v = torch.from_numpy(synth.normalish(1, 24 * 7 * 5)).view(24, 7, 5)
+    g = torch.from_numpy(synth.uniform(2, 24, 0.5, 1.5)).view(24, 1, 1)
+    assert torch.equal(fold.weight_norm_fold(v, g), torch._weight_norm(v, g, 0))
+    assert torch.equal(fold.weight_standardization_fold(v, g, torch.tensor([1.3])),
+                       O.fold_weight_standardization(v, g, torch.tensor([1.3])))
+    m = SConv1d(7, 24, 1, norm="weight_norm", bias=True)
+    with torch.no_grad():
+        m.conv.conv.weight_v.copy_(v[:, :, :1]); m.conv.conv.weight_g.copy_(g)
+    w0 = m.conv.conv.effective_weight()
+    m.conv.conv.remove_reparameterization()
+    assert "conv.conv.weight" in m.state_dict() and "conv.conv.weight_g" not in m.state_dict()
+    assert torch.equal(m.conv.conv.effective_weight(), w0)
+    basis = synth.stft_basis(64)
+    bt = fold.stft_basis_layout(basis)
+    assert bt.shape == (64, 96) and torch.equal(bt[:, 0], basis[0, 0]) and torch.equal(bt[:, 1], basis[33, 0])
+    assert torch.equal(bt[:, 64], basis[32, 0]) and torch.equal(bt[:, 65], basis[65, 0]) and not bt[:, 66:].any()
+    cb, cbt, norms = fold.codebook_tables([v[:, :, 0], v[:, :, 1]])
+    assert cb.shape == (2, 24, 7) and torch.equal(cbt[1], v[:, :, 1].t()) and torch.equal(norms[0], v[:, :, 0].t().pow(2).sum(0))
+
+
+def test_streaming_module_tree_and_mapping():
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec
+    from oracle import hilcodec_oracle as O
+    mk = dict(synth.model_kwargs("hil_speech"))
+    full = synth.model_kwargs("hil_speech")
+    for k in ("spec_learnable", "causal", "pad_mode"):
+        mk.pop(k)
+    m = HILCodec(24000, **mk).eval()
+    x = torch.zeros(5, 1)
+    ce, cd = m.initialize_cache(x)
+    enc_shapes, dec_shapes = O.stream_cache_shapes(full)
+    assert [tuple(c.shape) for c in ce] == [(5, c, l) for c, l in enc_shapes]
+    assert [tuple(c.shape) for c in cd] == [(5, c, l) for c, l in dec_shapes]
+    assert m.encoder.num_cache == 22 and not any(c.any() for c in ce + cd)
+    sd = synth.synth_state_dict("hil_speech", seed=7)
+    m.load_offline_state_dict(sd)
+    assert m.decoder.blocks[0][2].pre_scale == 1.0 and m.encoder.blocks[0][1].pre_scale == (1 + 2 * 0.5773502691896258 ** 2) ** -0.5
+    m.remove_weight_reparameterizations()
+    p = O.stream_prepare(sd, full)
+    # merge_scaling reproduces the reference's algebra bit for bit (oracle == reference, tests/test_oracle_*)
+    assert torch.equal(m.encoder.conv_pre.weight.data, p["enc.conv_pre.weight"])
+    assert torch.equal(m.encoder.spec_post.layer.weight.data, p["enc.spec_post.layer.weight"])
+    assert torch.equal(m.encoder.spec_post.layer.bias.data, p["enc.spec_post.layer.bias"])
+    assert torch.equal(m.encoder.blocks[2][1].block[1].depthwise.weight.data, p["enc.blocks.2.1.1.dw.weight"])
+    assert torch.equal(m.decoder.blocks[3][2].block[1].depthwise.bias.data, p["dec.blocks.3.2.1.dw.bias"])
+    assert torch.equal(m.decoder.conv_post.weight.data, p["dec.post.weight"])
+    assert torch.equal(m.decoder.conv_post.bias.data, p["dec.post.bias"])
+    assert torch.equal(m.dequantizer.layers[3].embed, sd["quantizer.layers.3.embed"])

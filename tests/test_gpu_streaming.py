@@ -1,0 +1,140 @@
+"""GPU parity of the streaming model (cache-in/cache-out protocol of models/hilcodec/streaming.py) against
+golden vectors from the REAL reference streaming model and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from hilcodec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def build_streaming(seed=7, name="hil_speech"):
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec
+    mk = dict(synth.model_kwargs(name))
+    sd = synth.synth_state_dict(name, seed=seed)
+    for k in ("spec_learnable", "causal", "pad_mode"):
+        mk.pop(k)
+    model = HILCodec(24000, **mk).eval()
+    model.load_offline_state_dict(sd)
+    model.remove_weight_reparameterizations()
+    return model, synth.model_kwargs(name), sd
+
+
+def test_streaming_golden(golden):
+    g = golden("stream_hil_speech")
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming(int(g["weight_seed"]))
+    hops = int(g["hops"])
+    x = synth.synth_clips(1, 320 * hops, seed=int(g["clip_seed"])).to(dev)
+    ce, cd = model.initialize_cache(x)
+    assert len(ce) == 22 and len(cd) == 30 and model.encoder.num_cache == 22
+    zs, ids, ws = [], [], []
+    for h in range(hops):
+        z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)], *ce)
+        idx = model.quantizer(z, 8)
+        q = model.dequantizer(idx, 8)
+        w, cd = model.decoder(q, *cd)
+        zs.append(z); ids.append(idx); ws.append(w)
+        if h == 0:
+            assert np.allclose([c.double().sum().item() for c in ce], g["e_first_sums"], rtol=1e-4, atol=2e-3)
+            assert np.allclose([c.double().sum().item() for c in cd], g["d_first_sums"], rtol=1e-4, atol=2e-3)
+    z = torch.cat(zs, 1).cpu(); idx = torch.cat(ids, 2).cpu(); wav = torch.cat(ws, 2).cpu()
+    assert z.shape == (1, hops, 128) and idx.shape == (8, 1, hops) and idx.dtype == torch.int64 and wav.shape == (1, 1, 320 * hops)
+    assert (z - T(g["z"])).abs().max() < 2e-5
+    assert torch.equal(idx, T(g["indices"]).long())
+    assert (wav - T(g["wav"])).abs().max() < 1e-4
+    for i, c in enumerate(ce):
+        ref = T(g[f"e_out{i}"])
+        assert c.shape == ref.shape and (c.cpu() - ref).abs().max() < 5e-5, f"e_out{i}"
+    for i, c in enumerate(cd):
+        ref = T(g[f"d_out{i}"])
+        assert c.shape == ref.shape and (c.cpu() - ref).abs().max() < 5e-5, f"d_out{i}"
+    # multi-frame chunk == frame-by-frame (caches are exact)
+    ce2, _ = model.initialize_cache(x)
+    z3, _ = model.encoder(x[:, :, :960], *ce2)
+    assert (z3.cpu() - T(g["z_chunk3"])).abs().max() < 2e-5
+    # whole-model forward: encoder -> quantizer -> dequantizer -> decoder with both cache lists
+    ce3, cd3 = model.initialize_cache(x)
+    w_all, ce4, cd4 = model(x[:, :, :640], 8, *ce3, *cd3)
+    assert (w_all.cpu() - T(g["wav"])[:, :, :640]).abs().max() < 1e-4 and len(ce4) == 22 and len(cd4) == 30
+
+
+def test_streaming_vs_oracle_batched_and_int16_indices():
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming(seed=11)
+    p = O.stream_prepare(sd, mk)
+    B, hops = 3, 4
+    x = synth.synth_clips(B, 320 * hops, seed=5)
+    ce, cd = model.initialize_cache(x.to(dev))
+    oe, od = O.stream_init_cache(mk, B)
+    for h in range(hops):
+        xin = x[:, :, 320 * h: 320 * (h + 1)]
+        z, ce = model.encoder(xin.to(dev), *ce)
+        idx = model.quantizer(z, 4)
+        zo, oe = O.stream_encoder(p, mk, xin, oe)
+        io = O.stream_quantize(p, zo, 4)
+        assert (z.cpu() - zo).abs().max() < 2e-5
+        assert torch.equal(idx.cpu(), io)
+        # the wire format of test_onnx.py is int16: the dequantizer must accept it
+        q = model.dequantizer(idx.to(torch.int16), 4)
+        qo = O.stream_dequantize(p, io, 4)
+        assert torch.equal(q.cpu(), qo)
+        w, cd = model.decoder(q, *cd)
+        wo, od = O.stream_decoder(p, mk, qo, od)
+        assert (w.cpu() - wo).abs().max() < 1e-4
+        for a, b in zip(ce, oe):
+            assert (a.cpu() - b).abs().max() < 5e-5
+        for a, b in zip(cd, od):
+            assert (a.cpu() - b).abs().max() < 5e-5
+
+
+def test_streaming_unmerged_equals_merged():
+    """merge_scaling is algebra only: the un-merged streaming model gives the same z up to rounding —
+    except for the wav_std scalings, which (as in the reference) only exist in merged form."""
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec
+    dev = torch.device("cuda:0")
+    mk = dict(synth.model_kwargs("hil_speech"))
+    sd = synth.synth_state_dict("hil_speech", seed=7)
+    for k in ("spec_learnable", "causal", "pad_mode"):
+        mk.pop(k)
+    m1 = HILCodec(24000, **mk).eval(); m1.load_offline_state_dict(sd)
+    m2 = HILCodec(24000, **mk).eval(); m2.load_offline_state_dict(sd); m2.remove_weight_reparameterizations()
+    x = synth.synth_clips(1, 640, seed=2).to(dev)
+    c1, _ = m1.initialize_cache(x); c2, _ = m2.initialize_cache(x)
+    z1, _ = m1.encoder(x / 0.1122080159, *c1)      # un-merged conv_pre lacks the 1/wav_std
+    z2, _ = m2.encoder(x, *c2)
+    # the spectrogram branch of m1 sees the rescaled waveform too, so only compare shapes/finite here
+    assert z1.shape == z2.shape and torch.isfinite(z1).all()
+    assert "encoder.conv_pre.weight" in m2.state_dict() and "encoder.conv_pre.weight_g" in m1.state_dict()
+    assert "encoder.spec_post.layer.bias" in m2.state_dict()
+
+
+def test_streaming_layer_classes(golden):
+    """CausalConv1d / CausalConvTranspose1d / CausalSTFT with the reference's forward(x, cache) protocol."""
+    from hilcodec_amd.models.hilcodec import causal_layers as CL
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    g = golden("ops")
+    c = CL.CausalConv1d(8, 8, 10, 5, groups=8, bias=True, norm="none")
+    with torch.no_grad():
+        c.weight.copy_(T(g["cconv.w"])); c.bias.copy_(T(g["cconv.b"]))
+    y, nc = c(T(g["cconv.x"]).to(dev), T(g["cconv.cache"]).to(dev))
+    assert (y.cpu() - T(g["cconv.y"])).abs().max() < 2e-6 and torch.equal(nc.cpu(), T(g["cconv.cache_out"]))
+    assert c.initialize_cache(torch.zeros(3, 1)).shape == (3, 8, 5)
+    ct = CL.CausalConvTranspose1d(8, 8, 10, 5, groups=8, bias=False, norm="none")
+    with torch.no_grad():
+        ct.weight.copy_(T(g["cconvtr.w"]))
+    y, nc = ct(T(g["cconvtr.x"]).to(dev), T(g["cconvtr.cache"]).to(dev))
+    assert (y.cpu() - T(g["cconvtr.y"])).abs().max() < 2e-6 and torch.equal(nc.cpu(), T(g["cconvtr.cache_out"]))
+    st = CL.CausalSTFT(64, 2)
+    wav = synth.synth_clips(2, 63 + 128, seed=1)
+    ref = O.causal_stft_mag(wav, st.weight, 2, pad=False, clamp=False)
+    assert (st(wav.to(dev)).cpu() - ref).abs().max() < 2e-5
+    with pytest.raises(ValueError):
+        CL.SConv1d(4, 4, 3, norm="spectral_norm")
