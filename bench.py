@@ -3,14 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-One "step" = one offline pass (encoder -> RVQ(Nq) -> decoder) over a batch of 256 synthetic 1 s,
-24 kHz clips per GPU, inputs resident in HBM.  Metric = audio-seconds processed per wall second
-(xRT), whole job.  Clips shard embarrassingly: every rank processes its own 256 clips (weak scaling);
-the only collective is a gather of per-rank counters (RCCL), as in BASELINE.json's north star.
+Default (BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = one
+offline pass (encoder -> RVQ(Nq) -> decoder) over a batch of 256 synthetic 1 s, 24 kHz clips per GPU,
+inputs resident in HBM.  Metric = audio-seconds processed per wall second (xRT), whole job.  Clips
+shard embarrassingly: rank r processes clips [r*256, (r+1)*256) (weak scaling); the only collective
+is an all_gather of per-rank counters over RCCL after the timed region.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the fp32-MFMA pointwise-conv GEMM,
-timed per launch with HIP events on the launch stream inside the timed region) and `cpu_baseline`
-(the CPU oracle timed on the host cores over a bounded sample of the same workload)."""
+Other workloads (parity-test configs, not the headline line): `--model hil_music` (configs[2]),
+`--mode streaming` (configs[3]: 1024 concurrent streams per GPU, one 320-sample hop per step, the 52
+cache tensors of every stream resident in HBM).
+
+Prints ONE JSON line (rank 0) with
+  roofline     — dominant kernel = the fp32-MFMA GEMM core (pointwise convs and everything fused
+                 onto them), every launch timed with HIP events on the launch stream INSIDE the timed
+                 region; achieved = algorithmic FLOPs / summed launch time; peak 157.3 TFLOP/s.
+  cpu_baseline — the CPU oracle (restatement of the reference in plain torch fp32 ops, bit-identical
+                 to the reference, tests/test_oracle_vs_reference.py) timed on this box's host cores
+                 over a bounded sample of the same workload."""
 from __future__ import annotations
 
 import argparse
@@ -24,35 +33,44 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, no xf32 on gfx950
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense; no xf32/TF32 on gfx950
 FLOP_PER_AUDIO_SECOND = {"hil_speech": 34.219e9, "hil_music": 34.298e9}
+MFMA_KINDS = ("pw_conv", "dws_conv", "resblock", "up_conv")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--model", default="hil_speech", choices=["hil_speech", "hil_music"])
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
+    ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=16)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.mode == "offline":
+        a.steps = 5 if a.steps is None else a.steps
+        a.warmup = 2 if a.warmup is None else a.warmup
+        a.batch = 256 if a.batch is None else a.batch
+    else:
+        a.steps = 75 if a.steps is None else a.steps
+        a.warmup = 5 if a.warmup is None else a.warmup
+        a.batch = 1024 if a.batch is None else a.batch
+    return a
 
 
 def cpu_baseline(name, mk, sd, clips: int, samples: int):
-    """The oracle (CPU restatement of the reference, plain torch fp32 ops == the reference's own
-    arithmetic) on the host cores, bounded sample."""
     from hilcodec_amd import synth
-    from oracle import hilcodec_oracle as O
+    from oracle import hilcodec_oracle as O           # the checker doubles as the timed CPU baseline
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     x = synth.synth_clips(clips, samples, seed=1234)
     chunk = 8
     with torch.no_grad():
-        O.codec_forward(sd, x[:1], mk)                        # warm-up
+        O.codec_forward(sd, x[:1], mk)                # warm-up
         t0 = time.perf_counter()
         for i in range(0, clips, chunk):
             O.codec_forward(sd, x[i:i + chunk], mk)
@@ -65,19 +83,14 @@ def cpu_baseline(name, mk, sd, clips: int, samples: int):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    from hilcodec_amd import distributed as D
+    rank, world, local = D.env_rank_world()
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    D.init("nccl", dev)
 
     import hilcodec_amd
     from hilcodec_amd import ops, synth
@@ -85,70 +98,83 @@ def main():
     name = args.model
     mk = synth.model_kwargs(name)
     sd = synth.synth_state_dict(name, seed=7)
-    model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
-    model.load_state_dict(sd, strict=False)
-    for l in model.quantizer.layers:
-        l.initted = True
     nq = mk["vq_kwargs"]["num_quantizers"]
-
-    # this rank's shard of the global batch: clips [rank*B, (rank+1)*B)
     B, T = args.batch, args.samples
-    x = synth.synth_clips(B, T, seed=1234, first=rank * B).to(dev)
+    lo, hi = D.shard_range(B * world, rank, world)     # this rank's clips / streams of the global batch
 
-    def step():
-        z = model.encoder(x)
-        q, _, _, idx = model.quantizer(z, None, return_indices=True)
-        wav = model.decoder(q)
-        return idx, wav
+    if args.mode == "offline":
+        model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+        model.load_state_dict(sd, strict=False)
+        for l in model.quantizer.layers:
+            l.initted = True
+        x = synth.synth_clips(hi - lo, T, seed=1234, first=lo).to(dev)
+        audio_per_step = (hi - lo) * T / 24000.0
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        def step(i):
+            z = model.encoder(x)
+            q, _, _, idx = model.quantizer(z, None, return_indices=True)
+            wav = model.decoder(q)
+            return idx, wav
+    else:
+        from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
+        smk = {k: v for k, v in mk.items() if k not in ("spec_learnable", "causal", "pad_mode")}
+        model = StreamingHILCodec(24000, **smk).eval()
+        model.load_offline_state_dict(sd)
+        model.remove_weight_reparameterizations()
+        hop = 320
+        nbuf = 8                                           # distinct input hops, cycled
+        xs = [synth.synth_clips(hi - lo, hop, seed=4321 + 7 * j, first=lo).to(dev) for j in range(nbuf)]
+        state = {"ce": None, "cd": None}
+        state["ce"], state["cd"] = model.initialize_cache(xs[0])
+        audio_per_step = (hi - lo) * hop / 24000.0
+
+        def step(i):
+            z, state["ce"] = model.encoder(xs[i % nbuf], *state["ce"])
+            idx = model.quantizer(z, nq)
+            q = model.dequantizer(idx, nq)
+            wav, state["cd"] = model.decoder(q, *state["cd"])
+            return idx, wav
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            idx, wav = step()
+        for i in range(args.warmup):
+            idx, wav = step(i)
         torch.cuda.synchronize()
         timer = None
         if not args.no_launch_timing:
             timer = ops.LaunchTimer()
             ops.TIMER = timer
-        barrier()
+        D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            idx, wav = step()
+        for i in range(args.steps):
+            idx, wav = step(args.warmup + i)
         torch.cuda.synchronize()
-        barrier()
+        D.barrier()
         dt = time.perf_counter() - t0
         ops.TIMER = None
 
-    checksum = int(idx.sum().item())
-    counters = torch.tensor([float(B * args.steps), B * args.steps * T / 24000.0, dt, float(checksum)],
-                            dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        gathered = [torch.zeros_like(counters) for _ in range(world)]
-        dist.all_gather(gathered, counters)
-        gathered = torch.stack(gathered).cpu()
-    else:
-        gathered = counters.cpu().unsqueeze(0)
-
+    per_rank = D.gather_counters({"clips": float((hi - lo) * args.steps), "audio_s": audio_per_step * args.steps,
+                                  "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)
     if rank == 0:
-        wall = float(gathered[:, 2].max())
-        audio_s = float(gathered[:, 1].sum())
-        value = audio_s / wall
+        agg = D.aggregate(per_rank)
+        value = agg["xrt"]
+        cfg_ix = {("offline", "hil_speech"): 1, ("offline", "hil_music"): 2, ("streaming", "hil_speech"): 3}.get(
+            (args.mode, name), None)
+        if args.mode == "offline":
+            workload = (f"{name}, batch={B}x{T / 24000.0:g} s 24 kHz per GPU, Nq={nq}, offline encode+RVQ+decode "
+                        f"(BASELINE configs[{cfg_ix}])")
+        else:
+            workload = (f"{name} streaming, hop=320, {B} concurrent streams per GPU, Nq={nq}, 22+30 caches per stream "
+                        f"resident in HBM (BASELINE configs[{cfg_ix}])")
         out = {
             "metric": "audio-seconds/sec (xRT) encode+RVQ+decode, 24 kHz batch=256",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": agg["wall_s"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name}, batch={B}x{T / 24000.0:g} s 24 kHz per GPU, Nq={nq}, offline "
-                                   f"encode+RVQ+decode (BASELINE configs[{1 if name == 'hil_speech' else 2}])",
-                       "global_batch": B * world, "samples_per_clip": T, "parallelism": f"clip-sharded x{world}"},
+            "config": {"workload": workload, "global_batch": B * world, "samples_per_clip": T if args.mode == "offline" else 320,
+                       "parallelism": f"clip-sharded x{world}, replicated weights, counters all_gather only"},
             "frames_per_sec": value * 75.0,
-            "index_checksum": int(gathered[:, 3].sum()),
+            "index_checksum": int(agg["index_checksum"]),
         }
         whole_tflops = value * FLOP_PER_AUDIO_SECOND[name] / 1e12 / world
         roof = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
@@ -156,14 +182,12 @@ def main():
                 "whole_path_frac": whole_tflops / FP32_MFMA_PEAK_TFLOPS}
         if timer is not None:
             tot = timer.totals()
-            # dominant kernel = the fp32-MFMA GEMM core (every instantiation of hilc::gemm_kernel /
-            # the fused residual-block kernel built on it): pointwise convs with their fused epilogues
-            mfma_kinds = [k for k in ("pw_conv", "dws_conv", "resblock") if k in tot]
-            launches = sum(tot[k][0] for k in mfma_kinds)
-            flops = sum(tot[k][1] for k in mfma_kinds)
-            secs = sum(tot[k][2] for k in mfma_kinds)
+            kinds = [k for k in MFMA_KINDS if k in tot]
+            launches = sum(tot[k][0] for k in kinds)
+            flops = sum(tot[k][1] for k in kinds)
+            secs = sum(tot[k][2] for k in kinds)
             roof.update({
-                "kernel": "hilc::gemm_kernel<MB,Loader,Epilogue> family (" + "+".join(mfma_kinds) +
+                "kernel": "hilc::gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C> (" + "+".join(kinds) +
                           "; fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": flops / secs / 1e12, "frac": flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "launches_per_step": launches // args.steps, "avg_launch_us": secs / launches * 1e6,
@@ -171,8 +195,8 @@ def main():
                 "share_of_gpu_time": secs / sum(v[2] for v in tot.values()),
             })
             out["kernel_time_breakdown_ms_per_step"] = {k: v[2] / args.steps * 1e3 for k, v in sorted(tot.items())}
-            hbm = {k: v[1] / v[2] / 1e9 for k, v in tot.items() if k in ("dw_conv", "dw_convtr", "conv_pre", "conv_post")}
-            out["hbm_bound_ops_GBps"] = hbm
+            out["hbm_bound_ops_GBps"] = {k: v[1] / v[2] / 1e9 for k, v in tot.items()
+                                         if k in ("dw_conv", "dw_convtr", "conv_pre", "conv_post")}
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, mk, sd, args.cpu_clips, T)

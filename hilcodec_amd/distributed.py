@@ -1,0 +1,61 @@
+"""Multi-GPU layout of the path: one process per GPU, clips (or streams) sharded contiguously, weights
+replicated, NO data-path collective — the only exchange is a gather of per-rank counters after the
+timed region.  `torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used by
+the CPU tests."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str, device: torch.device = None) -> Tuple[int, int]:
+    rank, world, _ = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of `total` independent clips/streams for `rank`
+    (the first `total % world` ranks get one extra)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def gather_counters(counters: Dict[str, float], device: torch.device) -> List[Dict[str, float]]:
+    """all_gather of a small dict of scalars (<= 64 B per rank); returns one dict per rank, on every rank."""
+    keys = sorted(counters)
+    t = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+    else:
+        out = [t]
+    return [dict(zip(keys, o.cpu().tolist())) for o in out]
+
+
+def aggregate(per_rank: List[Dict[str, float]]) -> Dict[str, float]:
+    """Whole-job figures: audio seconds add up, wall time is the slowest rank's."""
+    wall = max(r["wall_s"] for r in per_rank)
+    audio = sum(r["audio_s"] for r in per_rank)
+    return {"wall_s": wall, "audio_s": audio, "clips": sum(r["clips"] for r in per_rank), "xrt": audio / wall,
+            "index_checksum": sum(r.get("index_checksum", 0.0) for r in per_rank)}

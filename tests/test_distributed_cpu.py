@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the multi-GPU layout of the path — contiguous clip shards, replicated
+weights, no data-path collective, one gather of counters."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_everything():
+    from hilcodec_amd.distributed import shard_range
+    for total in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(2048, 3, 8) == (768, 1024)        # BASELINE config 5: 256 clips per GPU
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from hilcodec_amd import distributed as D, synth
+    from oracle import hilcodec_oracle as O
+    torch.set_num_threads(2)
+    r, w = D.init("gloo")
+    assert (r, w) == (rank, world)
+    total = 5                                   # uneven on purpose: shards of 3 and 2 clips
+    lo, hi = D.shard_range(total, rank, world)
+    mk = synth.model_kwargs("hil_speech")
+    sd = synth.synth_state_dict("hil_speech", seed=7)       # replicated weights: every rank builds the same
+    x = synth.synth_clips(hi - lo, 1600, seed=1234, first=lo)
+    D.barrier()
+    z = O.encoder_forward(sd, x, mk)            # CPU stand-in for the per-rank work; the GPU path is tested with -m gpu
+    _, _, _, idx = O.rvq_forward(sd, z, None, 8)
+    D.barrier()
+    per_rank = D.gather_counters({"clips": hi - lo, "audio_s": (hi - lo) * 1600 / 24000.0, "wall_s": 1.0 + rank,
+                                  "index_checksum": float(idx.sum())}, torch.device("cpu"))
+    agg = D.aggregate(per_rank)
+    q.put((rank, lo, hi, per_rank, agg, float(idx.sum())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_gather():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, pr0, agg0, cs0), (r1, lo1, hi1, pr1, agg1, cs1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 5)
+    assert pr0 == pr1 and agg0 == agg1                       # every rank sees the same gathered table
+    assert agg0["clips"] == 5 and agg0["wall_s"] == 2.0      # max over ranks
+    assert abs(agg0["audio_s"] - 5 * 1600 / 24000.0) < 1e-12 and abs(agg0["xrt"] - agg0["audio_s"] / 2.0) < 1e-12
+    assert agg0["index_checksum"] == cs0 + cs1
+    # sharding does not change results: the union of the shards equals the un-sharded batch
+    sys.path.insert(0, ROOT)
+    from hilcodec_amd import synth
+    from oracle import hilcodec_oracle as O
+    mk = synth.model_kwargs("hil_speech")
+    sd = synth.synth_state_dict("hil_speech", seed=7)
+    x = synth.synth_clips(5, 1600, seed=1234)
+    _, _, _, idx = O.rvq_forward(sd, O.encoder_forward(sd, x, mk), None, 8)
+    assert float(idx.sum()) == cs0 + cs1

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output (kernel stats + FETCH_SIZE / WRITE_SIZE PMC passes) into the small
+summaries committed under profiles/.  HBM traffic follows MI355X_MICROARCH.md §HBM: bytes =
+FETCH_SIZE*1024*2 (gfx950 reports half of a wide coalesced read) + WRITE_SIZE*1024; separate passes."""
+import collections
+import csv
+import json
+import re
+import sys
+
+d, out_prefix, steps_total = sys.argv[1], sys.argv[2], int(sys.argv[3])
+
+
+def short(name):
+    m = re.search(r"gemm_kernel<(\d), \(anonymous namespace\)::(\w+), \(anonymous namespace\)::(\w+)>", name)
+    if m:
+        return f"gemm_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>"
+    m = re.search(r"(\w+_kernel)(<\d+>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+stats = collections.OrderedDict()
+for r in csv.DictReader(open(f"{d}/stats_kernel_stats.csv")):
+    stats[short(r["Name"])] = dict(calls=int(r["Calls"]), total_ms=float(r["TotalDurationNs"]) / 1e6,
+                                   avg_us=float(r["AverageNs"]) / 1e3, pct=float(r["Percentage"]))
+traffic = collections.defaultdict(lambda: [0.0, 0.0, 0])
+for which, col in (("fetch", 0), ("write", 1)):
+    for r in csv.DictReader(open(f"{d}/{which}_counter_collection.csv")):
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        k = short(r["Kernel_Name"])
+        traffic[k][col] += float(r["Counter_Value"])
+        if col == 0:
+            traffic[k][2] += 1
+with open(out_prefix + "_kernel_stats.csv", "w") as f:
+    f.write("kernel,calls,total_ms,avg_us,percent,hbm_read_GB_per_step,hbm_write_GB_per_step\n")
+    for k, s in stats.items():
+        fe, wr, n = traffic.get(k, [0, 0, 0])
+        f.write(f"{k},{s['calls']},{s['total_ms']:.3f},{s['avg_us']:.1f},{s['pct']:.2f},"
+                f"{fe * 1024 * 2 / 1e9 / steps_total:.3f},{wr * 1024 / 1e9 / steps_total:.3f}\n")
+mf = [k for k in stats if k.startswith("gemm_kernel") and "Stft" not in k or k.startswith("resblock")]
+tot_ms = sum(stats[k]["total_ms"] for k in mf)
+calls = sum(stats[k]["calls"] for k in mf)
+rd = sum(traffic[k][0] for k in mf) * 1024 * 2
+wr = sum(traffic[k][1] for k in mf) * 1024
+print(json.dumps({"mfma_family_kernels": mf, "calls": calls, "total_ms": tot_ms, "avg_launch_us": tot_ms / calls * 1e3,
+                  "hbm_bytes_per_launch": (rd + wr) / calls, "hbm_read_GB_per_step": rd / 1e9 / steps_total,
+                  "hbm_write_GB_per_step": wr / 1e9 / steps_total}))
