@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhilcodec_amd.so")
+LIB_PATH = os.environ.get("HILC_LIB") or os.path.join(_HERE, "lib", "libhilcodec_amd.so")   # HILC_LIB: A/B builds (tools/)
 
 _f, _i, _p, _d = C.c_float, C.c_int, C.c_void_p, C.c_double
 

@@ -168,6 +168,45 @@ __global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
   a.y[b * (long)a.T + t] = acc;
 }
 
+// Offline fast path (k = 5, T % 4 == 0, no history): 64 threads x 4 samples = 256 samples per block;
+// the block's 4 waves split the channels (c = wave, wave+4, ...) so 4x more loads are in flight, each
+// lane moves 16 B, each sample's prologue (ELU) is evaluated once; partial sums meet in LDS.  The
+// channel order of the reduction is c ascending within a wave, then wave 0..3 — fixed.
+__global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
+  __shared__ float part[4][256];
+  const long b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = (blockIdx.y * 64 + lane) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t < a.T) {
+    for (int c = wave; c < a.C; c += 4) {
+      const float* xrow = a.x + (b * a.C + c) * (long)a.T;
+      const f32x4 cur = prologue4v(*reinterpret_cast<const f32x4*>(xrow + t), a.in_scale, a.in_elu);
+      f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+      if (t >= 4) prev = prologue4v(*reinterpret_cast<const f32x4*>(xrow + t - 4), a.in_scale, a.in_elu);
+      const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
+      float w[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[j] = a.w[c * 5 + j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[e] = fmaf(w[j], v[e + j], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[wave][lane * 4 + e] = acc[e];
+  __syncthreads();
+  const int tt = blockIdx.y * 256 + threadIdx.x;
+  if (tt < a.T) {
+    float s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (a.bias) s = __fadd_rn(s, a.bias[0]);
+    s = __fmul_rn(s, a.out_scale);
+    if (a.do_tanh) s = tanhf(s);
+    a.y[b * (long)a.T + tt] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, float* y, int C, int T, float eps,
                                                      float scale, int channel_last_out) {
   long b = blockIdx.x;
@@ -270,7 +309,10 @@ extern "C" int hilc_conv_post(const float* x, const float* hist, const float* w,
   a.x = x; a.hist = hist; a.w = w; a.bias = bias; a.y = y; a.C = C; a.T = T; a.ksize = ksize;
   a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.do_tanh = do_tanh;
   dim3 grid((unsigned)B, (unsigned)ceil_div(T, 256));
-  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  const bool fast = ksize == 5 && T % 4 == 0 && hist == nullptr && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  HILC_CLEAR_ERROR();
+  if (fast) hipLaunchKernelGGL(conv_post_k5_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();
   if (hist_out)
     return launch_hist_out(x, hist, hist_out, (long)B * C, T, ksize - 1, ksize - 1, in_scale, in_elu, (hipStream_t)stream);

@@ -14,12 +14,18 @@
 // Epilogue — consumes the accumulators; may route them through LDS (the staging buffers are dead by
 //            then) to apply a depthwise convolution along time before anything touches HBM.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hilc {
 
 constexpr int BN = 128;
-constexpr int BK = 16;
+#ifndef HILC_BK
+#define HILC_BK 16
+#endif
+constexpr int BK = HILC_BK;   // K-slice depth (multiple of 8)
+constexpr int BP = BK / 8;     // B staging passes: 256 threads cover 8 rows x 128 columns per pass
 constexpr int NT = 256;
 
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, 
 
   // Straight-line staging code: every guard is a select on the address / value, never a branch, so
   // the K loop body stays one basic block and the scheduler can run the LDS reads ahead of the MFMAs.
-  f32x4 ra[AP], rb[2];
+  f32x4 ra[AP], rb[BP];
   bool a_ok[AP];
   const float* a_ptr[AP];
   int a_k[AP];
@@ -84,8 +90,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, 
       ra_ok[p] = a_ok[p] && (k0 + a_k[p]) < K;   // rows k >= K of A are zero: B may hold anything finite there
       ra[p] = *reinterpret_cast<const f32x4*>(ra_ok[p] ? a_ptr[p] + (long)k0 * ldw : wt);
     }
-    rb[0] = ld.fetch(ls, min(k0 + (tid >> 5), K - 1));
-    rb[1] = ld.fetch(ls, min(k0 + (tid >> 5) + 8, K - 1));
+#pragma unroll
+    for (int h = 0; h < BP; ++h) rb[h] = ld.fetch(ls, min(k0 + (tid >> 5) + 8 * h, K - 1));
   };
   auto stage = [&](int buf, int k0) {
 #pragma unroll
@@ -96,8 +102,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, 
         *reinterpret_cast<f32x4*>(&As[buf][k][m4]) = zero_unless(ra_ok[p], ra[p]);
       }
     }
-    *reinterpret_cast<f32x4*>(&Bs[buf][tid >> 5][(tid & 31) * 4]) = ld.transform(ls, rb[0], min(k0 + (tid >> 5), K - 1));
-    *reinterpret_cast<f32x4*>(&Bs[buf][(tid >> 5) + 8][(tid & 31) * 4]) = ld.transform(ls, rb[1], min(k0 + (tid >> 5) + 8, K - 1));
+#pragma unroll
+    for (int h = 0; h < BP; ++h)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(tid >> 5) + 8 * h][(tid & 31) * 4]) =
+          ld.transform(ls, rb[h], min(k0 + (tid >> 5) + 8 * h, K - 1));
   };
 
   const int ktiles = (K + BK - 1) / BK;
@@ -146,6 +154,7 @@ int launch_gemm(const float* wt, int M, int K, int ldw, long ntiles, bool lds_ep
     int pad4 = (4 - m32 % 4) % 4, pad3 = (3 - m32 % 3) % 3;
     MB = pad3 < pad4 ? 3 : 4;
   }
+  if (const char* e = getenv("HILC_MB")) { int v = atoi(e); if (v >= 1 && v <= 4) MB = v; }   // tuning aid
   int mtiles = (m32 + MB - 1) / MB;
   long groups = (ntiles + 7) / 8;
   long blocks = groups * 8 * mtiles;

@@ -40,6 +40,7 @@ struct ResArgs {
   const float* dw2_b;
   float* y;
   int T, tiles;
+  long total_tiles;
   float pre_scale, out_scale;
   unsigned first_round;
   int sleeps;
@@ -99,12 +100,33 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
   stagger_first_round(a.first_round, a.sleeps);
-#define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-  STAMP(0);
-  const long b = blockIdx.x / a.tiles;
-  const int tix = (int)(blockIdx.x - b * a.tiles);
-  const int t0 = tix * TO - 8;
+#define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  long stamp_tile = blockIdx.x;
   const int T = a.T;
+  // depthwise taps / biases -> LDS once per workgroup (read back as half-wave broadcasts in P3 / P6)
+  for (int e = threadIdx.x; e < C * DWS; e += 256) {
+    const int m = e / DWS, j = e - m * DWS;
+    float v;
+    if (j < 5) v = a.dw1_w[m * 5 + j];
+    else if (j == 5) v = a.dw1_b[m];
+    else if (j < 11) v = a.dw2_w[m * 5 + (j - 6)];
+    else v = a.dw2_b[m];
+    DW[e] = v;
+  }
+  // persistent: this workgroup walks tiles blockIdx.x, +gridDim.x, ... ; while tile i is in its second
+  // GEMM the x rows of tile i+gridDim.x are touched so that its P0 finds them in this XCD's L2.
+  float touch = 0.f;
+  for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+  stamp_tile = tile;
+  STAMP(0);
+  const long b = tile / a.tiles;
+  const int tix = (int)(tile - b * a.tiles);
+  const int t0 = tix * TO - 8;
+  // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
+  // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
+  const float* w1t = a.w1t;
+  const float* w2t = a.w2t;
+  asm volatile("" : "+s"(w1t), "+s"(w2t));
   // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 8*i), lane = 4 adjacent
   // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
   // wave instruction, so the in-place update of P3 needs no barrier.
@@ -116,16 +138,6 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   const float* xb = a.x + b * (long)C * T;
   float* yb = a.y + b * (long)C * T;
 
-  // depthwise taps / biases -> LDS once (read back as half-wave broadcasts in P3 / P6)
-  for (int e = threadIdx.x; e < C * DWS; e += 256) {
-    const int m = e / DWS, j = e - m * DWS;
-    float v;
-    if (j < 5) v = a.dw1_w[m * 5 + j];
-    else if (j == 5) v = a.dw1_b[m];
-    else if (j < 11) v = a.dw2_w[m * 5 + (j - 6)];
-    else v = a.dw2_b[m];
-    DW[e] = v;
-  }
   // ---- P0: every row's 16-B load in flight at once, then the prologue
   {
     f32x4 v[RW];
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
 
   f32x16 acc[CB];
   // ---- P1, P2
-  gemm_phase<C>(a.w1t, X, acc, wave, lane);
+  gemm_phase<C>(w1t, X, acc, wave, lane);
   __syncthreads();
   STAMP(2);
   acc_to_x<C>(acc, X, wave, lane);
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   STAMP(4);
 
   // ---- P4
-  gemm_phase<C>(a.w2t, X, acc, wave, lane);
+  gemm_phase<C>(w2t, X, acc, wave, lane);
   // shortcut samples for P6, PF rows at a time: the first chunk is issued here and lands under the
   // next two barriers, chunk n+1 is issued before chunk n is consumed
   constexpr int PF = RW < 4 ? RW : 4;
@@ -187,6 +199,25 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
       xs[slot][i] = *reinterpret_cast<const f32x4*>(xb + (long)(rsub + 8 * (i0 + i)) * T + (out_ok ? t : 0));
   };
   load_xs(0, 0);
+  // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM
+  // (nothing stays live across it), consumed by a never-true test at the end of P6
+  constexpr int NTOUCH = (C * 4 + 255) / 256;
+  float tv[NTOUCH];
+  {
+    const long nt = tile + gridDim.x;
+    const bool have = nt < a.total_tiles;
+    const long nb = have ? nt / a.tiles : b;
+    const int nt0 = have ? (int)(nt - nb * a.tiles) * TO - 8 : t0;
+    const float* nx = a.x + nb * (long)C * T;
+#pragma unroll
+    for (int i = 0; i < NTOUCH; ++i) {
+      int e = tid + 256 * i;
+      e = e < C * 4 ? e : C * 4 - 1;
+      int tt = nt0 + (e & 3) * 32;
+      tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+      tv[i] = nx[(long)(e >> 2) * T + tt];
+    }
+  }
   // ---- P5
   __syncthreads();
   STAMP(5);
@@ -222,14 +253,33 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
       if (out_ok) *reinterpret_cast<f32x4*>(yb + (long)m * T + t) = o;
     }
   }
+#pragma unroll
+  for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
   STAMP(7);
+  __syncthreads();   // the next tile's P0 overwrites X
+  }
+  if (touch == 1.2345678e-30f) a.y[0] = touch;   // keeps the touch loads alive; never true in practice
 #undef STAMP
 }
 
 template <int C>
-int launch_res(const ResArgs& a, int B, hipStream_t s) {
-  long blocks = (long)B * a.tiles;
-  if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+int launch_res(ResArgs a, int B, hipStream_t s) {
+  a.total_tiles = (long)B * a.tiles;
+  // persistent grid = exactly what can be resident (a surplus workgroup would only start after a
+  // resident one has walked its whole tile list)
+  static int per_cu = 0, n_cu = 0;
+  if (per_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HILC_ERR_LAUNCH;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C>, 256, 0) != hipSuccess || occ < 1)
+      return HILC_ERR_LAUNCH;
+    n_cu = prop.multiProcessorCount;
+    per_cu = occ;
+  }
+  const long resident = (long)n_cu * per_cu;
+  long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL(resblock_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   HILC_CHECK_LAUNCH();
