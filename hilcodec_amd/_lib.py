@@ -23,6 +23,7 @@ _f, _i, _p, _d = C.c_float, C.c_int, C.c_void_p, C.c_double
 SIGNATURES = {
     "hilc_pw_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p],
     "hilc_dws_conv": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
+    "hilc_up_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_supported": [_i, _i],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],

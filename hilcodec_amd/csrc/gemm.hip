@@ -22,6 +22,7 @@ struct PwFlatLoader {
   float in_scale;
   int in_elu;
   int vec;  // T % 4 == 0 and x 16-B aligned -> a 4-column group never straddles two clips
+  typedef f32x4 Raw;
   struct State {
     long b0, b1, b2, b3;
     bool o0, o1, o2, o3;
@@ -66,6 +67,7 @@ struct PwTileLoader {
   float in_scale;
   int in_elu;
   int vec;  // T % 4 == 0, step % 4 == 0, halo % 4 == 0, x aligned
+  typedef f32x4 Raw;
   struct State {
     long base;  // (b*K)*T + t  (t may be negative; only dereferenced when valid)
     int t;
@@ -105,6 +107,7 @@ struct StftLoader {
   int hist_len;
   int T, Tf, n_fft, hop;
   long ncols;  // B*Tf
+  typedef f32x4 Raw;
   struct Col {
     long b;
     int t0;  // f*hop - (n_fft-1)
@@ -143,6 +146,74 @@ struct StftLoader {
     v.x = keep(s.c0, k) ? v.x : 0.f; v.y = keep(s.c1, k) ? v.y : 0.f;
     v.z = keep(s.c2, k) ? v.z : 0.f; v.w = keep(s.c3, k) ? v.w : 0.f;
     return v;
+  }
+};
+
+// Up-sampling front-end: the B operand is the depthwise transposed conv (kernel 2r, stride r, causal,
+// right-trimmed) of pro(x), computed on the fly — the [K x T*r] up-sampled tensor never exists in HBM.
+//   u[k][q*r+p] = w[k][p] * a[k][q] + w[k][p+r] * a[k][q-1],   a = ELU(in_scale * x),  a[-1] = 0
+// Columns = flattened (clip, output time); a 4-column group touches at most q0-1, q0, q0+1.
+struct UpLoader {
+  const float* x;      // [B][K][Tin]
+  const float* w;      // [K][2r]
+  int K, Tin, r;
+  long ncols;          // B * Tin * r   (Tin*r % 4 == 0)
+  float in_scale;
+  int in_elu;
+  struct Raw {
+    float wa[4], wb[4], xv[3];
+  };
+  struct State {
+    long xbase;        // b*K*Tin + q0
+    int q0;
+    int p[4];          // phase of column e
+    int dq[4];         // q_e - q0  (0 or 1)
+    bool ok;
+  };
+  __device__ State init(long ntile, int tid) const {
+    State s;
+    const long n = ntile * BN + (tid & 31) * 4;
+    s.ok = n < ncols;
+    const long Tout = (long)Tin * r;
+    const long b = n / Tout;
+    const int t = (int)(n - b * Tout);
+    s.q0 = t / r;
+    s.xbase = b * (long)K * Tin + s.q0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = (t + e) / r;
+      s.p[e] = (t + e) - q * r;
+      s.dq[e] = q - s.q0;
+    }
+    return s;
+  }
+  __device__ Raw fetch(const State& s, int k) const {
+    Raw v;
+    const float* wr = w + (long)k * 2 * r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v.wa[e] = wr[s.p[e]];
+      v.wb[e] = wr[s.p[e] + r];
+    }
+    const long row = s.ok ? s.xbase + (long)k * Tin : 0;
+    v.xv[0] = x[(s.ok && s.q0 >= 1) ? row - 1 : 0];
+    v.xv[1] = x[row];
+    v.xv[2] = x[(s.ok && s.q0 + 1 < Tin) ? row + 1 : 0];
+    return v;
+  }
+  __device__ f32x4 transform(const State& s, const Raw& v, int) const {
+    float a[3];
+    a[0] = (s.ok && s.q0 >= 1) ? prologue(v.xv[0], in_scale, in_elu) : 0.f;
+    a[1] = s.ok ? prologue(v.xv[1], in_scale, in_elu) : 0.f;
+    a[2] = (s.ok && s.q0 + 1 < Tin) ? prologue(v.xv[2], in_scale, in_elu) : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float cur = s.dq[e] ? a[2] : a[1];
+      const float prev = s.dq[e] ? a[1] : a[0];
+      o[e] = fmaf(v.wa[e], cur, v.wb[e] * prev);     // same expression as hilc_dw_convtr
+    }
+    return o;
   }
 };
 
@@ -370,6 +441,22 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   ld.vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   PwEpilogue ep;
   ep.y = y; ep.bias = bias; ep.res = res; ep.M = M; ep.T = T; ep.ncols = ncols; ep.out_scale = out_scale;
+  return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
+}
+
+extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
+                            int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream) {
+  if (!x || !tr_w || !wt || !y) return HILC_ERR_NULL;
+  if (B <= 0 || K <= 0 || M <= 0 || Tin <= 0 || stride <= 0) return HILC_ERR_SHAPE;
+  if (M % 4 != 0 || ((long)Tin * stride) % 4 != 0) return HILC_ERR_UNSUPPORTED;
+  const long Tout = (long)Tin * stride;
+  if (Tout > 0x7fffffffL) return HILC_ERR_SHAPE;
+  const long ncols = (long)B * Tout;
+  UpLoader ld;
+  ld.x = x; ld.w = tr_w; ld.K = K; ld.Tin = Tin; ld.r = stride; ld.ncols = ncols; ld.in_scale = in_scale;
+  ld.in_elu = in_elu;
+  PwEpilogue ep;
+  ep.y = y; ep.bias = bias; ep.res = nullptr; ep.M = M; ep.T = (int)Tout; ep.ncols = ncols; ep.out_scale = 1.0f;
   return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }
 

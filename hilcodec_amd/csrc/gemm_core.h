@@ -69,7 +69,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, 
 
   // Straight-line staging code: every guard is a select on the address / value, never a branch, so
   // the K loop body stays one basic block and the scheduler can run the LDS reads ahead of the MFMAs.
-  f32x4 ra[AP], rb[BP];
+  f32x4 ra[AP];
+  typename Loader::Raw rb[BP];
   bool a_ok[AP];
   const float* a_ptr[AP];
   int a_k[AP];

@@ -23,6 +23,7 @@ from . import ops
 # kernels remain the streaming path (per-hop tiles are a few samples wide) and a debugging aid.
 FUSE_DWS = True
 # narrow layers (C <= 192) are HBM-bound unless the whole residual block is one launch (hilc_resblock)
+FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside the pointwise GEMM's loader
 FUSE_RESBLOCK = True
 FUSE_RESBLOCK_MAX_C = 192
 
@@ -217,10 +218,15 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             u, c = ops.dw_convtr(x, st.tr_w, st.ratio, hist=caches[ci], want_hist=True,
                                  in_scale=st.in_scale, in_elu=True)
             new_caches.append(c)
+        elif FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0:
+            u = None     # the up-sampled tensor only exists inside the GEMM's loader
         else:
             u = ops.dw_convtr(x, st.tr_w, st.ratio, in_scale=st.in_scale, in_elu=True)
         ci += 1
-        x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        if u is None:
+            x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True)
+        else:
+            x = ops.pw_conv(u, st.pw_wt, st.pw_b)
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
             ci += 2

@@ -97,6 +97,19 @@ def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None,
     return y
 
 
+def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
+            in_elu: bool = True) -> Tensor:
+    """Fused [Scale, ELU, depthwise transposed conv (k=2*stride), pointwise conv + bias]:
+    x `[B,K,Tin]`, tr_w `[K,2*stride]`, wt `[K,M]` -> `[B,M,Tin*stride]`; see hilc_up_conv."""
+    B, K, Tin = x.shape
+    M = wt.shape[1]
+    y = torch.empty(B, M, Tin * stride, device=x.device, dtype=torch.float32)
+    with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride}"):
+        check(lib.hilc_up_conv(_ptr(x), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y), B, K, M, Tin, stride,
+                               in_scale, int(in_elu), _stream()), "hilc_up_conv")
+    return y
+
+
 def resblock_supported(C: int, T: int) -> bool:
     return bool(lib.hilc_resblock_supported(C, T))
 

@@ -63,6 +63,15 @@ int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const floa
                   float* y, int B, int K, int M, int T, int ksize, int stride, float in_scale, int in_elu,
                   float out_scale, int out_elu, void* stream);
 
+/* ---- fused up-sampling stage: [Scale, ELU,] depthwise transposed conv (k = 2*stride) -> pointwise conv ---
+ * u[b,k,q*stride+p] = tr_w[k][p] * pro(x[b,k,q]) + tr_w[k][p+stride] * pro(x[b,k,q-1])      (x[-1] = 0)
+ * y[b,m,t] = sum_k wt[k][m] * u[b,k,t] + bias[m],   t < Tin*stride
+ * The up-sampled tensor u only exists as the GEMM's B operand (computed in the loader).
+ * Replaces: `seanet.py:424-441` (Scale, ELU, SConvTranspose1d, SConv1d k=1 with bias). Requires
+ * (Tin*stride) % 4 == 0 and M % 4 == 0 (else HILC_ERR_UNSUPPORTED: use hilc_dw_convtr + hilc_pw_conv). */
+int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
+                 int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream);
+
 /* ---- fully fused residual block (narrow, long layers: C in {64, 96, 128, 192}, T % 4 == 0) --------
  * y = x + out_scale * (dw2(pw2(ELU(dw1(pw1(ELU(pre_scale * x))) + dw1_b))) + dw2_b)
  * One HBM read of x and one write of y per block; both pointwise outputs and the mid activation

@@ -307,3 +307,18 @@ def test_elu_fast_error(env):
     err = (y - ref).abs().max().item()
     assert err <= 1.3e-7, err
     assert torch.equal(y[x.double() > 0].float(), x[x > 0])      # identity on the positive side
+
+
+@pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 75, 8), (768, 384, 60, 5), (384, 192, 301, 4), (192, 96, 1000, 2),
+                                       (64, 32, 4, 5)])
+def test_up_conv_vs_oracle(env, K, M, Tin, r):
+    """fused [Scale, ELU, depthwise ConvTranspose k=2r, 1x1 conv + bias] against the three-step oracle"""
+    ops, fold, O, dev = env
+    x = rnd(K + Tin, 2, K, Tin)
+    tw = rnd(K + r, K, 1, 2 * r)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    b = rnd(M, M) * 0.1
+    ref = F.conv1d(O.sconvtr1d(F.elu(x * 0.7071), tw, None, stride=r, groups=K), w, b)
+    y = ops.up_conv(x.to(dev), tw[:, 0].contiguous().to(dev), fold.pointwise_layout(w).to(dev), b.to(dev), r,
+                    in_scale=0.7071, in_elu=True)
+    close(y, ref, 3e-5, "up_conv")
