@@ -38,13 +38,15 @@ __device__ __forceinline__ float dw_post(const DwArgs& a, float acc, int c, long
   return acc;
 }
 
-// generic: one thread per output sample. grid.x = rows (b*C + c), grid.y = time chunks of 256.
-__global__ __launch_bounds__(256) void dw_generic_kernel(DwArgs a) {
-  long row = blockIdx.x;
+// generic: one thread per output sample over the flattened (row = b*C + c, o) index, so that the
+// few-sample rows of a streaming hop still fill whole wavefronts.
+__global__ __launch_bounds__(256) void dw_generic_kernel(DwArgs a, long total) {
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  long row = e / a.To;
+  int o = (int)(e - row * a.To);
   int c = (int)(row % a.C);
   long b = row / a.C;
-  int o = blockIdx.y * 256 + threadIdx.x;
-  if (o >= a.To) return;
   long inrow = a.Cin == 1 ? b : row;
   const float* xrow = a.x + inrow * (long)a.T;
   const float* hrow = a.hist ? a.hist + inrow * (long)a.hist_len : nullptr;
@@ -56,13 +58,16 @@ __global__ __launch_bounds__(256) void dw_generic_kernel(DwArgs a) {
   a.y[off] = dw_post(a, acc, c, off);
 }
 
-// k == 5, stride 1, T % 4 == 0, 16-B aligned rows: 4 outputs per thread from two float4 loads.
-__global__ __launch_bounds__(256) void dw_k5_vec_kernel(DwArgs a) {
-  long row = blockIdx.x;
+// k == 5, stride 1, T % 4 == 0, 16-B aligned rows: 4 outputs per thread from two float4 loads;
+// flattened (row, t/4) index.
+__global__ __launch_bounds__(256) void dw_k5_vec_kernel(DwArgs a, long total) {
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int T4 = a.T >> 2;
+  long row = e / T4;
+  int t = (int)(e - row * T4) * 4;
   int c = (int)(row % a.C);
   long b = row / a.C;
-  int t = (blockIdx.y * 256 + threadIdx.x) * 4;
-  if (t >= a.T) return;
   long inrow = a.Cin == 1 ? b : row;
   const float* xrow = a.x + inrow * (long)a.T;
   const float* hrow = a.hist ? a.hist + inrow * (long)a.hist_len : nullptr;
@@ -116,12 +121,13 @@ struct TrArgs {
   int in_elu;
 };
 
-__global__ __launch_bounds__(256) void dw_convtr_kernel(TrArgs a) {
-  long row = blockIdx.x;
-  int c = (int)(row % a.C);
-  int n = blockIdx.y * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void dw_convtr_kernel(TrArgs a, long total) {
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
   int To = a.T * a.r;
-  if (n >= To) return;
+  long row = e / To;
+  int n = (int)(e - row * To);
+  int c = (int)(row % a.C);
   int q = n / a.r, p = n - q * a.r;
   const float* xrow = a.x + row * (long)a.T;
   float cur = prologue(xrow[q], a.in_scale, a.in_elu);
@@ -242,11 +248,13 @@ int launch_dw(DwArgs a, int B, hipStream_t s) {
   bool vec = a.stride == 1 && a.ksize == 5 && a.T % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(a.y) & 15) == 0 && (a.hist == nullptr || a.hist_len >= 4);
   if (vec) {
-    dim3 grid((unsigned)rows, (unsigned)ceil_div(a.T / 4, 256));
-    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_k5_vec_kernel, grid, dim3(256), 0, s, a);
+    long total = rows * (a.T / 4);
+    if ((total + 255) / 256 > 0x7fffffffL) return HILC_ERR_SHAPE;
+    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_k5_vec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
   } else {
-    dim3 grid((unsigned)rows, (unsigned)ceil_div(a.To, 256));
-    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_generic_kernel, grid, dim3(256), 0, s, a);
+    long total = rows * a.To;
+    if ((total + 255) / 256 > 0x7fffffffL) return HILC_ERR_SHAPE;
+    HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
   }
   HILC_CHECK_LAUNCH();
   return HILC_OK;
@@ -293,8 +301,9 @@ extern "C" int hilc_dw_convtr(const float* x, const float* hist, const float* w,
   if (rows > 0x7fffffffL) return HILC_ERR_SHAPE;
   TrArgs a;
   a.x = x; a.hist = hist; a.w = w; a.y = y; a.C = C; a.T = T; a.r = stride; a.in_scale = in_scale; a.in_elu = in_elu;
-  dim3 grid((unsigned)rows, (unsigned)ceil_div((long)T * stride, 256));
-  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_convtr_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  long total = rows * (long)T * stride;
+  if ((total + 255) / 256 > 0x7fffffffL) return HILC_ERR_SHAPE;
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(dw_convtr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, total);
   HILC_CHECK_LAUNCH();
   if (hist_out) return launch_hist_out(x, hist, hist_out, rows, T, 1, 1, in_scale, in_elu, (hipStream_t)stream);
   return HILC_OK;
