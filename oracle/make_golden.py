@@ -243,9 +243,41 @@ def main():
     model, mk, sd = offline_golden(ref, "hil_speech", n_clips=2, partial_n=4)
     streaming_golden(ref, model, mk, sd, "hil_speech")
     offline_golden(ref, "hil_music", n_clips=1, partial_n=2)
+    trained_codebook_golden(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 
 
+
+
+def trained_codebook_golden(ref):
+    """Dequantizer known-answer test on the reference's SHIPPED data: trained codebooks
+    (`onnx/hil_speech_deq{i}.onnx`) + the first frames of `onnx/hil_speech_quantized.npy`, run through the
+    reference's own `Dequantizer`.  Only the 8 x F referenced code vectors are stored, not the 4 MB tables."""
+    from hilcodec_amd import wire
+    onnx_dir = os.path.join(R.REFERENCE_ROOT, "onnx")
+    idx_all = np.load(os.path.join(onnx_dir, "hil_speech_quantized.npy"))
+    assert idx_all.dtype == np.int16 and idx_all.shape == (8, 1, 2296)
+    F = 16
+    idx = torch.from_numpy(idx_all[:, :, 100:100 + F].astype(np.int64))
+    mk = synth.model_kwargs("hil_speech")
+    deq = ref.StreamingHILCodec(24000, **{k: v for k, v in mk.items() if k not in ("spec_learnable", "causal", "pad_mode")}).dequantizer.eval()
+    rows = np.zeros((8, F, 128), dtype=np.float32)
+    for i in range(8):
+        cb = wire.read_onnx_codebook(os.path.join(onnx_dir, f"hil_speech_deq{i}.onnx"))
+        assert cb.shape == (1024, 128)
+        deq.layers[i].embed.copy_(cb)
+        rows[i] = cb[idx[i, 0]].numpy()
+    with torch.no_grad():
+        q = deq(idx, 8)
+    np.savez_compressed(os.path.join(OUT, "trained_deq.npz"), indices=idx.numpy().astype(np.int16), rows=rows, q=t2n(q),
+                        quantized_shape=np.array(idx_all.shape), quantized_sum=np.int64(idx_all.astype(np.int64).sum()))
+    print("trained dequantizer KAT:", q.shape, float(q.abs().mean()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--trained" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        trained_codebook_golden(R.load_reference())
+    else:
+        main()

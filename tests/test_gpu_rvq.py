@@ -128,3 +128,21 @@ def test_rvq_modules_reference_api():
     q2, nr2, loss2 = old(z.to(dev))
     q_o2, _, loss_o2, _ = O.rvq_forward(sd, z, None, nq, variant="legacy")
     assert torch.equal(q2.cpu(), q_o2)
+
+
+def test_trained_dequantizer_kat(golden):
+    """Dequantizer kernel on the reference's shipped trained codebooks + indices (int16 wire dtype)."""
+    from hilcodec_amd.models.hilcodec.streaming import Dequantizer
+    dev = torch.device("cuda:0")
+    g = golden("trained_deq")
+    idx = torch.from_numpy(g["indices"])                                # int16 [8,1,F]
+    deq = Dequantizer(num_quantizers=8, dim=128, codebook_size=1024).eval()
+    for i in range(8):
+        cb = torch.zeros(1024, 128)
+        cb[idx[i, 0].long()] = torch.from_numpy(g["rows"][i])
+        deq.layers[i].embed.copy_(cb)
+    q = deq(idx.to(dev), 8)
+    assert torch.equal(q.cpu(), torch.from_numpy(g["q"]))
+    q4 = deq(idx.to(dev), 4)
+    ref4 = sum(torch.from_numpy(g["rows"][i]) for i in range(4)).unsqueeze(0)
+    assert torch.allclose(q4.cpu(), ref4, atol=1e-6)
