@@ -143,7 +143,9 @@ def read_onnx_initializers(path: str) -> Dict[str, np.ndarray]:
 def read_onnx_codebook(path: str) -> Tensor:
     """The `[K, C]` embed table of one `*_deq{i}.onnx` / `*_vq{i}.onnx` file."""
     inits = read_onnx_initializers(path)
+    if "embed" in inits and inits["embed"].ndim == 2:        # the buffer's name in both exported graphs
+        return torch.from_numpy(inits["embed"])
     cands = [v for v in inits.values() if v.ndim == 2]
     if len(cands) != 1:
-        raise ValueError(f"{path}: expected exactly one 2-D fp32 initializer, found {[v.shape for v in inits.values()]}")
+        raise ValueError(f"{path}: no 'embed' initializer and {len(cands)} 2-D fp32 candidates")
     return torch.from_numpy(cands[0])
