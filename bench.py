@@ -197,6 +197,18 @@ def main():
             out["kernel_time_breakdown_ms_per_step"] = {k: v[2] / args.steps * 1e3 for k, v in sorted(tot.items())}
             out["hbm_bound_ops_GBps"] = {k: v[1] / v[2] / 1e9 for k, v in tot.items()
                                          if k in ("dw_conv", "dw_convtr", "conv_pre", "conv_post")}
+        # HBM traffic of the dominant kernel family comes from rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate passes; tools/summarize_profile.py) — it cannot be
+        # sampled from inside the process, so the committed summary of the latest profiled build is quoted.
+        try:
+            with open(os.path.join(ROOT, "profiles", "latest_mfma_family.json")) as f:
+                prof = json.load(f)
+            if args.mode == "offline" and name == "hil_speech" and B == 256 and T == 24000:
+                roof["traffic"] = prof["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes per launch (avg over the family), rocprofv3 PMC, profiles/latest_mfma_family.json"
+                roof["algorithmic_bytes_per_step"] = 196800 * B + 38150404 + nq * 524288 + 5602816
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, mk, sd, args.cpu_clips, T)

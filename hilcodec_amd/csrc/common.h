@@ -64,16 +64,4 @@ __device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
   return ok ? v : z;
 }
 
-// Co-resident workgroups that run the same phase program start together and stay in lock-step:
-// their MFMA phases contend for the one matrix pipe per SIMD, then their VALU phases leave it idle
-// together.  Skewing the FIRST round of workgroups by their hardware wave slot (HW_ID.wave_id,
-// bits [3:0]) de-phases the slots; every later workgroup inherits the skew of the one it replaces.
-// Purely a scheduling aid: results do not depend on it.
-__device__ __forceinline__ void stagger_first_round(unsigned first_round_blocks, int sleeps_per_slot) {
-  if (blockIdx.x < first_round_blocks) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 7u;   // HW_REG_HW_ID[3:0]
-    for (int i = 0; i < (int)slot * sleeps_per_slot; ++i) __builtin_amdgcn_s_sleep(127);   // ~8k cycles each
-  }
-}
-
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

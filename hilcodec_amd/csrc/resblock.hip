@@ -42,8 +42,6 @@ struct ResArgs {
   int T, tiles;
   long total_tiles;
   float pre_scale, out_scale;
-  unsigned first_round;
-  int sleeps;
   unsigned long long* dbg;   // optional [blocks][8] s_memtime stamps (tools/res_phase_times.py)
 };
 
@@ -99,7 +97,6 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   __shared__ float DW[C * DWS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
-  stagger_first_round(a.first_round, a.sleeps);
 #define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   long stamp_tile = blockIdx.x;
   const int T = a.T;
@@ -299,11 +296,6 @@ extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_
   ResArgs a;
   a.x = x; a.w1t = w1t; a.dw1_w = dw1_w; a.dw1_b = dw1_b; a.w2t = w2t; a.dw2_w = dw2_w; a.dw2_b = dw2_b;
   a.y = y; a.T = T; a.tiles = (T + TO - 1) / TO; a.pre_scale = pre_scale; a.out_scale = out_scale;
-  {
-    const char* e = getenv("HILC_STAGGER");
-    a.sleeps = e ? atoi(e) : 0;
-    a.first_round = a.sleeps > 0 ? 256u * 4u : 0u;
-  }
   a.dbg = g_dbg;
   switch (C) {
     case 64: return launch_res<64>(a, B, (hipStream_t)stream);
