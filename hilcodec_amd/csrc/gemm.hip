@@ -153,6 +153,10 @@ struct StftLoader {
 // right-trimmed) of pro(x), computed on the fly — the [K x T*r] up-sampled tensor never exists in HBM.
 //   u[k][q*r+p] = w[k][p] * a[k][q] + w[k][p+r] * a[k][q-1],   a = ELU(in_scale * x),  a[-1] = 0
 // Columns = flattened (clip, output time); a 4-column group touches at most q0-1, q0, q0+1.
+// R = 2 / 4 / 8: the 2R taps of a channel sit in one or two aligned 16-B rows and a 4-column group
+// (t % 4 == 0) uses taps p0..p0+3 (+R) with p0 a multiple of 4 — two float4 loads instead of eight
+// scalar gathers; R = 0: generic stride (e.g. 5).
+template <int R>
 struct UpLoader {
   const float* x;      // [B][K][Tin]
   const float* w;      // [K][2r]
@@ -161,7 +165,8 @@ struct UpLoader {
   float in_scale;
   int in_elu;
   struct Raw {
-    float wa[4], wb[4], xv[3];
+    f32x4 wa, wb;
+    float xv[3];
   };
   struct State {
     long xbase;        // b*K*Tin + q0
@@ -190,10 +195,19 @@ struct UpLoader {
   __device__ Raw fetch(const State& s, int k) const {
     Raw v;
     const float* wr = w + (long)k * 2 * r;
+    if (R == 8 || R == 4) {            // p = p0..p0+3, p0 in {0, 4}
+      v.wa = *reinterpret_cast<const f32x4*>(wr + s.p[0]);
+      v.wb = *reinterpret_cast<const f32x4*>(wr + s.p[0] + R);
+    } else if (R == 2) {               // p = 0,1,0,1: taps (w0,w1 | w2,w3) of one 16-B row
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(wr);
+      v.wa = f32x4{t4.x, t4.y, t4.x, t4.y};
+      v.wb = f32x4{t4.z, t4.w, t4.z, t4.w};
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v.wa[e] = wr[s.p[e]];
-      v.wb[e] = wr[s.p[e] + r];
+      for (int e = 0; e < 4; ++e) {
+        v.wa[e] = wr[s.p[e]];
+        v.wb[e] = wr[s.p[e] + r];
+      }
     }
     const long row = s.ok ? s.xbase + (long)k * Tin : 0;
     v.xv[0] = x[(s.ok && s.q0 >= 1) ? row - 1 : 0];
@@ -452,12 +466,18 @@ extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, 
   const long Tout = (long)Tin * stride;
   if (Tout > 0x7fffffffL) return HILC_ERR_SHAPE;
   const long ncols = (long)B * Tout;
-  UpLoader ld;
-  ld.x = x; ld.w = tr_w; ld.K = K; ld.Tin = Tin; ld.r = stride; ld.ncols = ncols; ld.in_scale = in_scale;
-  ld.in_elu = in_elu;
   PwEpilogue ep;
   ep.y = y; ep.bias = bias; ep.res = nullptr; ep.M = M; ep.T = (int)Tout; ep.ncols = ncols; ep.out_scale = 1.0f;
-  return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
+  const bool w_aligned = (reinterpret_cast<uintptr_t>(tr_w) & 15) == 0;
+  auto go = [&](auto ld) {
+    ld.x = x; ld.w = tr_w; ld.K = K; ld.Tin = Tin; ld.r = stride; ld.ncols = ncols; ld.in_scale = in_scale;
+    ld.in_elu = in_elu;
+    return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
+  };
+  if (w_aligned && stride == 8) return go(UpLoader<8>{});
+  if (w_aligned && stride == 4) return go(UpLoader<4>{});
+  if (w_aligned && stride == 2) return go(UpLoader<2>{});
+  return go(UpLoader<0>{});
 }
 
 extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b,
