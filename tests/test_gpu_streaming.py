@@ -138,3 +138,43 @@ def test_streaming_layer_classes(golden):
     assert (st(wav.to(dev)).cpu() - ref).abs().max() < 2e-5
     with pytest.raises(ValueError):
         CL.SConv1d(4, 4, 3, norm="spectral_norm")
+
+
+def test_stream_driver_protocol(tmp_path):
+    """test_onnx.py's protocol end to end: chunked encode -> int16 [n,B,T] .npy -> chunked decode -> wav;
+    frame-by-frame and 5-frames-at-a-time give the same codes; the codes equal the oracle's."""
+    import numpy as np
+    from hilcodec_amd import stream_driver as SD, wire
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming()
+    model = model.to(dev)
+    x = torch.cat([synth.sweep_clip(4800), synth.synth_clips(1, 4800, seed=9)], dim=0)[:, :, :4800 + 0]
+    x = torch.nn.functional.pad(x, (0, 100))                         # 4900 samples: the 100-sample tail is dropped
+    idx1, ce1 = SD.encode_stream(model, x.to(dev), 8, num_frames=1)
+    idx5, ce5 = SD.encode_stream(model, x.to(dev), 8, num_frames=5)
+    assert idx1.dtype == torch.int16 and idx1.shape == (8, 2, 15) and torch.equal(idx1, idx5)
+    p = O.stream_prepare(sd, mk)
+    oe, od = O.stream_init_cache(mk, 2)
+    zo, oe = O.stream_encoder(p, mk, x[:, :, :4800], oe)
+    assert torch.equal(idx1.long().cpu(), O.stream_quantize(p, zo, 8))
+    path = str(tmp_path / "hil_speech_quantized.npy")
+    wire.save_indices_npy(path, idx1)
+    assert np.load(path).dtype == np.int16
+    timer = SD.Timer(24000)
+    w1, _ = SD.decode_stream(model, wire.load_indices_npy(path), 8, num_frames=1, timer=timer)
+    w3, _ = SD.decode_stream(model, idx1, 8, num_frames=3)
+    assert w1.shape == (2, 1, 4800) and (w1 - w3).abs().max() < 2e-6
+    wo, _ = O.stream_decoder(p, mk, O.stream_dequantize(p, idx1.long().cpu(), 8), od)
+    assert (w1.cpu() - wo).abs().max() < 1e-4
+    rep = timer.report()
+    assert rep["wav_seconds"] == 0.2 and rep["decoder_rtf"] > 0
+    # fewer codebooks than trained (bitrate scalability): n = 2 uses the first two index planes
+    w_n2, _ = SD.decode_stream(model, idx1, 2, num_frames=15)
+    wo2, _ = O.stream_decoder(p, mk, O.stream_dequantize(p, idx1.long().cpu(), 2), O.stream_init_cache(mk, 2)[1])
+    assert (w_n2.cpu() - wo2).abs().max() < 1e-4
+    # WAV I/O of the driver
+    wav_path = str(tmp_path / "o.wav")
+    SD.write_wav(wav_path, w1[0, 0].cpu().numpy(), 24000)
+    back = SD.read_wav(wav_path, 24000)
+    assert back.shape == (4800,) and np.abs(back - w1[0, 0].cpu().numpy()).max() < 1.0 / 32767 + 1e-6
