@@ -36,6 +36,8 @@ SIGNATURES = {
     "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_mse_finalize": [_p, _p, _i, _d, _p],
     "hilc_rvq_decode": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_encode_mixed": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
 ABI_VERSION = 1

@@ -22,6 +22,7 @@ struct RvqArgs {
   const float* cb;    // [Nq][K][C]
   const float* cbt;   // [Nq][C][K]
   const float* norms; // [Nq][K]
+  const int* n_clip;  // optional [B]: stages used by clip b (mixed-bitrate batches); NULL = n for every clip
   int64_t* indices;
   float* q;
   float* frame_err;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
   __shared__ float wbest[4][FR];
   __shared__ int widx[4][FR];
   __shared__ int sel[FR];
+  __shared__ int nfr[FR];   // stages of each frame's clip
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -54,6 +56,15 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     long g = g0 + f;
     res[c][f] = g < nframes ? a.z[zoff(a, g, c)] : 0.f;
     qsum[c][f] = 0.f;
+  }
+  if (tid < FR) {
+    long g = g0 + tid;
+    int nf = a.n;
+    if (a.n_clip != nullptr && g < nframes) {
+      nf = a.n_clip[g / a.T];
+      nf = nf < 1 ? 1 : (nf > a.n ? a.n : nf);
+    }
+    nfr[tid] = nf;
   }
   __syncthreads();
 
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
         int oi = widx[w][tid];
         if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
       }
+      if (s >= nfr[tid]) bi = -1;   // this clip stops before stage s: no code, residual and sum untouched
       sel[tid] = bi;
       long g = g0 + tid;
       if (g < nframes) {
@@ -128,9 +140,12 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     // residual -= E[idx]; quantized_out += E[idx]   (vector_quantize.py:225-229)
     for (int e = tid; e < FR * C; e += 256) {
       int c = e % C, f = e / C;
-      float qv = cb[(long)sel[f] * C + c];
-      res[c][f] = res[c][f] - qv;
-      qsum[c][f] = qsum[c][f] + qv;
+      const int k = sel[f];
+      if (k >= 0) {
+        float qv = cb[(long)k * C + c];
+        res[c][f] = res[c][f] - qv;
+        qsum[c][f] = qsum[c][f] + qv;
+      }
     }
     __syncthreads();
   }
@@ -170,6 +185,7 @@ __global__ __launch_bounds__(256) void mse_finalize_kernel(const float* frame_er
 struct DeqArgs {
   const int64_t* indices;
   const float* cb;
+  const int* n_clip;   // optional [B]
   float* q;
   int B, C, T, K, n;
   int channel_last, stage_major;
@@ -192,7 +208,9 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(DeqArgs a) {
     b = bc / a.C;
   }
   float acc = 0.f;
-  for (int s = 0; s < a.n; ++s) {
+  int nb = a.n;
+  if (a.n_clip != nullptr) { nb = a.n_clip[b]; nb = nb < 1 ? 1 : (nb > a.n ? a.n : nb); }
+  for (int s = 0; s < nb; ++s) {
     long ioff = a.stage_major ? ((long)s * a.B + b) * a.T + t : (b * a.n + s) * (long)a.T + t;
     long k = a.indices[ioff];
     k = k < 0 ? 0 : (k >= a.K ? a.K - 1 : k);
@@ -203,15 +221,16 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(DeqArgs a) {
 
 }  // namespace
 
-extern "C" int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t,
-                               const float* norms, int64_t* indices, float* q, float* frame_err, int B, int C,
-                               int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream) {
+extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, const float* codebooks_t,
+                                     const float* norms, const int* n_per_clip, int64_t* indices, float* q,
+                                     float* frame_err, int B, int C, int T, int K, int Nq, int n, int channel_last,
+                                     int stage_major, void* stream) {
   if (!z || !codebooks || !codebooks_t || !norms || !indices) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || Nq <= 0) return HILC_ERR_SHAPE;
   if (n < 1 || n > Nq) return HILC_ERR_RANGE;
   if (C != 128 || K != 256 * CPT) return HILC_ERR_UNSUPPORTED;
   RvqArgs a;
-  a.z = z; a.cb = codebooks; a.cbt = codebooks_t; a.norms = norms; a.indices = indices; a.q = q;
+  a.z = z; a.cb = codebooks; a.cbt = codebooks_t; a.norms = norms; a.n_clip = n_per_clip; a.indices = indices; a.q = q;
   a.frame_err = frame_err; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
   a.channel_last = channel_last; a.stage_major = stage_major;
   long nframes = (long)B * T;
@@ -219,6 +238,13 @@ extern "C" int hilc_rvq_encode(const float* z, const float* codebooks, const flo
                      (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
+}
+
+extern "C" int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t,
+                               const float* norms, int64_t* indices, float* q, float* frame_err, int B, int C,
+                               int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream) {
+  return hilc_rvq_encode_mixed(z, codebooks, codebooks_t, norms, nullptr, indices, q, frame_err, B, C, T, K, Nq, n,
+                               channel_last, stage_major, stream);
 }
 
 extern "C" int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream) {
@@ -229,18 +255,24 @@ extern "C" int hilc_mse_finalize(const float* frame_err, float* loss, int frames
   return HILC_OK;
 }
 
-extern "C" int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T, int K,
-                               int Nq, int n, int channel_last, int stage_major, void* stream) {
+extern "C" int hilc_rvq_decode_mixed(const int64_t* indices, const float* codebooks, const int* n_per_clip, float* q,
+                                     int B, int C, int T, int K, int Nq, int n, int channel_last, int stage_major,
+                                     void* stream) {
   if (!indices || !codebooks || !q) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || Nq <= 0) return HILC_ERR_SHAPE;
   if (n < 1 || n > Nq) return HILC_ERR_RANGE;
   DeqArgs a;
-  a.indices = indices; a.cb = codebooks; a.q = q; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
+  a.indices = indices; a.cb = codebooks; a.n_clip = n_per_clip; a.q = q; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
   a.channel_last = channel_last; a.stage_major = stage_major;
   long total = (long)B * T * C;
   HILC_CLEAR_ERROR(); hipLaunchKernelGGL(rvq_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
+}
+
+extern "C" int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T, int K,
+                               int Nq, int n, int channel_last, int stage_major, void* stream) {
+  return hilc_rvq_decode_mixed(indices, codebooks, nullptr, q, B, C, T, K, Nq, n, channel_last, stage_major, stream);
 }
 
 thread_local int hilc_last_hip_error_code = 0;

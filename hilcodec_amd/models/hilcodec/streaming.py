@@ -70,9 +70,11 @@ class ResidualVQ(_CodebookStack):
 
     def forward(self, x: Tensor, n: int) -> Tensor:
         sp = self._tables(x.device)
-        n = min(int(n), len(self.layers))               # reference: `self.layers[:n]`
-        if n < 1:
-            raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
+        if isinstance(n, int) or (isinstance(n, Tensor) and n.dim() == 0):
+            n = min(int(n), len(self.layers))           # reference: `self.layers[:n]`
+            if n < 1:
+                raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
+        # else: one n per stream (mixed-bitrate batch); rows >= n_b of the result hold -1
         idx, _, _ = ops.rvq_encode(x.contiguous().float(), sp.codebooks, sp.codebooks_t, sp.norms, n,
                                    channel_last=True, stage_major=True, want_q=False)
         return idx
@@ -105,7 +107,9 @@ class Dequantizer(_CodebookStack):
         sp = self._tables(indices.device)
         if indices.dtype != torch.int64:
             indices = indices.long()                   # test_onnx.py stores int16 (:96-100)
-        return ops.rvq_decode(indices.contiguous(), sp.codebooks, int(n), channel_last=True, stage_major=True)
+        if isinstance(n, int) or (isinstance(n, Tensor) and n.dim() == 0):
+            n = int(n)
+        return ops.rvq_decode(indices.contiguous(), sp.codebooks, n, channel_last=True, stage_major=True)
 
 
 class DWSBlock(nn.Module):

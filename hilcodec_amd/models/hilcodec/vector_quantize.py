@@ -61,7 +61,9 @@ class EuclideanCodebook(nn.Module):
 class ResidualVQ(nn.Module):
     """`ResidualVQ` (`vector_quantize.py:179-243`).
     forward(x `[B,C,T]`, n=None, return_indices=False) ->
-        (quantized `[B,C,T]`, num_replaces np.int64[Nq], mse loss 0-d[, indices `[B,n,T]` int64])."""
+        (quantized `[B,C,T]`, num_replaces np.int64[Nq], mse loss 0-d[, indices `[B,n,T]` int64]).
+    Extension: `n` may be a sequence / tensor of B ints (clip b is quantised with its own n_b stages; rows
+    >= n_b of `indices` hold -1); each clip's result equals a uniform call with n = n_b."""
 
     def __init__(self, num_quantizers: int, dropout: bool = False,
                  dropout_index: tp.Optional[tp.List[int]] = None, channel_last: bool = False, **kwargs):
@@ -91,7 +93,9 @@ class ResidualVQ(nn.Module):
                 raise RuntimeError("codebook not initialised (kmeans_init=True and no checkpoint loaded); the "
                                    "reference would silently run k-means on this input (vector_quantize.py:139-140)")
         num_replaces = np.zeros(len(self.layers), dtype=np.int64)
-        if n is not None:
+        if n is not None and not isinstance(n, int):
+            high = n       # one n per clip (mixed-bitrate batch); ops.per_clip_n applies the assert per entry
+        elif n is not None:
             assert 1 <= n <= len(self.layers), f"'n' must be in range of 1 <= n <= {len(self.layers)}"
             high = n
         else:

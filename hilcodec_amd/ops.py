@@ -213,23 +213,40 @@ def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: 
     return y
 
 
-def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor, n: int,
+def per_clip_n(n, B: int, Nq: int, device):
+    """`n` as the reference takes it (one int for the whole batch) or one int per clip (mixed-bitrate batch).
+    Returns (rows, int32 [B] device tensor or None).  Every entry obeys the reference's assert
+    (`models/hilcodec/vector_quantize.py:213-214`)."""
+    if isinstance(n, (int,)) or (isinstance(n, Tensor) and n.dim() == 0):
+        return int(n), None
+    host = torch.as_tensor(n).detach().to("cpu", torch.int64).reshape(-1)
+    if host.numel() != B:
+        raise RuntimeError(f"per-clip n needs {B} entries, got {host.numel()}")
+    lo, hi = int(host.min()), int(host.max())
+    assert 1 <= lo and hi <= Nq, f"'n' must be in range of 1 <= n <= {Nq}"
+    return hi, host.to(torch.int32).to(device)
+
+
+def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor, n,
                channel_last: bool = False, stage_major: bool = False, want_q: bool = True,
                want_loss: bool = False):
-    """Returns (indices int64, q or None, loss 0-d or None)."""
+    """Returns (indices int64, q or None, loss 0-d or None).  `n`: int, or one int per clip (rows of `indices`
+    beyond a clip's own n hold -1)."""
     if channel_last:
         B, T, Cc = z.shape
     else:
         B, Cc, T = z.shape
     Nq, K, _ = codebooks.shape
+    n, n_clip = per_clip_n(n, B, Nq, z.device)
     nn = max(1, min(n, Nq))
     idx = torch.empty((nn, B, T) if stage_major else (B, nn, T), device=z.device, dtype=torch.int64)
     q = torch.empty_like(z) if want_q else None
     ferr = torch.empty(B * T, device=z.device, dtype=torch.float32) if want_loss else None
     with _timed("rvq_encode", 2.0 * B * T * K * Cc * nn):
-        check(lib.hilc_rvq_encode(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
-                                  _ptr(idx, torch.int64), _ptr(q), _ptr(ferr), B, Cc, T, K, Nq, n,
-                                  int(channel_last), int(stage_major), _stream()), "hilc_rvq_encode")
+        check(lib.hilc_rvq_encode_mixed(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
+                                        _ptr(n_clip, torch.int32), _ptr(idx, torch.int64), _ptr(q), _ptr(ferr),
+                                        B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
+              "hilc_rvq_encode")
     loss = None
     if want_loss:
         loss = torch.empty((), device=z.device, dtype=torch.float32)
@@ -237,14 +254,16 @@ def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor,
     return idx, q, loss
 
 
-def rvq_decode(indices: Tensor, codebooks: Tensor, n: int, channel_last: bool = True,
+def rvq_decode(indices: Tensor, codebooks: Tensor, n, channel_last: bool = True,
                stage_major: bool = True) -> Tensor:
     if stage_major:
         _, B, T = indices.shape
     else:
         B, _, T = indices.shape
     Nq, K, Cc = codebooks.shape
+    n, n_clip = per_clip_n(n, B, Nq, indices.device)
     q = torch.empty((B, T, Cc) if channel_last else (B, Cc, T), device=indices.device, dtype=torch.float32)
-    check(lib.hilc_rvq_decode(_ptr(indices, torch.int64), _ptr(codebooks), _ptr(q), B, Cc, T, K, Nq, n,
-                              int(channel_last), int(stage_major), _stream()), "hilc_rvq_decode")
+    check(lib.hilc_rvq_decode_mixed(_ptr(indices, torch.int64), _ptr(codebooks), _ptr(n_clip, torch.int32), _ptr(q),
+                                    B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
+          "hilc_rvq_decode")
     return q

@@ -151,6 +151,15 @@ int hilc_rvq_encode(const float* z, const float* codebooks, const float* codeboo
                     int64_t* indices, float* q, float* frame_err, int B, int C, int T, int K, int Nq, int n,
                     int channel_last, int stage_major, void* stream);
 
+/* Mixed-bitrate batch (`n` drawn per request from `dropout_index`, configs/hilcodec_*.yaml:38,
+ * `infer_n` :117,130): clip b uses stages [0, n_per_clip[b]) (int32 `[B]`, device; values clamped to [1, n]);
+ * rows >= n_per_clip[b] of `indices` are written as -1 and leave q / the residual untouched, so clip b's
+ * results equal a uniform call with n = n_per_clip[b].  `n` = rows of `indices` (>= every entry).
+ * n_per_clip == NULL is hilc_rvq_encode. */
+int hilc_rvq_encode_mixed(const float* z, const float* codebooks, const float* codebooks_t, const float* norms,
+                          const int* n_per_clip, int64_t* indices, float* q, float* frame_err, int B, int C,
+                          int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream);
+
 /* mean over `count` of frame_err[0..frames) in a fixed order -> loss[0]  (F.mse_loss, `vector_quantize.py:233`) */
 int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream);
 
@@ -158,6 +167,11 @@ int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double co
  * Replaces: Dequantizer.forward (`streaming.py:148-157`) / F.embedding sums in ResidualVQ. */
 int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T,
                     int K, int Nq, int n, int channel_last, int stage_major, void* stream);
+
+/* mixed-bitrate decode: clip b sums stages [0, n_per_clip[b]) only (rows beyond are ignored, e.g. the -1 rows
+ * hilc_rvq_encode_mixed writes); n_per_clip == NULL is hilc_rvq_decode. */
+int hilc_rvq_decode_mixed(const int64_t* indices, const float* codebooks, const int* n_per_clip, float* q, int B,
+                          int C, int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream);
 
 #ifdef __cplusplus
 }

@@ -146,3 +146,42 @@ def test_trained_dequantizer_kat(golden):
     q4 = deq(idx.to(dev), 4)
     ref4 = sum(torch.from_numpy(g["rows"][i]) for i in range(4)).unsqueeze(0)
     assert torch.allclose(q4.cpu(), ref4, atol=1e-6)
+
+
+def test_rvq_mixed_n_per_clip():
+    """one batch, a different bitrate per clip.  Each clip must equal the reference's (oracle's)
+    result for a uniform call with that clip's n; unused index rows hold -1; the dequantiser honours the same n."""
+    from hilcodec_amd.models.hilcodec.vector_quantize import ResidualVQ
+    from hilcodec_amd.models.hilcodec.streaming import ResidualVQ as SRVQ, Dequantizer
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    nq, D, B, Tn = 8, 128, 7, 75           # 75 frames per clip: 16-frame workgroups straddle clips
+    ns = [2, 8, 4, 1, 8, 2, 5]
+    sd = make_codebooks(17, nq)
+    z = torch.from_numpy(synth.normalish(99, B * D * Tn)).view(B, D, Tn)
+    z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+    rvq = ResidualVQ(num_quantizers=nq, dim=D, codebook_size=1024).eval()
+    rvq.load_state_dict({f"layers.{i}.embed": sd[f"quantizer.layers.{i}.embed"] for i in range(nq)}, strict=False)
+    q, _, loss, idx = rvq(z.to(dev), ns, return_indices=True)
+    assert idx.shape == (B, 8, Tn)
+    err = 0.0
+    for b, n in enumerate(ns):
+        q_o, _, loss_o, idx_o = O.rvq_forward(sd, z[b:b + 1], n, nq)
+        assert torch.equal(idx[b:b + 1, :n].cpu(), idx_o), f"clip {b} n={n}"
+        assert (idx[b, n:] == -1).all()
+        assert torch.equal(q[b:b + 1].cpu(), q_o)
+        err += float(loss_o) * D * Tn
+    assert abs(float(loss) - err / (B * D * Tn)) <= 2e-6 * float(loss)
+    # streaming layout [n,B,T] + dequantiser
+    zs = z.transpose(1, 2).contiguous().to(dev)
+    srvq, deq = SRVQ(num_quantizers=nq, dim=D, codebook_size=1024).eval(), Dequantizer(num_quantizers=nq, dim=D, codebook_size=1024).eval()
+    for m in (srvq, deq):
+        m.load_state_dict({f"layers.{i}.embed": sd[f"quantizer.layers.{i}.embed"] for i in range(nq)}, strict=False)
+    sidx = srvq(zs, torch.tensor(ns))
+    assert torch.equal(sidx.permute(1, 0, 2), idx)
+    qd = deq(sidx, ns)
+    assert torch.equal(qd.transpose(1, 2), q)
+    with pytest.raises(AssertionError):
+        rvq(z.to(dev), [2, 9, 4, 1, 8, 2, 5])
+    with pytest.raises(RuntimeError):
+        rvq(z.to(dev), [2, 4])
