@@ -18,6 +18,12 @@
 // A operands (weights, k-major [K][C]) are read straight from global memory (L1/L2 resident, a few
 // tens of KB) into VGPRs one 16-deep K slice ahead — no LDS staging, no barrier in the K loop.
 // Summation order: k ascending (an fmaf chain), taps j = 0..4 — the same as the un-fused kernels.
+//
+// STREAM instantiation (hilc_resblock_stream; streaming.py:195-276 with causal_layers.py:147-167 caches): the
+// tile walks the FLAT column space (clip-major, b*T + t) so short hops (T = 160 / 320 per stream) still fill
+// 120 of 128 columns; the 4 samples before a clip's t = 0 come from the caches hist1 / hist2 (= last 4
+// pointwise outputs of the previous hop) instead of the LDS neighbours, and the lanes holding t = T-4..T-1
+// store the new caches.  Per-column arithmetic is identical, so hop-by-hop output == offline output bit for bit.
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -42,6 +48,12 @@ struct ResArgs {
   int T, tiles;
   long total_tiles;
   float pre_scale, out_scale;
+  int B;
+  unsigned div_magic, div_shift;   // STREAM: n / T == __umulhi(n, div_magic) >> div_shift for n < 2^31
+  const float* hist1;   // STREAM: [B][C][4] caches of the two depthwise convs (NULL = zeros), and their successors
+  const float* hist2;
+  float* hist1_out;
+  float* hist2_out;
   unsigned long long* dbg;   // optional [blocks][8] s_memtime stamps (tools/res_phase_times.py)
 };
 
@@ -90,11 +102,14 @@ __device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[C / 32], float* X, 
     for (int r = 0; r < 16; ++r) X[(i * 32 + acc_row(r, lane)) * XS + wave * 32 + (lane & 31)] = acc[i][r];
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
+template <int C, bool STREAM>
+__global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_kernel(ResArgs a) {
   constexpr int CB = C / 32;
   __shared__ __attribute__((aligned(16))) float X[C * XS];
   __shared__ float DW[C * DWS];
+  // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
+  // do not pay one exposed global-load latency per row for the single lane that needs them
+  __shared__ __attribute__((aligned(16))) float HS[STREAM ? 2 * C * 4 : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
 #define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -116,31 +131,95 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
   stamp_tile = tile;
   STAMP(0);
-  const long b = tile / a.tiles;
-  const int tix = (int)(tile - b * a.tiles);
-  const int t0 = tix * TO - 8;
-  // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
-  // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
-  const float* w1t = a.w1t;
-  const float* w2t = a.w2t;
-  asm volatile("" : "+s"(w1t), "+s"(w2t));
   // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 8*i), lane = 4 adjacent
   // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
   // wave instruction, so the in-place update of P3 needs no barrier.
   constexpr int RW = C / 8;
   const int rsub = wave * 2 + (lane >> 5);
   const int c4 = (lane & 31) * 4;
-  const int t = t0 + c4;                   // multiple of 4; T % 4 == 0: the group is entirely inside or outside
-  const bool t_in = t >= 0 && t < T;
-  const float* xb = a.x + b * (long)C * T;
-  float* yb = a.y + b * (long)C * T;
+  // this lane's 4 columns: clip b, time t (a multiple of 4; T % 4 == 0: the group is entirely inside or outside)
+  long b;
+  int t;
+  bool t_in;
+  // STREAM: clips differ between lanes, so the lane carries one 32-bit BYTE offset against the scalar tensor
+  // base (saddr + voffset form) — B*C*T*4 < 2^32, launcher-checked — plus the cache offset and two flags.
+  // They are RE-DERIVED from a laundered copy of c4 at the start of P3 and P6 instead of staying live across
+  // the GEMMs: the C = 128 kernel sits 12 VGPRs under the 2-waves/SIMD budget and hipcc gives up on that
+  // occupancy for the whole kernel (+150 VGPRs) as soon as one region exceeds it.
+  [[maybe_unused]] unsigned boff = 0;
+  [[maybe_unused]] unsigned hoff = 0;          // element offset of this clip's [C][4] cache block
+  [[maybe_unused]] bool clip_head = false;     // t == 0: the previous 4 samples live in the cache
+  [[maybe_unused]] bool clip_tail = false;     // t == T-4 (an output column): these 4 samples are the new cache
+  [[maybe_unused]] const unsigned row_b = (unsigned)T * 4u;
+  auto lane_columns = [&]() {
+    if constexpr (STREAM) {
+      int c = c4;
+      asm volatile("" : "+v"(c));
+      const int flat = (int)tile * TO - 8 + c;
+      t_in = flat >= 0 && flat < a.B * T;
+      const unsigned ub = t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
+      b = ub;
+      t = t_in ? flat - (int)ub * T : 0;
+      boff = (ub * (unsigned)(C * T) + (unsigned)t) * 4u;
+      hoff = ub * (unsigned)(C * 4);
+      clip_head = t_in && t == 0;
+      clip_tail = t_in && c >= 8 && t == T - 4;
+    }
+  };
+  if constexpr (STREAM) {
+    lane_columns();
+  } else {
+    b = tile / a.tiles;
+    const int t0 = (int)(tile - b * a.tiles) * TO - 8;
+    t = t0 + c4;
+    t_in = t >= 0 && t < T;
+  }
+  const float* xb = a.x + (STREAM ? 0 : b) * (long)C * T;
+  float* yb = a.y + (STREAM ? 0 : b) * (long)C * T;
+  auto xrow = [&](int m, bool ok) -> const f32x4* {
+    if constexpr (STREAM)
+      return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (boff + (unsigned)m * row_b));
+    else
+      return reinterpret_cast<const f32x4*>(xb + (long)m * T + (ok ? t : 0));
+  };
+  auto yrow = [&](int m) -> f32x4* {
+    if constexpr (STREAM)
+      return reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (boff + (unsigned)m * row_b));
+    else
+      return reinterpret_cast<f32x4*>(yb + (long)m * T + t);
+  };
 
+  // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
+  // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
+  const float* w1t = a.w1t;
+  const float* w2t = a.w2t;
+  asm volatile("" : "+s"(w1t), "+s"(w2t));
+  [[maybe_unused]] const bool one_head = STREAM && T >= XS;
+  if constexpr (STREAM) {
+    if (one_head && __builtin_amdgcn_ballot_w64(clip_head) != 0) {   // wave-uniform
+      if (clip_head) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const float* hp = which == 0 ? a.hist1 : a.hist2;
+          f32x4 h[RW];
+#pragma unroll
+          for (int i = 0; i < RW; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (hp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < RW; ++i) h[i] = *reinterpret_cast<const f32x4*>(hp + hoff + (rsub + 8 * i) * 4);
+          }
+#pragma unroll
+          for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(&HS[(which * C + rsub + 8 * i) * 4]) = h[i];
+        }
+      }
+    }
+  }
   // ---- P0: every row's 16-B load in flight at once, then the prologue
   {
     f32x4 v[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i)
-      v[i] = *reinterpret_cast<const f32x4*>(xb + (long)(rsub + 8 * i) * T + (t_in ? t : 0));
+      v[i] = *xrow(rsub + 8 * i, t_in);
 #pragma unroll
     for (int i = 0; i < RW; ++i)
       *reinterpret_cast<f32x4*>(&X[(rsub + 8 * i) * XS + c4]) = prologue4v(zero_unless(t_in, v[i]), a.pre_scale, 1);
@@ -158,12 +237,24 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   STAMP(3);
 
   // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place
+  lane_columns();
 #pragma unroll 2
   for (int i = 0; i < RW; ++i) {
     const int m = rsub + 8 * i;
     float* row = &X[m * XS];
     const f32x4 cur = *reinterpret_cast<const f32x4*>(row + c4);
-    const f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));   // c4 == 0: discarded columns
+    f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));   // c4 == 0: discarded columns
+    if constexpr (STREAM) {
+      if (clip_head) {
+        if (one_head) {
+          prev = *reinterpret_cast<const f32x4*>(&HS[m * 4]);   // written by this same lane before P0
+        } else {
+          prev = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (a.hist1 != nullptr) prev = *reinterpret_cast<const f32x4*>(a.hist1 + hoff + m * 4);
+        }
+      }
+      if (clip_tail && a.hist1_out != nullptr) *reinterpret_cast<f32x4*>(a.hist1_out + hoff + m * 4) = cur;
+    }
     const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
     float w[5];
 #pragma unroll
@@ -176,7 +267,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
 #pragma unroll
       for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
       s = elu_fast(__fadd_rn(s, bias));
-      o[e] = (t >= 0) ? s : 0.f;
+      o[e] = (STREAM || t >= 0) ? s : 0.f;   // STREAM: a clip's first samples never read their LDS neighbours
     }
     *reinterpret_cast<f32x4*>(row + c4) = o;
   }
@@ -185,15 +276,16 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
 
   // ---- P4
   gemm_phase<C>(w2t, X, acc, wave, lane);
+  lane_columns();
   // shortcut samples for P6, PF rows at a time: the first chunk is issued here and lands under the
   // next two barriers, chunk n+1 is issued before chunk n is consumed
   constexpr int PF = RW < 4 ? RW : 4;
-  const bool out_ok = c4 >= 8 && t < T;
+  const bool out_ok = STREAM ? (c4 >= 8 && t_in) : (c4 >= 8 && t < T);
   f32x4 xs[2][PF];
   auto load_xs = [&](int slot, int i0) {
 #pragma unroll
     for (int i = 0; i < PF; ++i)
-      xs[slot][i] = *reinterpret_cast<const f32x4*>(xb + (long)(rsub + 8 * (i0 + i)) * T + (out_ok ? t : 0));
+      xs[slot][i] = *xrow(rsub + 8 * (i0 + i), out_ok);
   };
   load_xs(0, 0);
   // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM
@@ -201,10 +293,21 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
   constexpr int NTOUCH = (C * 4 + 255) / 256;
   float tv[NTOUCH];
   {
-    const long nt = tile + gridDim.x;
-    const bool have = nt < a.total_tiles;
-    const long nb = have ? nt / a.tiles : b;
-    const int nt0 = have ? (int)(nt - nb * a.tiles) * TO - 8 : t0;
+    const long nt = tile + gridDim.x < a.total_tiles ? tile + gridDim.x : tile;
+    // (these loads also keep hipcc from hoisting P6's shortcut loads above the GEMM: without them, or with
+    // per-lane clip indices here, the kernel needs ~130 more VGPRs)
+    const bool have = tile + gridDim.x < a.total_tiles;
+    long nb;
+    int nt0;
+    if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
+      const int nf0 = (int)nt * TO - 8;
+      const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
+      nb = q;
+      nt0 = nf0 - (int)q * T;
+    } else {
+      nb = have ? nt / a.tiles : b;
+      nt0 = (int)(nt - nb * a.tiles) * TO - 8;
+    }
     const float* nx = a.x + nb * (long)C * T;
 #pragma unroll
     for (int i = 0; i < NTOUCH; ++i) {
@@ -232,7 +335,18 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
       const int m = rsub + 8 * (i0 + i);
       const float* row = &X[m * XS];
       const f32x4 cur = *reinterpret_cast<const f32x4*>(row + c4);
-      const f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));
+      f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));
+      if constexpr (STREAM) {
+        if (clip_head) {
+          if (one_head) {
+            prev = *reinterpret_cast<const f32x4*>(&HS[(C + m) * 4]);
+          } else {
+            prev = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.hist2 != nullptr) prev = *reinterpret_cast<const f32x4*>(a.hist2 + hoff + m * 4);
+          }
+        }
+        if (clip_tail && a.hist2_out != nullptr) *reinterpret_cast<f32x4*>(a.hist2_out + hoff + m * 4) = cur;
+      }
       const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
       float w[5];
 #pragma unroll
@@ -247,7 +361,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
         s = __fmul_rn(__fadd_rn(s, bias), a.out_scale);
         o[e] = __fadd_rn(s, xs[slot][i][e]);
       }
-      if (out_ok) *reinterpret_cast<f32x4*>(yb + (long)m * T + t) = o;
+      if (out_ok) *yrow(m) = o;
     }
   }
 #pragma unroll
@@ -259,9 +373,18 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResArgs a) {
 #undef STAMP
 }
 
-template <int C>
+template <int C, bool STREAM>
 int launch_res(ResArgs a, int B, hipStream_t s) {
-  a.total_tiles = (long)B * a.tiles;
+  a.B = B;
+  {  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
+    int l = 0;
+    while ((1L << l) < a.T) ++l;
+    if (l < 1) l = 1;
+    const unsigned long long p = 1ULL << (31 + l);
+    a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
+    a.div_shift = (unsigned)(l - 1);
+  }
+  a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
   // persistent grid = exactly what can be resident (a surplus workgroup would only start after a
   // resident one has walked its whole tile list)
   static int per_cu = 0, n_cu = 0;
@@ -270,7 +393,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HILC_ERR_LAUNCH;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C>, 256, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM>, 256, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
     n_cu = prop.multiProcessorCount;
     per_cu = occ;
@@ -278,16 +401,18 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
   const long resident = (long)n_cu * per_cu;
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL(resblock_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
 
 }  // namespace
 
-extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
-                             const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,
-                             int T, float pre_scale, float out_scale, void* stream) {
+namespace {
+int resblock_entry(bool streaming, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                   const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
+                   float* hist1_out, float* hist2_out, float* y, int B, int C, int T, float pre_scale,
+                   float out_scale, void* stream) {
   if (!x || !w1t || !dw1_w || !dw1_b || !w2t || !dw2_w || !dw2_b || !y) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
   if (x == y) return HILC_ERR_UNSUPPORTED;   // neighbouring tiles read each other's halo: not in place
@@ -296,14 +421,42 @@ extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_
   ResArgs a;
   a.x = x; a.w1t = w1t; a.dw1_w = dw1_w; a.dw1_b = dw1_b; a.w2t = w2t; a.dw2_w = dw2_w; a.dw2_b = dw2_b;
   a.y = y; a.T = T; a.tiles = (T + TO - 1) / TO; a.pre_scale = pre_scale; a.out_scale = out_scale;
+  a.hist1 = hist1; a.hist2 = hist2; a.hist1_out = hist1_out; a.hist2_out = hist2_out;
   a.dbg = g_dbg;
+  if (streaming) {
+    if ((hist1 && hist1 == hist1_out) || (hist2 && hist2 == hist2_out)) return HILC_ERR_UNSUPPORTED;   // first / last tiles of a clip race
+    if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
+    switch (C) {
+      case 64: return launch_res<64, true>(a, B, (hipStream_t)stream);
+      case 96: return launch_res<96, true>(a, B, (hipStream_t)stream);
+      case 128: return launch_res<128, true>(a, B, (hipStream_t)stream);
+      case 192: return launch_res<192, true>(a, B, (hipStream_t)stream);
+      default: return HILC_ERR_UNSUPPORTED;
+    }
+  }
   switch (C) {
-    case 64: return launch_res<64>(a, B, (hipStream_t)stream);
-    case 96: return launch_res<96>(a, B, (hipStream_t)stream);
-    case 128: return launch_res<128>(a, B, (hipStream_t)stream);
-    case 192: return launch_res<192>(a, B, (hipStream_t)stream);
+    case 64: return launch_res<64, false>(a, B, (hipStream_t)stream);
+    case 96: return launch_res<96, false>(a, B, (hipStream_t)stream);
+    case 128: return launch_res<128, false>(a, B, (hipStream_t)stream);
+    case 192: return launch_res<192, false>(a, B, (hipStream_t)stream);
     default: return HILC_ERR_UNSUPPORTED;
   }
+}
+}  // namespace
+
+extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                             const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,
+                             int T, float pre_scale, float out_scale, void* stream) {
+  return resblock_entry(false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, B, C, T,
+                        pre_scale, out_scale, stream);
+}
+
+extern "C" int hilc_resblock_stream(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                                    const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
+                                    const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C,
+                                    int T, float pre_scale, float out_scale, void* stream) {
+  return resblock_entry(true, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, B, C, T,
+                        pre_scale, out_scale, stream);
 }
 
 extern "C" void hilc_debug_set_stamp_buffer(unsigned long long* p) { g_dbg = p; }

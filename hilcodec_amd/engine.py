@@ -128,6 +128,14 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, rb.pw2_wt, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
+    if (caches is not None and FUSE_RESBLOCK and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
+            and rb.dw1_b is not None and rb.dw2_b is not None and x.shape[2] >= 4
+            and x.shape[1] <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(x.shape[1], x.shape[2])):
+        # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns
+        y, cs = ops.resblock(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, rb.pw2_wt, rb.dw2_w, rb.dw2_b,
+                             rb.pre_scale, rb.out_scale, hist=(caches[0].contiguous(), caches[1].contiguous()))
+        new_caches.extend(cs)
+        return y
     if caches is None and FUSE_DWS and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5:
         # two launches per block: [ELU, pw, dw, ELU] and [pw, dw, *scale + shortcut]; the pointwise
         # outputs never leave LDS

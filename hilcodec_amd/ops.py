@@ -5,7 +5,7 @@ hand-written gfx950 kernels of `csrc/`.  All tensors must be fp32 (indices int64
 GPU; anything else raises — there is deliberately no fallback path."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 from torch import Tensor
@@ -115,14 +115,25 @@ def resblock_supported(C: int, T: int) -> bool:
 
 
 def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, dw2_w: Tensor, dw2_b: Tensor,
-             pre_scale: float, out_scale: float) -> Tensor:
-    """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`."""
+             pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None):
+    """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`.
+    Streaming: hist = (cache of depthwise 1, cache of depthwise 2), each `[B,C,4]` -> (y, [new caches])."""
     B, Cc, T = x.shape
     y = torch.empty_like(x)
-    with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
-        check(lib.hilc_resblock(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w), _ptr(dw2_b),
-                                _ptr(y), B, Cc, T, pre_scale, out_scale, _stream()), "hilc_resblock")
-    return y
+    if hist is None:
+        with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
+            check(lib.hilc_resblock(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w), _ptr(dw2_b),
+                                    _ptr(y), B, Cc, T, pre_scale, out_scale, _stream()), "hilc_resblock")
+        return y
+    h1, h2 = hist
+    if tuple(h1.shape) != (B, Cc, 4) or tuple(h2.shape) != (B, Cc, 4):
+        raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h1.shape)} / {tuple(h2.shape)}")
+    o1, o2 = torch.empty_like(h1), torch.empty_like(h2)
+    with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} stream"):
+        check(lib.hilc_resblock_stream(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
+                                       _ptr(dw2_b), _ptr(h1), _ptr(h2), _ptr(o1), _ptr(o2), _ptr(y), B, Cc, T,
+                                       pre_scale, out_scale, _stream()), "hilc_resblock_stream")
+    return y, [o1, o2]
 
 
 def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,

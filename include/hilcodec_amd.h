@@ -83,6 +83,15 @@ int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const fl
                   float out_scale, void* stream);
 int hilc_resblock_supported(int C, int T);
 
+/* Streaming form of the same block (`streaming.py:195-276` ResBlock with two DWSBlock caches,
+ * `causal_layers.py:147-167`): hist1 / hist2 `[B][C][4]` = the last 4 samples of the two depthwise convs'
+ * inputs (the pointwise outputs) from the previous hop, hist*_out receive the new caches.  All four are
+ * optional (NULL = zero history / no cache written); outputs must not alias inputs. */
+int hilc_resblock_stream(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                         const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
+                         const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C, int T,
+                         float pre_scale, float out_scale, void* stream);
+
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)
  * y[b,c,o] = post((sum_j w[c][j] * xe[b,c,o*stride - pad + j] + bias[c]) * out_scale + res[b,c,o])

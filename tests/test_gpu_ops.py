@@ -294,6 +294,32 @@ def test_fused_resblock_vs_oracle(env, C, Tn, B):
     assert not ops.resblock_supported(80, Tn) and not ops.resblock_supported(C, 75)
 
 
+@pytest.mark.parametrize("C,hop,hops,B", [(64, 320, 3, 2), (96, 320, 2, 1), (128, 160, 3, 2), (192, 160, 2, 3), (64, 8, 5, 2),
+                                          (96, 4, 4, 1)])
+def test_fused_resblock_streaming_equals_offline(env, C, hop, hops, B):
+    """hilc_resblock_stream hop by hop (caches = last 4 pointwise outputs of each depthwise conv,
+    causal_layers.py:147-167) must reproduce the offline block on the concatenated signal bit for bit, and its
+    caches must equal the oracle's streaming caches."""
+    ops, fold, O, dev = env
+    w1, w2 = (rnd(1, C, C) / C ** 0.5).to(dev), (rnd(4, C, C) / C ** 0.5).to(dev)
+    d1, b1 = (rnd(2, C, 5) * 0.5).to(dev), (rnd(3, C) * 0.2).to(dev)
+    d2, b2 = (rnd(5, C, 5) * 0.5).to(dev), (rnd(6, C) * 0.2).to(dev)
+    x = rnd(C + hop, B, C, hop * hops).to(dev)
+    full = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.4)
+    caches = [torch.zeros(B, C, 4, device=dev), torch.zeros(B, C, 4, device=dev)]
+    outs = []
+    for h in range(hops):
+        y, caches = ops.resblock(x[:, :, h * hop:(h + 1) * hop].contiguous(), w1, d1, b1, w2, d2, b2, 0.9, 0.4, hist=caches)
+        outs.append(y)
+    assert torch.equal(torch.cat(outs, dim=2), full)
+    # caches against the un-fused streaming ops (pointwise GEMM + depthwise conv with history)
+    h1 = ops.pw_conv(x, w1, in_scale=0.9, in_elu=True)
+    g = ops.dw_conv(h1, d1, b1)
+    h2 = ops.pw_conv(g, w2, in_elu=True)
+    close(caches[0], h1[:, :, -4:].cpu(), 2e-5, "cache 1")
+    close(caches[1], h2[:, :, -4:].cpu(), 2e-5, "cache 2")
+
+
 def test_elu_fast_error(env):
     """The hot-path ELU (2^(x log2 e) - 1 via v_exp_f32) against expm1 in fp64 on a dense grid:
     absolute error bounded by one fp32 ulp of an O(1) activation."""
