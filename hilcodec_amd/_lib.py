@@ -38,6 +38,8 @@ SIGNATURES = {
     "hilc_mse_finalize": [_p, _p, _i, _d, _p],
     "hilc_rvq_decode": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_rvq_encode_mixed": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_ema_stats": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_ema_update": [_p, _p, _p, _p, _d, _i, _i, _i, _p],
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 

@@ -219,6 +219,106 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(DeqArgs a) {
   a.q[e] = acc;
 }
 
+
+// ---- training-side EMA statistics (models/hilcodec/vector_quantize.py:155-172) ----------------
+// bucket[s] = [ num_curr (K) | embed_curr (K*C) ] with num_curr[k] = #frames whose stage-s code is k and
+// embed_curr[k] = sum of those frames' stage-s INPUT residuals (z - sum_{j<s} E_j[idx_j], subtracted in stage
+// order exactly like the encoder) — the reference's `cat([onehot.sum(0), (onehot.T @ flatten).view(-1)])`, laid
+// out for ONE all-reduce over all stages.  One wave per (stage, code): it scans the stage's indices 64 frames
+// at a time (coalesced), and adds the matching frames in ascending frame order, so the result is deterministic
+// (no atomics).  Lane l owns channels l and l + 64.
+struct EmaStatsArgs {
+  const float* z;
+  const float* cb;          // [Nq][K][C] (pre-update tables, the ones the indices were computed with)
+  const int64_t* indices;
+  float* bucket;            // [n][K + K*C]
+  int B, C, T, K, n, rows;  // rows = stage dimension of `indices`
+  int channel_last, stage_major;
+};
+
+__global__ __launch_bounds__(256) void rvq_ema_stats_kernel(EmaStatsArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wave;
+  const int s = blockIdx.y;
+  if (k >= a.K) return;
+  const long nframes = (long)a.B * a.T;
+  float acc0 = 0.f, acc1 = 0.f;
+  long count = 0;
+  for (long g0 = 0; g0 < nframes; g0 += 64) {
+    const long g = g0 + lane;
+    bool hit = false;
+    if (g < nframes) {
+      const long b = g / a.T, t = g - b * a.T;
+      const long off = a.stage_major ? ((long)s * a.B + b) * a.T + t : (b * a.rows + s) * (long)a.T + t;
+      hit = a.indices[off] == k;
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    count += __builtin_popcountll(m);
+    while (m) {
+      const int f = __builtin_ctzll(m);
+      m &= m - 1;
+      const long gf = g0 + f;
+      const long b = gf / a.T, t = gf - b * a.T;
+      float r0, r1;
+      if (a.channel_last) {
+        r0 = a.z[gf * a.C + lane];
+        r1 = a.z[gf * a.C + lane + 64];
+      } else {
+        r0 = a.z[(b * a.C + lane) * (long)a.T + t];
+        r1 = a.z[(b * a.C + lane + 64) * (long)a.T + t];
+      }
+      for (int j = 0; j < s; ++j) {
+        const long off = a.stage_major ? ((long)j * a.B + b) * a.T + t : (b * a.rows + j) * (long)a.T + t;
+        const long kj = a.indices[off];
+        const float* e = a.cb + ((long)j * a.K + kj) * a.C;
+        r0 = r0 - e[lane];
+        r1 = r1 - e[lane + 64];
+      }
+      acc0 = acc0 + r0;
+      acc1 = acc1 + r1;
+    }
+  }
+  float* out = a.bucket + (long)s * (a.K + (long)a.K * a.C);
+  if (lane == 0) out[k] = (float)count;
+  out[a.K + (long)k * a.C + lane] = acc0;
+  out[a.K + (long)k * a.C + lane + 64] = acc1;
+}
+
+// ema_num = ema_num*decay + num*(1-decay); ema_embed likewise; embed = ema_embed / ema_num   (ema_inplace +
+// vector_quantize.py:165-169).  One thread per (stage, code, channel) reads the OLD ema_num; a second, stream-
+// ordered launch then updates ema_num itself (one thread per code) — writing it here would race with the other
+// channels' reads.
+struct EmaUpdateArgs {
+  float* embed;
+  float* ema_num;
+  float* ema_embed;
+  const float* bucket;
+  float decay, alpha;
+  int K, C, n;
+};
+
+__global__ __launch_bounds__(256) void rvq_ema_update_kernel(EmaUpdateArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)a.K * a.C;
+  if (e >= per * a.n) return;
+  const int s = (int)(e / per);
+  const long kc = e - s * per;
+  const int k = (int)(kc / a.C);
+  const float* bk = a.bucket + (long)s * (a.K + per);
+  const float en = fmaf(bk[k], a.alpha, __fmul_rn(a.ema_num[(long)s * a.K + k], a.decay));
+  const float ee = fmaf(bk[a.K + kc], a.alpha, __fmul_rn(a.ema_embed[e], a.decay));
+  a.ema_embed[e] = ee;
+  a.embed[e] = __fdiv_rn(ee, en);
+}
+
+__global__ __launch_bounds__(256) void rvq_ema_num_kernel(EmaUpdateArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)a.K * a.n) return;
+  const int s = (int)(e / a.K), k = (int)(e - (long)s * a.K);
+  const float* bk = a.bucket + (long)s * (a.K + (long)a.K * a.C);
+  a.ema_num[e] = fmaf(bk[k], a.alpha, __fmul_rn(a.ema_num[e], a.decay));
+}
+
 }  // namespace
 
 extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, const float* codebooks_t,
@@ -273,6 +373,37 @@ extern "C" int hilc_rvq_decode_mixed(const int64_t* indices, const float* codebo
 extern "C" int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, int B, int C, int T, int K,
                                int Nq, int n, int channel_last, int stage_major, void* stream) {
   return hilc_rvq_decode_mixed(indices, codebooks, nullptr, q, B, C, T, K, Nq, n, channel_last, stage_major, stream);
+}
+
+extern "C" int hilc_rvq_ema_stats(const float* z, const float* codebooks, const int64_t* indices, float* bucket,
+                                  int B, int C, int T, int K, int n, int index_rows, int channel_last,
+                                  int stage_major, void* stream) {
+  if (!z || !codebooks || !indices || !bucket) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || n <= 0 || index_rows < n) return HILC_ERR_SHAPE;
+  if (C != 128) return HILC_ERR_UNSUPPORTED;
+  EmaStatsArgs a;
+  a.z = z; a.cb = codebooks; a.indices = indices; a.bucket = bucket; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
+  a.rows = index_rows; a.channel_last = channel_last; a.stage_major = stage_major;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(rvq_ema_stats_kernel, dim3((unsigned)((K + 3) / 4), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_rvq_ema_update(float* embed, float* ema_num, float* ema_embed, const float* bucket, double decay,
+                                   int K, int C, int n, void* stream) {
+  if (!embed || !ema_num || !ema_embed || !bucket) return HILC_ERR_NULL;
+  if (K <= 0 || C <= 0 || n <= 0) return HILC_ERR_SHAPE;
+  EmaUpdateArgs a;
+  a.embed = embed; a.ema_num = ema_num; a.ema_embed = ema_embed; a.bucket = bucket;
+  a.decay = (float)decay; a.alpha = (float)(1.0 - decay); a.K = K; a.C = C; a.n = n;
+  const long total = (long)n * K * C;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(rvq_ema_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rvq_ema_num_kernel, dim3((unsigned)(((long)n * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
 }
 
 thread_local int hilc_last_hip_error_code = 0;

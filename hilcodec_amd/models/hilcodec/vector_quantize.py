@@ -1,18 +1,20 @@
-"""Residual VQ with the reference's API (`models/hilcodec/vector_quantize.py`), eval branch only,
-on the gfx950 RVQ kernel (`csrc/rvq.hip`).
+"""Residual VQ with the reference's API (`models/hilcodec/vector_quantize.py`) on the gfx950 RVQ kernels
+(`csrc/rvq.hip`).
 
-Training-side behaviour (EMA cluster statistics, k-means init, dead-code expiry and their
-collectives, `vector_quantize.py:32-130,155-172`) is out of scope of the forward hot path: calling
-these modules in training mode raises."""
+Eval branch = the forward hot path.  Training branch of `ResidualVQ.forward`: code search with the
+same kernel, EMA cluster statistics + codebook update on the GPU (`hilc_rvq_ema_stats` / `hilc_rvq_ema_update`),
+ONE RCCL all-reduce for all stages, dead-code expiry (`vector_quantize.py:101-130,155-172`).  k-means
+initialisation (`:32-58,91-99`) is not implemented: un-initialised codebooks raise."""
 from __future__ import annotations
 
+import random
 import typing as tp
 
 import numpy as np
 import torch
 from torch import Tensor, nn
 
-from ... import engine, fold, ops
+from ... import distributed, engine, fold, ops
 
 
 class EuclideanCodebook(nn.Module):
@@ -40,6 +42,24 @@ class EuclideanCodebook(nn.Module):
 
     def set_extra_state(self, state: tp.Dict[str, tp.Any]) -> None:
         self.initted = state["initted"]
+
+    @torch.no_grad()
+    def replace_(self, samples: Tensor, mask: Tensor) -> int:
+        """`replace` (`vector_quantize.py:101-112`): expired codes <- random vectors of the batch (rank 0's choice is
+        broadcast).  Like the reference, `ema_num` keeps its value: there `self.ema_num[idx].fill_(...)` fills a
+        temporary produced by advanced indexing, so the buffer is never written."""
+        idx = torch.nonzero(mask).squeeze(1)
+        num = idx.size(0)
+        ns = samples.shape[0]
+        if ns >= num:
+            pick = torch.randperm(ns, device=samples.device)[:num]
+        else:
+            pick = torch.randint(0, ns, (num,), device=samples.device)
+        new_embed = distributed.broadcast_(samples[pick].float().contiguous(), 0)
+        tgt = idx.to(self.embed.device)
+        self.embed[tgt, :] = new_embed.to(self.embed.device)
+        self.ema_embed[tgt, :] = (new_embed * self.ema_num_initial).to(self.ema_embed.device)
+        return num
 
     @torch.no_grad()
     def forward(self, x: Tensor) -> tp.Tuple[Tensor, int, Tensor]:
@@ -85,9 +105,62 @@ class ResidualVQ(nn.Module):
             self._key = key
         return self._spec
 
+    @torch.no_grad()
+    def _train_update(self, x: Tensor, high: int):
+        """Code search + EMA update of the first `high` codebooks (`vector_quantize.py:132-176` training branch).
+        Every stage searches with its PRE-update table, exactly as in the reference (stage i's update only touches
+        table i, which later stages never read), so search -> statistics -> one all-reduce -> update is equivalent
+        to the reference's per-stage interleaving."""
+        dev = x.device
+        layers = list(self.layers[:high])
+        sp = self.spec(dev)
+        xin = x.detach().contiguous().float()
+        idx, q, _ = ops.rvq_encode(xin, sp.codebooks, sp.codebooks_t, sp.norms, high, channel_last=self.channel_last,
+                                   stage_major=False, want_q=True)
+        bucket = ops.rvq_ema_stats(xin, sp.codebooks, idx, high, channel_last=self.channel_last, stage_major=False)
+        distributed.all_reduce_sum_(bucket)
+        decay = layers[0].decay
+        if any(l.decay != decay for l in layers):
+            raise NotImplementedError("per-layer EMA decay")
+        embed = torch.stack([l.embed.detach().float() for l in layers]).to(dev).contiguous()
+        ema_num = torch.stack([l.ema_num.detach().float() for l in layers]).to(dev).contiguous()
+        ema_embed = torch.stack([l.ema_embed.detach().float() for l in layers]).to(dev).contiguous()
+        ops.rvq_ema_update(embed, ema_num, ema_embed, bucket, decay)
+        num_replaces = np.zeros(len(self.layers), dtype=np.int64)
+        for i, l in enumerate(layers):
+            l.embed.copy_(embed[i])
+            l.ema_num.copy_(ema_num[i])
+            l.ema_embed.copy_(ema_embed[i])
+            # dead-code expiry (`:101-130`): rare, host-side torch ops; samples = this stage's input residual
+            if l.ema_num_threshold != 0.0:
+                expired = ema_num[i] < l.ema_num_threshold
+                if bool(expired.any()):
+                    res = xin if self.channel_last else xin.transpose(1, 2)
+                    for j in range(i):
+                        res = res - torch.nn.functional.embedding(idx[:, j], sp.codebooks[j])
+                    num_replaces[i] = l.replace_(res.reshape(-1, res.shape[-1]), expired)
+        self._key = None          # the cached device tables are stale now
+        return idx, q, num_replaces
+
     def forward(self, x: Tensor, n: tp.Optional[int] = None, return_indices: bool = False):
         if self.training:
-            raise NotImplementedError("training-mode RVQ (dropout / EMA updates) is outside the forward hot path")
+            for l in self.layers:
+                if not l.initted:
+                    raise RuntimeError("k-means codebook initialisation (vector_quantize.py:91-99) is not implemented: "
+                                       "load or set the codebooks first")
+            if n is not None:
+                assert 1 <= n <= len(self.layers), f"'n' must be in range of 1 <= n <= {len(self.layers)}"
+                high = n
+            elif self.dropout:
+                high = random.sample(self.dropout_index, 1)[0]
+            else:
+                high = len(self.layers)
+            idx, q, num_replaces = self._train_update(x, high)
+            loss = torch.nn.functional.mse_loss(x, q)          # commitment loss: gradient w.r.t. x (`:233`)
+            q = q + x - x.detach()                              # straight-through estimator (`:234-235`)
+            if return_indices:
+                return q, num_replaces, loss, idx
+            return q, num_replaces, loss
         for l in self.layers:
             if not l.initted:
                 raise RuntimeError("codebook not initialised (kmeans_init=True and no checkpoint loaded); the "

@@ -278,3 +278,29 @@ def rvq_decode(indices: Tensor, codebooks: Tensor, n, channel_last: bool = True,
                                     B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
           "hilc_rvq_decode")
     return q
+
+
+def rvq_ema_stats(z: Tensor, codebooks: Tensor, indices: Tensor, n: int, channel_last: bool = False,
+                  stage_major: bool = False) -> Tensor:
+    """Training-side cluster statistics of the first n stages: bucket `[n, K + K*C]` (counts | residual sums),
+    the reference's per-stage all-reduce payload (`vector_quantize.py:155-162`) for all stages at once."""
+    if channel_last:
+        B, T, Cc = z.shape
+    else:
+        B, Cc, T = z.shape
+    Nq, K, _ = codebooks.shape
+    rows = indices.shape[0] if stage_major else indices.shape[1]
+    bucket = torch.empty(n, K + K * Cc, device=z.device, dtype=torch.float32)
+    with _timed("rvq_ema_stats", 4.0 * B * T * Cc * n):
+        check(lib.hilc_rvq_ema_stats(_ptr(z), _ptr(codebooks), _ptr(indices, torch.int64), _ptr(bucket), B, Cc, T, K,
+                                     n, rows, int(channel_last), int(stage_major), _stream()), "hilc_rvq_ema_stats")
+    return bucket
+
+
+def rvq_ema_update(embed: Tensor, ema_num: Tensor, ema_embed: Tensor, bucket: Tensor, decay: float) -> None:
+    """In place on stacked `[n,K,C]` / `[n,K]` tensors: EMA of counts and sums, embed = ema_embed / ema_num."""
+    n, K, Cc = embed.shape
+    if tuple(ema_num.shape) != (n, K) or tuple(ema_embed.shape) != (n, K, Cc) or tuple(bucket.shape) != (n, K + K * Cc):
+        raise RuntimeError("rvq_ema_update: inconsistent shapes")
+    check(lib.hilc_rvq_ema_update(_ptr(embed), _ptr(ema_num), _ptr(ema_embed), _ptr(bucket), float(decay), K, Cc, n,
+                                  _stream()), "hilc_rvq_ema_update")

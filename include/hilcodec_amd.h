@@ -182,6 +182,19 @@ int hilc_rvq_decode(const int64_t* indices, const float* codebooks, float* q, in
 int hilc_rvq_decode_mixed(const int64_t* indices, const float* codebooks, const int* n_per_clip, float* q, int B,
                           int C, int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream);
 
+/* ---- RVQ training side: EMA cluster statistics and codebook update -----------------
+ * hilc_rvq_ema_stats: bucket `[n][K + K*C]`, per stage s: K counts (#frames with code k) then `[K][C]` sums of
+ * the stage-s input residuals of those frames — `torch.cat([embed_onehot.sum(0), (embed_onehot.t() @ flatten).view(-1)])`
+ * (`models/hilcodec/vector_quantize.py:155-162`) for all stages at once, so that the data-parallel reduction is ONE
+ * all-reduce of n*(K + K*C) floats instead of n (`:163`).  `indices` as written by hilc_rvq_encode (rows =
+ * index_rows >= n), `codebooks` = the tables the indices were computed with.  Deterministic (no atomics).
+ * hilc_rvq_ema_update: ema_num = ema_num*decay + counts*(1-decay); ema_embed likewise; embed = ema_embed/ema_num
+ * (`ema_inplace` `:16-17`, `:165-169`), in place on `[n][K]` / `[n][K][C]` tensors. */
+int hilc_rvq_ema_stats(const float* z, const float* codebooks, const int64_t* indices, float* bucket, int B, int C,
+                       int T, int K, int n, int index_rows, int channel_last, int stage_major, void* stream);
+int hilc_rvq_ema_update(float* embed, float* ema_num, float* ema_embed, const float* bucket, double decay, int K,
+                        int C, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,6 +276,46 @@ def rvq_forward(sd: SD, z: Tensor, n: Optional[int], num_quantizers: int,
     return out, np.zeros(num_quantizers, dtype=np.int64), loss, torch.stack(indices, dim=1)
 
 
+def rvq_train_step(state: Dict[str, Tensor], z: Tensor, n: Optional[int], num_quantizers: int, decay: float,
+                   ema_num_threshold: float = 0.0, bucket_hook=None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Training branch of `EuclideanCodebook.forward` / `ResidualVQ.forward`
+    (`models/hilcodec/vector_quantize.py:132-176,199-243`, channel_last=False), single process, expiry only
+    reported (the replacement vectors are random: `:21-29,101-112`).  `state` holds `layers.{i}.embed`,
+    `layers.{i}.ema_embed`, `layers.{i}.ema_num` and is updated IN PLACE like the module's buffers.
+    `bucket_hook(bucket)` stands for `dist.all_reduce(bucket)` (`:158-162`).
+    Returns `(quantized [B,C,T] (values of the straight-through output), loss, indices [B,n,T], expired masks [n,K])`."""
+    high = n if n is not None else num_quantizers
+    residual = z.transpose(1, 2)
+    shape = residual.shape
+    out = None
+    indices, expired = [], []
+    for i in range(high):
+        embed = state[f"layers.{i}.embed"]
+        flatten = residual.reshape(-1, shape[-1])
+        ind = codebook_argmin(flatten, embed)
+        onehot = F.one_hot(ind, embed.shape[0]).type(embed.dtype)
+        q = F.embedding(ind.view(*shape[:-1]), embed)
+        num_curr = onehot.sum(dim=0)
+        embed_curr = onehot.t() @ flatten.float()
+        if bucket_hook is not None:
+            bucket = torch.cat([num_curr, embed_curr.view(-1)])
+            bucket_hook(bucket)
+            num_curr = bucket[:embed.shape[0]]
+            embed_curr = bucket[embed.shape[0]:].reshape(embed.shape)
+        state[f"layers.{i}.ema_num"].mul_(decay).add_(num_curr, alpha=(1 - decay))
+        state[f"layers.{i}.ema_embed"].mul_(decay).add_(embed_curr, alpha=(1 - decay))
+        embed.copy_(state[f"layers.{i}.ema_embed"] / state[f"layers.{i}.ema_num"].unsqueeze(1))
+        expired.append(state[f"layers.{i}.ema_num"] < ema_num_threshold if ema_num_threshold != 0.0
+                       else torch.zeros_like(state[f"layers.{i}.ema_num"], dtype=torch.bool))
+        indices.append(ind.view(*shape[:-1]))
+        residual = residual - q
+        out = q if out is None else out + q
+    out = out.transpose(1, 2)
+    loss = F.mse_loss(z, out)
+    out = out + z - z.detach()            # straight-through estimator (`:234-235`): (q + x) - x in fp32
+    return out, loss, torch.stack(indices, dim=1), torch.stack(expired)
+
+
 def rvq_gaps_fp64(sd: SD, z: Tensor, indices: Tensor, prefix: str = "quantizer.layers.{i}.embed") -> Tensor:
     """fp64 best-vs-second-best distance gap per (b, stage, t) along the *given* index path
     (used by the parity tests to tell a genuine mismatch from a sub-ulp near-tie)."""

@@ -234,6 +234,33 @@ def rvq_golden(ref):
     print("rvq: idx", idx.shape, "legacy q diff", (q - qo).abs().max().item())
 
 
+def rvq_train_golden(ref):
+    """Training-branch known answer: two EMA steps of the reference `ResidualVQ` in train mode
+    (dead-code expiry off so that no random replacement enters), from hash-generated codebooks."""
+    nq, K, D, B, Tn, decay, init = 4, 1024, 128, 4, 75, 0.99, 0.5
+    rvq = ref.vq_new.ResidualVQ(num_quantizers=nq, dropout=False, channel_last=False, dim=D, codebook_size=K,
+                                kmeans_init=False, decay=decay, ema_num_threshold=0.0, ema_num_initial=init).train()
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(synth.key_seed(77, f"rvq{i}"), K * D) * np.float32(0.3 * 0.95 ** i)).view(K, D)
+        rvq.layers[i].embed.copy_(e)
+        rvq.layers[i].ema_embed.copy_(e * init)
+    out = dict(codebook_seed=np.int64(77), decay=np.float64(decay), ema_num_initial=np.float64(init))
+    for step in range(2):
+        z = torch.from_numpy(synth.normalish(600 + step, B * D * Tn)).view(B, D, Tn)
+        z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+        q, nr, loss, idx = rvq(z, None, return_indices=True)
+        out[f"z_seed{step}"] = np.int64(600 + step)
+        out[f"indices{step}"] = t2n(idx).astype(np.int16)
+        out[f"loss{step}"] = t2n(loss)
+        out[f"q_probe{step}"] = t2n(q[:, :, ::5])
+    out["ema_num"] = np.stack([t2n(l.ema_num) for l in rvq.layers])
+    out["embed_rows"] = np.stack([t2n(l.embed[::16]) for l in rvq.layers])
+    out["ema_embed_rows"] = np.stack([t2n(l.ema_embed[::16]) for l in rvq.layers])
+    out["embed_sum"] = np.array([float(l.embed.double().sum()) for l in rvq.layers])
+    np.savez_compressed(os.path.join(OUT, "rvq_train.npz"), **out)
+    print("rvq_train: loss", float(loss), "ema_num range", out["ema_num"].min(), out["ema_num"].max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -244,6 +271,7 @@ def main():
     streaming_golden(ref, model, mk, sd, "hil_speech")
     offline_golden(ref, "hil_music", n_clips=1, partial_n=2)
     trained_codebook_golden(ref)
+    rvq_train_golden(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 
@@ -279,5 +307,8 @@ if __name__ == "__main__":
     if "--trained" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         trained_codebook_golden(R.load_reference())
+    elif "--rvq-train" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        rvq_train_golden(R.load_reference())
     else:
         main()

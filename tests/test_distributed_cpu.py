@@ -77,3 +77,65 @@ def test_two_rank_gloo_sharding_and_gather():
     x = synth.synth_clips(5, 1600, seed=1234)
     _, _, _, idx = O.rvq_forward(sd, O.encoder_forward(sd, x, mk), None, 8)
     assert float(idx.sum()) == cs0 + cs1
+
+
+def _ema_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    from hilcodec_amd import distributed as D, synth
+    from oracle import hilcodec_oracle as O
+    torch.set_num_threads(2)
+    D.init("gloo")
+    nq, K, Dm, total, Tn = 2, 1024, 128, 6, 30
+    st = {}
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(300 + i, K * Dm) * np.float32(0.3)).view(K, Dm)
+        st[f"layers.{i}.embed"], st[f"layers.{i}.ema_embed"], st[f"layers.{i}.ema_num"] = e.clone(), e * 0.5, torch.ones(K) * 0.5
+    z = torch.from_numpy(synth.normalish(55, total * Dm * Tn)).view(total, Dm, Tn)
+    lo, hi = D.shard_range(total, rank, world)
+    calls = []
+
+    def hook(bucket):                      # the reference's dist.all_reduce(bucket) (vector_quantize.py:158-162)
+        calls.append(bucket.numel())
+        D.all_reduce_sum_(bucket)
+
+    _, _, idx, _ = O.rvq_train_step(st, z[lo:hi], None, nq, 0.9, bucket_hook=hook)
+    q.put((rank, calls, {k: v.numpy() for k, v in st.items()}, idx.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_rvq_ema_all_reduce():
+    """The one real exchange of the codec: per-rank cluster statistics summed over ranks.  Both
+    ranks must end with the SAME codebooks, equal to a single process that saw the whole batch."""
+    import numpy as np
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ema_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, calls0, st0, idx0), (_, calls1, st1, idx1) = res
+    assert calls0 == calls1 == [1024 + 1024 * 128] * 2
+    for k in st0:
+        assert np.array_equal(st0[k], st1[k]), k
+    sys.path.insert(0, ROOT)
+    from hilcodec_amd import synth
+    from oracle import hilcodec_oracle as O
+    st = {}
+    for i in range(2):
+        e = torch.from_numpy(synth.normalish(300 + i, 1024 * 128) * np.float32(0.3)).view(1024, 128)
+        st[f"layers.{i}.embed"], st[f"layers.{i}.ema_embed"], st[f"layers.{i}.ema_num"] = e.clone(), e * 0.5, torch.ones(1024) * 0.5
+    z = torch.from_numpy(synth.normalish(55, 6 * 128 * 30)).view(6, 128, 30)
+    _, _, idx, _ = O.rvq_train_step(st, z, None, 2, 0.9)
+    assert np.array_equal(np.concatenate([idx0, idx1]), idx.numpy())
+    for k in st:
+        assert np.allclose(st0[k], st[k].numpy(), rtol=1e-6, atol=1e-7), k

@@ -185,3 +185,94 @@ def test_rvq_mixed_n_per_clip():
         rvq(z.to(dev), [2, 9, 4, 1, 8, 2, 5])
     with pytest.raises(RuntimeError):
         rvq(z.to(dev), [2, 4])
+
+
+def _train_module(seed, nq, decay, threshold, init, dev):
+    from hilcodec_amd.models.hilcodec.vector_quantize import ResidualVQ
+    rvq = ResidualVQ(num_quantizers=nq, dropout=False, channel_last=False, dim=128, codebook_size=1024,
+                     kmeans_init=False, decay=decay, ema_num_threshold=threshold, ema_num_initial=init).to(dev).train()
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(synth.key_seed(seed, f"rvq{i}"), 1024 * 128) * np.float32(0.3 * 0.95 ** i)).view(1024, 128)
+        rvq.layers[i].embed.copy_(e)
+        rvq.layers[i].ema_embed.copy_(e * init)
+    return rvq
+
+
+def test_rvq_training_branch_golden(golden):
+    """two training steps (code search, EMA cluster statistics, codebook update) against the
+    reference's ResidualVQ in train mode (tests/golden/rvq_train.npz).  Indices bit-exact; the statistics are a
+    sum over frames whose order differs from the CPU GEMM's, so tables agree to fp32 rounding."""
+    g = golden("rvq_train")
+    dev = torch.device("cuda:0")
+    nq, D, B, Tn = 4, 128, 4, 75
+    rvq = _train_module(int(g["codebook_seed"]), nq, float(g["decay"]), 0.0, float(g["ema_num_initial"]), dev)
+    for step in range(2):
+        z = torch.from_numpy(synth.normalish(int(g[f"z_seed{step}"]), B * D * Tn)).view(B, D, Tn)
+        z = (torch.nn.functional.normalize(z, dim=1) * D ** 0.5).to(dev).requires_grad_(True)
+        q, nr, loss, idx = rvq(z, None, return_indices=True)
+        assert torch.equal(idx.cpu(), T(g[f"indices{step}"]).long()), f"step {step}"
+        assert abs(float(loss.detach()) - float(g[f"loss{step}"])) <= 2e-6 * float(loss.detach())
+        assert (q[:, :, ::5].detach().cpu() - T(g[f"q_probe{step}"])).abs().max() <= 1e-6
+        assert nr.dtype == np.int64 and not nr.any()
+        loss.backward()                                     # commitment loss reaches the encoder output
+        assert z.grad is not None and torch.isfinite(z.grad).all() and float(z.grad.abs().sum()) > 0
+    for i in range(nq):
+        assert torch.equal(rvq.layers[i].ema_num.cpu(), T(g["ema_num"][i]))     # counts are exact integers
+        assert (rvq.layers[i].embed[::16].cpu() - T(g["embed_rows"][i])).abs().max() <= 2e-6
+        assert (rvq.layers[i].ema_embed[::16].cpu() - T(g["ema_embed_rows"][i])).abs().max() <= 2e-6
+        assert abs(float(rvq.layers[i].embed.double().sum()) - float(g["embed_sum"][i])) < 1e-3
+
+
+def test_rvq_training_stats_and_expiry_vs_oracle():
+    """hilc_rvq_ema_stats / hilc_rvq_ema_update against the oracle's training step on a larger batch, n < Nq,
+    then the dead-code expiry: the oracle says WHICH codes expire; the replacements must be batch residuals."""
+    from hilcodec_amd import fold, ops
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    nq, D, B, Tn, decay, init, thr = 3, 128, 16, 75, 0.9, 0.5, 0.46
+    rvq = _train_module(123, nq, decay, thr, init, dev)
+    st = {}
+    for i in range(nq):
+        st[f"layers.{i}.embed"] = rvq.layers[i].embed.cpu().clone()
+        st[f"layers.{i}.ema_embed"] = rvq.layers[i].ema_embed.cpu().clone()
+        st[f"layers.{i}.ema_num"] = rvq.layers[i].ema_num.cpu().clone()
+    z = torch.from_numpy(synth.normalish(31, B * D * Tn)).view(B, D, Tn)
+    z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+    # raw statistics first
+    cb, cbt, norms = [t.to(dev) for t in fold.codebook_tables([st[f"layers.{i}.embed"] for i in range(nq)])]
+    idx, _, _ = ops.rvq_encode(z.to(dev), cb, cbt, norms, 2)
+    bucket = ops.rvq_ema_stats(z.to(dev), cb, idx, 2).cpu()
+    res = z.transpose(1, 2).reshape(-1, D)
+    for s in range(2):
+        ind = idx[:, s].reshape(-1).cpu()
+        onehot = torch.nn.functional.one_hot(ind, 1024).float()
+        assert torch.equal(bucket[s, :1024], onehot.sum(0))
+        assert (bucket[s, 1024:].view(1024, D) - onehot.t() @ res).abs().max() <= 2e-5
+        res = res - st[f"layers.{s}.embed"][ind]
+    # three module steps with expiry on (decay 0.9: unused codes fall to 0.5 * 0.9^k < 0.46 at the 1st step)
+    for step in range(2):
+        before = [rvq.layers[i].embed.cpu().clone() for i in range(nq)]
+        q, nr, loss, idx = rvq(z.to(dev), 2, return_indices=True)
+        qo, losso, idxo, expired = O.rvq_train_step(st, z, 2, nq, decay, ema_num_threshold=thr)
+        assert torch.equal(idx.cpu(), idxo)
+        assert nr[2] == 0 and [int(v) for v in nr[:2]] == [int(expired[i].sum()) for i in range(2)]
+        assert torch.equal(rvq.layers[2].embed.cpu(), before[2])          # stage beyond n: untouched
+        resid = z.transpose(1, 2).reshape(-1, D)
+        for i in range(2):
+            keep = ~expired[i]
+            assert (rvq.layers[i].embed.cpu()[keep] - st[f"layers.{i}.embed"][keep]).abs().max() <= 2e-6
+            assert torch.equal(rvq.layers[i].ema_num.cpu(), st[f"layers.{i}.ema_num"])   # reference never resets ema_num
+            new = rvq.layers[i].embed.cpu()[expired[i]]
+            if len(new):
+                d = torch.cdist(new.double(), resid.double()).min(dim=1).values
+                assert d.max() < 1e-4, "replacement vectors must be residuals of this batch"
+                assert torch.allclose(rvq.layers[i].ema_embed.cpu()[expired[i]], new * init)
+            # carry the module's (random) replacements into the oracle state for the next step
+            st[f"layers.{i}.embed"] = rvq.layers[i].embed.cpu().clone()
+            st[f"layers.{i}.ema_embed"] = rvq.layers[i].ema_embed.cpu().clone()
+            resid = resid - before[i][idx[:, i].reshape(-1).cpu()]
+    rvq.eval()
+    q_eval, _, _, idx_eval = rvq(z.to(dev), None, return_indices=True)      # updated tables are what eval now uses
+    sd = {f"quantizer.layers.{i}.embed": rvq.layers[i].embed.cpu() for i in range(nq)}
+    _, _, _, idx_o = O.rvq_forward(sd, z, None, nq)
+    assert check_indices(O, sd, z, idx_eval.cpu(), idx_o) <= 1

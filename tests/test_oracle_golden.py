@@ -165,3 +165,32 @@ def test_ops_kat(golden):
     d = sub("cconvtr")
     y, c = O.causal_convtr1d(d["x"], d["cache"], d["w"], None, 5, 8)
     assert torch.equal(y, d["y"]) and torch.equal(c, d["cache_out"])
+
+
+def rvq_train_state(seed, nq, init, K=1024, D=128):
+    st = {}
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(synth.key_seed(seed, f"rvq{i}"), K * D) * np.float32(0.3 * 0.95 ** i)).view(K, D)
+        st[f"layers.{i}.embed"] = e.clone()
+        st[f"layers.{i}.ema_embed"] = e * init
+        st[f"layers.{i}.ema_num"] = torch.ones(K) * init
+    return st
+
+
+def test_rvq_train_kat(golden):
+    """training branch (EMA statistics + codebook update) against two steps of the reference in train mode"""
+    g = golden("rvq_train")
+    nq, D, B, Tn = 4, 128, 4, 75
+    st = rvq_train_state(int(g["codebook_seed"]), nq, float(g["ema_num_initial"]))
+    for step in range(2):
+        z = torch.from_numpy(synth.normalish(int(g[f"z_seed{step}"]), B * D * Tn)).view(B, D, Tn)
+        z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+        q, loss, idx, expired = O.rvq_train_step(st, z, None, nq, float(g["decay"]))
+        assert torch.equal(idx, T(g[f"indices{step}"]).long())
+        assert float(loss) == float(g[f"loss{step}"]) and torch.equal(q[:, :, ::5], T(g[f"q_probe{step}"]))
+        assert not expired.any()
+    for i in range(nq):
+        assert torch.equal(st[f"layers.{i}.ema_num"], T(g["ema_num"][i]))
+        assert torch.equal(st[f"layers.{i}.embed"][::16], T(g["embed_rows"][i]))
+        assert torch.equal(st[f"layers.{i}.ema_embed"][::16], T(g["ema_embed_rows"][i]))
+        assert abs(float(st[f"layers.{i}.embed"].double().sum()) - float(g["embed_sum"][i])) < 1e-9

@@ -98,3 +98,31 @@ def test_legacy_rvq_module(ref):
         q, nr, loss = old(z, 3)
         qo, nro, losso, _ = O.rvq_forward(sd, z, 3, nq, variant="legacy")
     assert torch.equal(q, qo) and torch.allclose(loss, losso) and (nr == nro).all()
+
+
+def test_rvq_training_branch(ref):
+    """oracle.rvq_train_step vs the reference ResidualVQ in train mode (n < Nq, expiry threshold on: the masks of
+    expired codes must agree; the reference then replaces them with random batch vectors)."""
+    D, K, nq, decay, init = 128, 1024, 3, 0.9, 0.5
+    rvq = ref.vq_new.ResidualVQ(num_quantizers=nq, dropout=False, channel_last=False, dim=D, codebook_size=K,
+                                kmeans_init=False, decay=decay, ema_num_threshold=0.0, ema_num_initial=init).train()
+    st = {}
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(800 + i, K * D) * np.float32(0.3)).view(K, D)
+        rvq.layers[i].embed.copy_(e)
+        rvq.layers[i].ema_embed.copy_(e * init)
+        st[f"layers.{i}.embed"] = e.clone()
+        st[f"layers.{i}.ema_embed"] = e * init
+        st[f"layers.{i}.ema_num"] = torch.ones(K) * init
+    for step in range(3):
+        z = torch.from_numpy(synth.normalish(70 + step, 2 * D * 40)).view(2, D, 40)
+        q, nr, loss, idx = rvq(z, 2, return_indices=True)
+        qo, losso, idxo, expired = O.rvq_train_step(st, z, 2, nq, decay, ema_num_threshold=0.46)
+        assert torch.equal(idx, idxo) and torch.equal(q, qo) and float(loss) == float(losso)
+        for i in range(nq):
+            assert torch.equal(rvq.layers[i].embed, st[f"layers.{i}.embed"])
+            assert torch.equal(rvq.layers[i].ema_num, st[f"layers.{i}.ema_num"])
+        assert expired.shape == (2, K)
+        for i in range(2):
+            assert torch.equal(expired[i], rvq.layers[i].ema_num < 0.46)
+    assert expired.any()          # after three steps at decay 0.9 unused codes have dropped below 0.46
