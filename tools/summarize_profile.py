@@ -12,11 +12,11 @@ d, out_prefix, steps_total = sys.argv[1], sys.argv[2], int(sys.argv[3])
 
 
 def short(name):
-    m = re.search(r"gemm_kernel<(\d), \(anonymous namespace\)::(\w+), \(anonymous namespace\)::(\w+)>", name)
+    name = name.replace("(anonymous namespace)::", "").replace("hilc::", "")
+    m = re.search(r"(\w+_kernel)(<[^(]*>)?\(", name)          # kernel name + its full template argument list
     if m:
-        return f"gemm_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>"
-    m = re.search(r"(\w+_kernel)(<\d+>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+        return (m.group(1) + (m.group(2) or "")).replace(", ", ",")
+    return name[:60]
 
 
 stats = collections.OrderedDict()
