@@ -26,6 +26,8 @@ SIGNATURES = {
     "hilc_up_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_supported": [_i, _i],
+    "hilc_dws_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
+    "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

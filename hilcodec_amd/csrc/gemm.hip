@@ -22,6 +22,7 @@ struct PwFlatLoader {
   float in_scale;
   int in_elu;
   int vec;  // T % 4 == 0 and x 16-B aligned -> a 4-column group never straddles two clips
+  int tile_cols = BN;   // columns of the flattened axis per tile (< BN: whole-clip tiles of the streaming path)
   typedef f32x4 Raw;
   struct State {
     long b0, b1, b2, b3;
@@ -29,9 +30,10 @@ struct PwFlatLoader {
   };
   __device__ State init(long ntile, int tid) const {
     State s;
-    long n = ntile * BN + (tid & 31) * 4;
+    const int c = (tid & 31) * 4;
+    long n = ntile * tile_cols + c;
     auto col = [&](long nn, long& base, bool& ok) {
-      ok = nn < ncols;
+      ok = nn < ncols && (int)(nn - ntile * tile_cols) < tile_cols;
       long b = nn / T;
       base = b * (long)K * T + (nn - b * T);
     };
@@ -156,10 +158,11 @@ struct StftLoader {
 // R = 2 / 4 / 8: the 2R taps of a channel sit in one or two aligned 16-B rows and a 4-column group
 // (t % 4 == 0) uses taps p0..p0+3 (+R) with p0 a multiple of 4 — two float4 loads instead of eight
 // scalar gathers; R = 0: generic stride (e.g. 5).
-template <int R>
+template <int R, bool HIST = false>
 struct UpLoader {
   const float* x;      // [B][K][Tin]
   const float* w;      // [K][2r]
+  const float* hist;   // streaming: [B][K] = pro(x[b,k,-1]) of the previous hop (already activated), or NULL
   int K, Tin, r;
   long ncols;          // B * Tin * r   (Tin*r % 4 == 0)
   float in_scale;
@@ -170,6 +173,7 @@ struct UpLoader {
   };
   struct State {
     long xbase;        // b*K*Tin + q0
+    long hbase;        // b*K
     int q0;
     int p[4];          // phase of column e
     int dq[4];         // q_e - q0  (0 or 1)
@@ -184,6 +188,7 @@ struct UpLoader {
     const int t = (int)(n - b * Tout);
     s.q0 = t / r;
     s.xbase = b * (long)K * Tin + s.q0;
+    s.hbase = s.ok ? b * (long)K : 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = (t + e) / r;
@@ -210,7 +215,12 @@ struct UpLoader {
       }
     }
     const long row = s.ok ? s.xbase + (long)k * Tin : 0;
-    v.xv[0] = x[(s.ok && s.q0 >= 1) ? row - 1 : 0];
+    if (HIST) {        // branch-free: the frame before the hop comes from the cache
+      const float* p0 = s.q0 >= 1 ? x + row - 1 : hist + s.hbase + k;
+      v.xv[0] = *(s.ok ? p0 : x);
+    } else {
+      v.xv[0] = x[(s.ok && s.q0 >= 1) ? row - 1 : 0];
+    }
     v.xv[1] = x[row];
     v.xv[2] = x[(s.ok && s.q0 + 1 < Tin) ? row + 1 : 0];
     return v;
@@ -218,6 +228,7 @@ struct UpLoader {
   __device__ f32x4 transform(const State& s, const Raw& v, int) const {
     float a[3];
     a[0] = (s.ok && s.q0 >= 1) ? prologue(v.xv[0], in_scale, in_elu) : 0.f;
+    if (HIST) a[0] = (s.ok && s.q0 < 1) ? v.xv[0] : a[0];                   // the cache holds activated samples
     a[1] = s.ok ? prologue(v.xv[1], in_scale, in_elu) : 0.f;
     a[2] = (s.ok && s.q0 + 1 < Tin) ? prologue(v.xv[2], in_scale, in_elu) : 0.f;
     f32x4 o;
@@ -441,6 +452,157 @@ struct DwStrideEpilogue {
   }
 };
 
+// Streaming hop, wide layers (T <= 128 samples per stream and call): a tile holds `cpt` WHOLE clips
+// (columns q*T + t), so there is no halo — the samples before t = 0 come from the cache
+// hist[b][m][pad] (pad = ksize - stride: the last `pad` pointwise outputs of the previous hop,
+// causal_layers.py:147-165) and the new cache is written from the tile.  Generic k / stride (k5 s1 and
+// k = 2r stride r); work item = (clip, row, output), output fastest: y / hist_out writes of a clip's
+// rows are contiguous.
+struct DwSegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][k]
+  const float* dw_b;
+  const float* res;    // [B][M][To] or null (may alias y)
+  const float* hist;   // [B][M][pad] or null (zeros)
+  float* hist_out;     // [B][M][pad] or null
+  int B, M, T, To, k, stride, pad, cpt;
+  unsigned to_magic, to_shift, pad_magic, pad_shift;   // n / To, n / pad as __umulhi(n, magic) >> shift
+  float out_scale;
+  int out_elu;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+      const int rows = 32 * nblk;                       // 32 or 64
+      const int rsh = nblk == 1 ? 5 : 6;
+      for (int idx = tid; idx < cpt * rows * To; idx += NT) {
+        const int qr = To == 1 ? idx : (int)(__umulhi((unsigned)idx, to_magic) >> to_shift);   // idx / To
+        const int o = idx - qr * To;
+        const int q = qr >> rsh, row = qr & (rows - 1);
+        const long b = ntile * cpt + q;
+        const int m = m0 + ch * CH * 32 + row;
+        if (m >= M || b >= B) continue;
+        const float* h = smem + row * HS + q * T;
+        const float* hp = hist != nullptr ? hist + (b * M + m) * (long)pad + pad : nullptr;   // hp[tt], tt < 0
+        const float* w = dw_w + (long)m * k;
+        float a = 0.f;
+        for (int j = 0; j < k; ++j) {
+          const int tt = o * stride - pad + j;
+          const float v = tt >= 0 ? h[tt] : (hp != nullptr ? hp[tt] : 0.f);
+          a = fmaf(w[j], v, a);
+        }
+        if (dw_b != nullptr) a = __fadd_rn(a, dw_b[m]);
+        a = __fmul_rn(a, out_scale);
+        const long off = (b * M + m) * (long)To + o;
+        if (res != nullptr) a = __fadd_rn(a, res[off]);
+        if (out_elu) a = elu_fast(a);
+        y[off] = a;
+      }
+      if (hist_out != nullptr) {
+        for (int idx = tid; idx < cpt * rows * pad; idx += NT) {
+          const int qr = pad == 1 ? idx : (int)(__umulhi((unsigned)idx, pad_magic) >> pad_shift);   // idx / pad
+          const int i = idx - qr * pad;
+          const int q = qr >> rsh, row = qr & (rows - 1);
+          const long b = ntile * cpt + q;
+          const int m = m0 + ch * CH * 32 + row;
+          if (m >= M || b >= B) continue;
+          const int src = T - pad + i;          // last `pad` samples of [cache | this hop]
+          const long ho = (b * M + m) * (long)pad;
+          hist_out[ho + i] = src >= 0 ? smem[row * HS + q * T + src] : (hist != nullptr ? hist[ho + pad + src] : 0.f);
+        }
+      }
+    }
+  }
+};
+
+// k = 5, stride 1, T % 4 == 0 (so T >= 4 and a 4-column group never straddles clips): vector form of the above.
+// Thread = (row, 16-column segment) like Dw5Epilogue; the 4 samples before a clip's t = 0 come from the cache.
+struct Dw5SegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][5]
+  const float* dw_b;
+  const float* res;
+  const float* hist;   // [B][M][4] or null
+  float* hist_out;     // [B][M][4] or null
+  int B, M, T, cpt;
+  unsigned t_magic, t_shift;   // n / T
+  float out_scale;
+  int out_elu;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int seg = tid + NT * s;
+        const int row = seg >> 3, c0 = (seg & 7) * 16;
+        const int m = m0 + ch * CH * 32 + row;
+        if (row >= nblk * 32 || m >= M) continue;
+        float v[20];
+        const float* hrow = smem + row * HS;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+          const int c = c0 - 4 + 4 * g;
+          const f32x4 qv = c >= 0 ? *reinterpret_cast<const f32x4*>(hrow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          v[4 * g] = qv.x; v[4 * g + 1] = qv.y; v[4 * g + 2] = qv.z; v[4 * g + 3] = qv.w;
+        }
+        float w[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
+        const float bias = dw_b ? dw_b[m] : 0.f;
+        int q = (int)(__umulhi((unsigned)c0, t_magic) >> t_shift);   // clip of the first column
+        int t = c0 - q * T;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long b = ntile * cpt + q;
+          const bool live = (c0 + 4 * g) < cpt * T && b < B;
+          if (live) {
+            const long bm = b * M + m;
+            float win[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) win[e] = v[4 * g + e];
+            if (t == 0) {                     // clip start: the previous 4 pointwise outputs are the cache
+              f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (hist != nullptr) hv = *reinterpret_cast<const f32x4*>(hist + bm * 4);
+              win[0] = hv.x; win[1] = hv.y; win[2] = hv.z; win[3] = hv.w;
+            }
+            if (hist_out != nullptr && t == T - 4)
+              *reinterpret_cast<f32x4*>(hist_out + bm * 4) = f32x4{win[4], win[5], win[6], win[7]};
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = 0.f;
+#pragma unroll
+              for (int j = 0; j < 5; ++j) a = fmaf(w[j], win[e + j], a);
+              a = __fadd_rn(a, bias);
+              o[e] = __fmul_rn(a, out_scale);
+            }
+            const long off = bm * (long)T + t;
+            if (res != nullptr) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], rr[e]);
+            }
+            if (out_elu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
+            }
+            *reinterpret_cast<f32x4*>(y + off) = o;
+          }
+          t += 4;
+          if (t >= T) { t = 0; ++q; }
+        }
+      }
+    }
+  }
+};
+
 }  // namespace
 
 extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
@@ -458,8 +620,18 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }
 
-extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
-                            int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream) {
+namespace {
+// new cache of the transposed conv: pro(x[b,k,Tin-1])  (causal_layers.py:168-188: cache = last input frame)
+__global__ __launch_bounds__(256) void up_hist_kernel(const float* x, float* hist_out, long n, int Tin, float in_scale,
+                                                      int in_elu) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) hist_out[e] = prologue(x[e * Tin + Tin - 1], in_scale, in_elu);
+}
+}  // namespace
+
+extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* hist_out, const float* tr_w,
+                                   const float* wt, const float* bias, float* y, int B, int K, int M, int Tin,
+                                   int stride, float in_scale, int in_elu, void* stream) {
   if (!x || !tr_w || !wt || !y) return HILC_ERR_NULL;
   if (B <= 0 || K <= 0 || M <= 0 || Tin <= 0 || stride <= 0) return HILC_ERR_SHAPE;
   if (M % 4 != 0 || ((long)Tin * stride) % 4 != 0) return HILC_ERR_UNSUPPORTED;
@@ -469,15 +641,34 @@ extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, 
   PwEpilogue ep;
   ep.y = y; ep.bias = bias; ep.res = nullptr; ep.M = M; ep.T = (int)Tout; ep.ncols = ncols; ep.out_scale = 1.0f;
   const bool w_aligned = (reinterpret_cast<uintptr_t>(tr_w) & 15) == 0;
+  if (hist_out != nullptr) {
+    if (hist_out == hist) return HILC_ERR_UNSUPPORTED;
+    const long n = (long)B * K;
+    HILC_CLEAR_ERROR();
+    hipLaunchKernelGGL(up_hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, hist_out, n,
+                       Tin, in_scale, in_elu);
+    HILC_CHECK_LAUNCH();
+  }
   auto go = [&](auto ld) {
-    ld.x = x; ld.w = tr_w; ld.K = K; ld.Tin = Tin; ld.r = stride; ld.ncols = ncols; ld.in_scale = in_scale;
+    ld.x = x; ld.w = tr_w; ld.hist = hist; ld.K = K; ld.Tin = Tin; ld.r = stride; ld.ncols = ncols; ld.in_scale = in_scale;
     ld.in_elu = in_elu;
     return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
   };
+  if (hist != nullptr) {
+    if (w_aligned && stride == 8) return go(UpLoader<8, true>{});
+    if (w_aligned && stride == 4) return go(UpLoader<4, true>{});
+    if (w_aligned && stride == 2) return go(UpLoader<2, true>{});
+    return go(UpLoader<0, true>{});
+  }
   if (w_aligned && stride == 8) return go(UpLoader<8>{});
   if (w_aligned && stride == 4) return go(UpLoader<4>{});
   if (w_aligned && stride == 2) return go(UpLoader<2>{});
   return go(UpLoader<0>{});
+}
+
+extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
+                            int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream) {
+  return hilc_up_conv_stream(x, nullptr, nullptr, tr_w, wt, bias, y, B, K, M, Tin, stride, in_scale, in_elu, stream);
 }
 
 extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b,
@@ -512,6 +703,48 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
   ld.tiles = ep.tiles; ld.step = ep.n_out * stride; ld.halo = ep.H;
   ld.vec = aligned && (T % 4 == 0);
   return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
+}
+
+extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, const float* dw_b,
+                                    const float* hist, float* hist_out, const float* res, float* y, int B, int K,
+                                    int M, int T, int ksize, int stride, float in_scale, int in_elu,
+                                    float out_scale, int out_elu, void* stream) {
+  if (!x || !wt || !dw_w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || K <= 0 || M <= 0 || T <= 0 || ksize <= 0 || stride <= 0) return HILC_ERR_SHAPE;
+  if (M % 4 != 0 || T > BN || T % stride != 0 || ksize < stride || ksize > 32) return HILC_ERR_UNSUPPORTED;
+  if (hist != nullptr && hist == hist_out) return HILC_ERR_UNSUPPORTED;
+  const int pad = ksize - stride;
+  if (pad == 0 && (hist != nullptr || hist_out != nullptr)) return HILC_ERR_SHAPE;
+  const int cpt = BN / T;
+  PwFlatLoader ld;
+  ld.x = x; ld.K = K; ld.T = T; ld.ncols = (long)B * T; ld.in_scale = in_scale; ld.in_elu = in_elu;
+  ld.vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  ld.tile_cols = cpt * T;
+  // n / d for n < 2^31 as __umulhi(n, magic) >> shift (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l)/d)
+  auto magic = [](int d, unsigned& m, unsigned& sh) {
+    int l = 0;
+    while ((1L << l) < d) ++l;
+    if (l < 1) l = 1;
+    m = (unsigned)(((1ULL << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+    sh = (unsigned)(l - 1);
+  };
+  const long ntiles = ((long)B + cpt - 1) / cpt;
+  const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(hist) |
+                    reinterpret_cast<uintptr_t>(hist_out)) & 15) == 0;
+  if (ksize == 5 && stride == 1 && T % 4 == 0 && al) {
+    Dw5SegEpilogue ep;
+    ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.res = res; ep.hist = hist; ep.hist_out = hist_out; ep.B = B; ep.M = M;
+    ep.T = T; ep.cpt = cpt; ep.out_scale = out_scale; ep.out_elu = out_elu;
+    magic(T, ep.t_magic, ep.t_shift);
+    return launch_gemm(wt, M, K, M, ntiles, true, ld, ep, (hipStream_t)stream);
+  }
+  DwSegEpilogue ep;
+  ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.res = res; ep.hist = hist; ep.hist_out = hist_out; ep.B = B; ep.M = M;
+  ep.T = T; ep.To = T / stride; ep.k = ksize; ep.stride = stride; ep.pad = pad; ep.cpt = cpt;
+  ep.out_scale = out_scale; ep.out_elu = out_elu;
+  magic(ep.To, ep.to_magic, ep.to_shift);
+  magic(pad > 0 ? pad : 1, ep.pad_magic, ep.pad_shift);
+  return launch_gemm(wt, M, K, M, ntiles, true, ld, ep, (hipStream_t)stream);
 }
 
 extern "C" int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const float* basis_t,

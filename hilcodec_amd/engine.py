@@ -25,6 +25,7 @@ FUSE_DWS = True
 # narrow layers (C <= 192) are HBM-bound unless the whole residual block is one launch (hilc_resblock)
 FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside the pointwise GEMM's loader
 FUSE_RESBLOCK = True
+FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
 
 
@@ -136,6 +137,15 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
                              rb.pre_scale, rb.out_scale, hist=(caches[0].contiguous(), caches[1].contiguous()))
         new_caches.extend(cs)
         return y
+    if (caches is not None and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], rb.dw1_w.shape[1], 1)
+            and ops.dws_conv_stream_profitable(x.shape[2], rb.dw2_w.shape[1], 1)):
+        # wide layers of a streaming hop (T <= 128): two launches, whole-clip tiles, caches read/written in the epilogue
+        g, c0 = ops.dws_conv_stream(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, caches[0].contiguous(), in_scale=rb.pre_scale,
+                                    in_elu=True, out_elu=True)
+        y, c1 = ops.dws_conv_stream(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, caches[1].contiguous(), res=x,
+                                    out_scale=rb.out_scale, out=x)
+        new_caches.extend([c0, c1])
+        return y
     if caches is None and FUSE_DWS and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5:
         # two launches per block: [ELU, pw, dw, ELU] and [pw, dw, *scale + shortcut]; the pointwise
         # outputs never leave LDS
@@ -180,7 +190,11 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
             ci += 2
-        if streaming:
+        if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
+            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci].contiguous(),
+                                       stride=st.ratio, in_scale=st.down_in_scale, in_elu=True)
+            new_caches.append(c)
+        elif streaming:
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
             x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True)
             new_caches.append(c)
@@ -211,7 +225,10 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     new_caches: Optional[list] = [] if streaming else None
     q = q.contiguous().float()
     ci = 0
-    if streaming:
+    if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
+        x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0].contiguous())
+        new_caches.append(c)
+    elif streaming:
         h = ops.pw_conv(q, ds.pre_pw_wt)
         x, c = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b, hist=caches[0], want_hist=True)
         new_caches.append(c)
@@ -222,7 +239,12 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         x = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b)
     ci = 1
     for st in ds.stages:
-        if streaming:
+        if streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
+            x, c = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True,
+                               hist=caches[ci].contiguous(), want_hist=True)
+            new_caches.append(c)
+            u = x                # already through the pointwise conv
+        elif streaming:
             u, c = ops.dw_convtr(x, st.tr_w, st.ratio, hist=caches[ci], want_hist=True,
                                  in_scale=st.in_scale, in_elu=True)
             new_caches.append(c)
@@ -233,7 +255,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         ci += 1
         if u is None:
             x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True)
-        else:
+        elif u is not x:
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)

@@ -97,17 +97,57 @@ def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None,
     return y
 
 
+def dws_conv_stream_supported(T: int, k: int, stride: int) -> bool:
+    """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride"""
+    return T <= 128 and T % stride == 0 and stride <= k <= 32
+
+
+def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
+    """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
+    --mode streaming): not for single-sample hops, whose depthwise taps are nearly all cache reads."""
+    return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
+
+
+def dws_conv_stream(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
+                    res: Optional[Tensor] = None, stride: int = 1, in_scale: float = 1.0, in_elu: bool = False,
+                    out_scale: float = 1.0, out_elu: bool = False, out: Optional[Tensor] = None):
+    """Streaming hop of a depthwise-separable block (hilc_dws_conv_stream): x `[B,K,T]`, T <= 128, cache
+    `[B,M,k-stride]` (last pointwise outputs of the previous hop) -> (y `[B,M,T/stride]`, new cache)."""
+    B, K, T = x.shape
+    M = wt.shape[1]
+    k = dw_w.shape[1]
+    pad = k - stride
+    if hist is not None and tuple(hist.shape) != (B, M, pad):
+        raise RuntimeError(f"cache must be [{B},{M},{pad}], got {tuple(hist.shape)}")
+    y = out if out is not None else torch.empty(B, M, T // stride, device=x.device, dtype=torch.float32)
+    hout = torch.empty(B, M, pad, device=x.device, dtype=torch.float32)
+    with _timed("dws_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k{k} s{stride} stream"):
+        check(lib.hilc_dws_conv_stream(_ptr(x), _ptr(wt), _ptr(dw_w), _ptr(dw_b), _ptr(hist), _ptr(hout), _ptr(res),
+                                       _ptr(y), B, K, M, T, k, stride, in_scale, int(in_elu), out_scale,
+                                       int(out_elu), _stream()), "hilc_dws_conv_stream")
+    return y, hout
+
+
 def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
-            in_elu: bool = True) -> Tensor:
+            in_elu: bool = True, hist: Optional[Tensor] = None, want_hist: bool = False):
     """Fused [Scale, ELU, depthwise transposed conv (k=2*stride), pointwise conv + bias]:
-    x `[B,K,Tin]`, tr_w `[K,2*stride]`, wt `[K,M]` -> `[B,M,Tin*stride]`; see hilc_up_conv."""
+    x `[B,K,Tin]`, tr_w `[K,2*stride]`, wt `[K,M]` -> `[B,M,Tin*stride]`; see hilc_up_conv.
+    Streaming: hist `[B,K,1]` = the activated last input frame of the previous hop -> (y, new cache)."""
     B, K, Tin = x.shape
     M = wt.shape[1]
     y = torch.empty(B, M, Tin * stride, device=x.device, dtype=torch.float32)
-    with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride}"):
-        check(lib.hilc_up_conv(_ptr(x), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y), B, K, M, Tin, stride,
-                               in_scale, int(in_elu), _stream()), "hilc_up_conv")
-    return y
+    if hist is None and not want_hist:
+        with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride}"):
+            check(lib.hilc_up_conv(_ptr(x), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y), B, K, M, Tin, stride,
+                                   in_scale, int(in_elu), _stream()), "hilc_up_conv")
+        return y
+    if hist is not None and hist.numel() != B * K:
+        raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(hist.shape)}")
+    hout = torch.empty(B, K, 1, device=x.device, dtype=torch.float32) if want_hist else None
+    with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride} stream"):
+        check(lib.hilc_up_conv_stream(_ptr(x), _ptr(hist), _ptr(hout), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y),
+                                      B, K, M, Tin, stride, in_scale, int(in_elu), _stream()), "hilc_up_conv_stream")
+    return (y, hout) if want_hist else y
 
 
 def resblock_supported(C: int, T: int) -> bool:

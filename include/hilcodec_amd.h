@@ -72,6 +72,21 @@ int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const floa
 int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
                  int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream);
 
+/* Streaming hop of the same stage (`streaming.py:520-648` Decoder.forward, `causal_layers.py:168-188`): hist `[B][K]` =
+ * pro(x[b,k,-1]) of the previous hop (the transposed conv's cache holds ACTIVATED samples, like hilc_dw_convtr's),
+ * hist_out receives pro(x[b,k,Tin-1]).  Both optional; must not alias. */
+int hilc_up_conv_stream(const float* x, const float* hist, float* hist_out, const float* tr_w, const float* wt,
+                        const float* bias, float* y, int B, int K, int M, int Tin, int stride, float in_scale,
+                        int in_elu, void* stream);
+
+/* Streaming hop of hilc_dws_conv for the wide layers (DWSBlock.forward `streaming.py:160-192`, CausalConv1d
+ * `causal_layers.py:147-165`): T <= 128 samples per stream and call, T % stride == 0, any ksize >= stride.
+ * hist `[B][M][ksize-stride]` = the last pointwise outputs of the previous hop (NULL = zeros), hist_out receives
+ * the new cache (must not alias hist).  A tile holds whole clips, so nothing is recomputed. */
+int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, const float* dw_b, const float* hist,
+                         float* hist_out, const float* res, float* y, int B, int K, int M, int T, int ksize,
+                         int stride, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
+
 /* ---- fully fused residual block (narrow, long layers: C in {64, 96, 128, 192}, T % 4 == 0) --------
  * y = x + out_scale * (dw2(pw2(ELU(dw1(pw1(ELU(pre_scale * x))) + dw1_b))) + dw2_b)
  * One HBM read of x and one write of y per block; both pointwise outputs and the mid activation

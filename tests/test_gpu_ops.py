@@ -348,3 +348,65 @@ def test_up_conv_vs_oracle(env, K, M, Tin, r):
     y = ops.up_conv(x.to(dev), tw[:, 0].contiguous().to(dev), fold.pointwise_layout(w).to(dev), b.to(dev), r,
                     in_scale=0.7071, in_elu=True)
     close(y, ref, 3e-5, "up_conv")
+
+
+@pytest.mark.parametrize("K,M,Tn,k,s,B", [(256, 256, 40, 5, 1, 7), (512, 512, 8, 5, 1, 33), (128, 1536, 1, 5, 1, 130),
+                                           (256, 512, 40, 10, 5, 5), (512, 1024, 8, 16, 8, 20), (96, 64, 128, 4, 2, 3),
+                                           (64, 128, 12, 5, 1, 11)])
+def test_dws_conv_stream_vs_unfused_and_offline(env, K, M, Tn, k, s, B):
+    """hilc_dws_conv_stream (whole-clip tiles, cache-aware epilogue) over 3 hops: against the pointwise GEMM +
+    cached depthwise conv (the already oracle-pinned streaming ops), and — concatenated — against the oracle's
+    offline causal conv of the whole signal (causal_layers.py:147-165 cache semantics)."""
+    ops, fold, O, dev = env
+    hops = 3
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    dw = rnd(K + k, M, 1, k) * 0.4
+    db = rnd(M, M) * 0.2
+    x = rnd(K + Tn + B, B, K, Tn * hops)
+    res = rnd(7, B, M, (Tn // s) * hops) if s == 1 else None
+    wt, dww, dbd = fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev)
+    cache_f = torch.zeros(B, M, k - s, device=dev)
+    cache_u = torch.zeros(B, M, k - s, device=dev)
+    outs = []
+    for h in range(hops):
+        xh = x[:, :, h * Tn:(h + 1) * Tn].contiguous().to(dev)
+        rh = res[:, :, h * Tn:(h + 1) * Tn].contiguous().to(dev) if res is not None else None
+        y, cache_f = ops.dws_conv_stream(xh, wt, dww, dbd, cache_f, res=rh, stride=s, in_scale=0.9, in_elu=True,
+                                         out_scale=0.5 if s == 1 else 1.0, out_elu=(s == 1))
+        hp = ops.pw_conv(xh, wt, in_scale=0.9, in_elu=True)
+        yu, cache_u = ops.dw_conv(hp, dww, dbd, res=rh, stride=s, hist=cache_u, want_hist=True,
+                                  out_scale=0.5 if s == 1 else 1.0, out_elu=(s == 1))
+        assert torch.equal(y, yu), f"hop {h}"
+        assert torch.equal(cache_f, cache_u), f"cache after hop {h}"
+        outs.append(y)
+    full = O.sconv1d(F.conv1d(F.elu(x * 0.9), w), dw, db, stride=s, groups=M)
+    if s == 1:
+        full = F.elu(full * 0.5 + res)
+    close(torch.cat(outs, dim=2), full, 3e-5, "streamed vs offline oracle")
+    assert not ops.dws_conv_stream_supported(160, 5, 1) and not ops.dws_conv_stream_supported(40, 16, 16)
+
+
+@pytest.mark.parametrize("K,M,Tin,r,B", [(1536, 768, 1, 8, 9), (768, 384, 8, 5, 4), (384, 192, 40, 4, 3), (192, 96, 160, 2, 2)])
+def test_up_conv_stream_vs_unfused_and_offline(env, K, M, Tin, r, B):
+    """hilc_up_conv_stream over 3 hops against hilc_dw_convtr (with cache) + hilc_pw_conv, and concatenated against
+    the offline fused op on the whole signal (causal_layers.py:168-188: cache = last activated input frame)."""
+    ops, fold, O, dev = env
+    hops = 3
+    x = rnd(K + Tin, B, K, Tin * hops).to(dev)
+    tw = rnd(K + r, K, 2 * r).to(dev)
+    wt = fold.pointwise_layout(rnd(K + M, M, K, 1) / K ** 0.5).to(dev)
+    b = (rnd(M, M) * 0.1).to(dev)
+    cf = torch.zeros(B, K, 1, device=dev)
+    cu = torch.zeros(B, K, 1, device=dev)
+    outs = []
+    for h in range(hops):
+        xh = x[:, :, h * Tin:(h + 1) * Tin].contiguous()
+        y, cf = ops.up_conv(xh, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=cf, want_hist=True)
+        u, cu = ops.dw_convtr(xh, tw, r, hist=cu, want_hist=True, in_scale=0.7071, in_elu=True)
+        yu = ops.pw_conv(u, wt, b)
+        assert torch.equal(cf, cu)
+        close(y, yu.cpu(), 1e-6, f"hop {h}")          # same products; the fused loader adds them in one fmaf
+        outs.append(y)
+    if (Tin * hops * r) % 4 == 0:
+        full = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True)
+        assert torch.equal(torch.cat(outs, dim=2), full)
