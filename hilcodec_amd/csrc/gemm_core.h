@@ -155,9 +155,12 @@ int launch_gemm(const float* wt, int M, int K, int ldw, long ntiles, bool lds_ep
     int pad4 = (4 - m32 % 4) % 4, pad3 = (3 - m32 % 3) % 3;
     MB = pad3 < pad4 ? 3 : 4;
   }
+  // few columns (a streaming hop's T = 1 layers: 8 column tiles): shorter row tiles so that more CUs get a
+  // workgroup — per-output arithmetic (k order) is unchanged
+  long groups = (ntiles + 7) / 8;
+  while (MB > 1 && groups * 8 * ((m32 + MB - 1) / MB) < 128) --MB;
   if (const char* e = getenv("HILC_MB")) { int v = atoi(e); if (v >= 1 && v <= 4) MB = v; }   // tuning aid
   int mtiles = (m32 + MB - 1) / MB;
-  long groups = (ntiles + 7) / 8;
   long blocks = groups * 8 * mtiles;
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   dim3 grid((unsigned)blocks), block(NT);

@@ -13,7 +13,8 @@
 
 namespace {
 
-constexpr int FR = 16;   // frames per workgroup
+// frames per workgroup: 16 for large batches; 4 when 16 would leave most CUs idle (a streaming hop of 1024 frames
+// = 64 workgroups otherwise) — the code scores are independent of FR, only the work split changes
 constexpr int RS = 20;   // LDS row stride (floats) of the [c][frame] tiles: 16-B aligned, spreads banks
 constexpr int CPT = 4;   // codes per thread (K / 256 for K = 1024)
 
@@ -37,8 +38,9 @@ __device__ __forceinline__ long zoff(const RvqArgs& a, long g, int c) {
   return (b * a.C + c) * (long)a.T + t;
 }
 
-template <int C>
+template <int C, int FR>
 __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
+  static_assert(FR % 4 == 0 && FR <= RS, "frames are read as float4 rows");
   __shared__ __attribute__((aligned(16))) float res[C][RS];
   __shared__ __attribute__((aligned(16))) float qsum[C][RS];
   __shared__ float wbest[4][FR];
@@ -334,8 +336,11 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   a.frame_err = frame_err; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
   a.channel_last = channel_last; a.stage_major = stage_major;
   long nframes = (long)B * T;
-  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(rvq_encode_kernel<128>, dim3((unsigned)((nframes + FR - 1) / FR)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  HILC_CLEAR_ERROR();
+  if (nframes <= 16 * 512)
+    hipLaunchKernelGGL((rvq_encode_kernel<128, 4>), dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((rvq_encode_kernel<128, 16>), dim3((unsigned)((nframes + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
