@@ -4,6 +4,7 @@
 //                     LDS: the [C x T] intermediate of a depthwise-separable block never reaches HBM
 //   hilc_stft_logmag  strided-window DFT (implicit im2col of the waveform) -> |.| -> log -> normalise
 #include "gemm_core.h"
+#include "gemm_lin.h"
 
 using namespace hilc;
 
@@ -605,6 +606,9 @@ struct Dw5SegEpilogue {
 
 }  // namespace
 
+// the linear-addressing core (gemm_lin.h) uses 32-bit byte offsets into x
+static bool lin_ok(int B, int K, int T) { return (long)B * K * T * 4 < (1L << 32); }
+
 extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
                             int B, int K, int M, int T, float in_scale, int in_elu, float out_scale,
                             void* stream) {
@@ -617,6 +621,11 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   ld.vec = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   PwEpilogue ep;
   ep.y = y; ep.bias = bias; ep.res = res; ep.M = M; ep.T = T; ep.ncols = ncols; ep.out_scale = out_scale;
+  if (ld.vec && lin_ok(B, K, T)) {
+    FlatCols cols;
+    cols.K = K; cols.T = T; cols.tile_cols = BN; cols.ncols = ncols;
+    return launch_gemm_lin(wt, x, M, K, M, T, (ncols + BN - 1) / BN, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
+  }
   return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }
 
@@ -690,6 +699,11 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
              (res == nullptr || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
     ld.tiles = ep.tiles; ld.step = Dw5Epilogue::STEP; ld.halo = 4;
     ld.vec = aligned && (T % 4 == 0);
+    if (ld.vec && lin_ok(B, K, T)) {
+      TileCols cols;
+      cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
+      return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
+    }
     return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
   }
   if (ksize != 2 * stride || stride > 16 || res != nullptr || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
@@ -702,6 +716,11 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
   ep.tiles = (ep.To + ep.n_out - 1) / ep.n_out;
   ld.tiles = ep.tiles; ld.step = ep.n_out * stride; ld.halo = ep.H;
   ld.vec = aligned && (T % 4 == 0);
+  if (ld.vec && lin_ok(B, K, T)) {
+    TileCols cols;
+    cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
+    return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
+  }
   return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
 }
 
@@ -731,11 +750,15 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
   const long ntiles = ((long)B + cpt - 1) / cpt;
   const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(hist) |
                     reinterpret_cast<uintptr_t>(hist_out)) & 15) == 0;
+  FlatCols cols;
+  cols.K = K; cols.T = T; cols.tile_cols = cpt * T; cols.ncols = (long)B * T;
+  const bool lin = ld.vec && lin_ok(B, K, T);
   if (ksize == 5 && stride == 1 && T % 4 == 0 && al) {
     Dw5SegEpilogue ep;
     ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.res = res; ep.hist = hist; ep.hist_out = hist_out; ep.B = B; ep.M = M;
     ep.T = T; ep.cpt = cpt; ep.out_scale = out_scale; ep.out_elu = out_elu;
     magic(T, ep.t_magic, ep.t_shift);
+    if (lin) return launch_gemm_lin(wt, x, M, K, M, T, ntiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
     return launch_gemm(wt, M, K, M, ntiles, true, ld, ep, (hipStream_t)stream);
   }
   DwSegEpilogue ep;
@@ -744,6 +767,7 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
   ep.out_scale = out_scale; ep.out_elu = out_elu;
   magic(ep.To, ep.to_magic, ep.to_shift);
   magic(pad > 0 ? pad : 1, ep.pad_magic, ep.pad_shift);
+  if (lin) return launch_gemm_lin(wt, x, M, K, M, T, ntiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
   return launch_gemm(wt, M, K, M, ntiles, true, ld, ep, (hipStream_t)stream);
 }
 
