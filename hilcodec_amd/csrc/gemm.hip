@@ -663,6 +663,24 @@ extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* his
     ld.in_elu = in_elu;
     return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
   };
+  if (lin_ok(B, K, Tin)) {   // linear-addressing core (gemm_lin.h): same arithmetic, far fewer VALU per K slice
+    auto lin = [&](auto bop) {
+      bop.x = x; bop.w = tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
+      bop.in_scale = in_scale;
+      return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, ep, (hipStream_t)stream);
+    };
+    const int rsel = !w_aligned ? 0 : stride == 8 ? 8 : stride == 4 ? 4 : stride == 2 ? 2 : 0;
+#define HILC_UP(RV)                                                                         \
+  do {                                                                                      \
+    if (in_elu) return hist ? lin(UpB<RV, true, true>{}) : lin(UpB<RV, true, false>{});     \
+    return hist ? lin(UpB<RV, false, true>{}) : lin(UpB<RV, false, false>{});               \
+  } while (0)
+    if (rsel == 8) HILC_UP(8);
+    if (rsel == 4) HILC_UP(4);
+    if (rsel == 2) HILC_UP(2);
+    HILC_UP(0);
+#undef HILC_UP
+  }
   if (hist != nullptr) {
     if (w_aligned && stride == 8) return go(UpLoader<8, true>{});
     if (w_aligned && stride == 4) return go(UpLoader<4, true>{});

@@ -50,10 +50,160 @@ struct TileCols {
   }
 };
 
-template <int MB, bool ELU, class Cols, class Epilogue>
-__global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ wt, const float* __restrict__ x, int M,
-                                                      int K, int ldw, int T, long ntiles, int mtiles,
-                                                      float in_scale, Cols cols, Epilogue ep) {
+// ---- B-operand policies: everything loop-invariant lives in State, a fetch is "uniform base + 32-bit offset"
+// rows of a [.., K, T] tensor through the Scale / ELU prologue
+template <class Cols, bool ELU>
+struct RowsB {
+  const float* x;
+  int T;
+  float in_scale;
+  Cols cols;
+  typedef f32x4 Raw;
+  struct State {
+    unsigned off[BP], off_last[BP];
+    float sc_last[BP];
+    bool ok;
+  };
+  __device__ State init(long ntile, int tid, int krem) const {
+    State s;
+    const LinCol lc = cols.at(ntile, (tid & 31) * 4);
+    s.ok = lc.ok;
+#pragma unroll
+    for (int h = 0; h < BP; ++h) {
+      const int r = (tid >> 5) + 8 * h;
+      const int rl = r < krem ? r : krem - 1;
+      s.off[h] = lc.ok ? (lc.off + (unsigned)r * (unsigned)T) * 4u : 0u;
+      s.off_last[h] = lc.ok ? (lc.off + (unsigned)rl * (unsigned)T) * 4u : 0u;
+      s.sc_last[h] = r < krem ? in_scale : 0.f;
+    }
+    return s;
+  }
+  __device__ Raw fetch(const State& s, int kt, bool last, int h) const {
+    const char* sb = reinterpret_cast<const char*>(x) + (size_t)kt * ((size_t)BK * (size_t)T * 4u);   // uniform
+    return *reinterpret_cast<const f32x4*>(sb + (last ? s.off_last[h] : s.off[h]));
+  }
+  __device__ f32x4 xform(const State& s, Raw v, bool last, int h) const {
+    if (Cols::kZeroInvalid) v = zero_unless(s.ok, v);
+    const float sc = last ? s.sc_last[h] : in_scale;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = v[e] * sc;
+      v[e] = ELU ? elu_fast(t) : t;
+    }
+    return v;
+  }
+};
+
+// Up-sampling front-end (see UpLoader in gemm.hip for the math): B = depthwise transposed conv (k = 2r, stride r)
+// of pro(x), computed from x[q-1], x[q], x[q+1] and the 2r taps of the channel.  R = 8 / 4: the four columns of a
+// group share one q (no selects); R = 2: columns map to q0,q0,q0+1,q0+1; R = 0: any stride, per-thread selects.
+template <int R, bool ELU, bool HIST>
+struct UpB {
+  const float* x;      // [B][K][Tin]
+  const float* w;      // [K][2r]
+  const float* hist;   // [B][K] activated x[-1] (HIST)
+  int K, Tin, r;
+  long ncols;          // B * Tin * r
+  float in_scale;
+  struct Raw {
+    f32x4 wa, wb;
+    float xm, x0, xp;
+  };
+  struct State {
+    unsigned xoff[BP], xoff_last[BP];   // byte offset of x[b][row][q0]
+    unsigned woff[BP], woff_last[BP];   // byte offset of w[row][p0]
+    unsigned hoff[BP], hoff_last[BP];   // byte offset of hist[b][row]
+    float sc_last[BP];
+    int p[4], dq[4];
+    bool ok, has_prev, has_next;
+  };
+  __device__ State init(long ntile, int tid, int krem) const {
+    State s;
+    const long n = ntile * BN + (tid & 31) * 4;
+    s.ok = n < ncols;
+    const long Tout = (long)Tin * r;
+    const long b = s.ok ? n / Tout : 0;
+    const int t = s.ok ? (int)(n - b * Tout) : 0;
+    const int q0 = t / r;
+    s.has_prev = s.ok && q0 >= 1;
+    s.has_next = s.ok && q0 + 1 < Tin;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = (t + e) / r;
+      s.p[e] = (t + e) - q * r;
+      s.dq[e] = q - q0;
+    }
+#pragma unroll
+    for (int h = 0; h < BP; ++h) {
+      const int rr = (tid >> 5) + 8 * h;
+      const int rl = rr < krem ? rr : krem - 1;
+      s.xoff[h] = (unsigned)((b * K + rr) * (long)Tin + q0) * 4u;
+      s.xoff_last[h] = (unsigned)((b * K + rl) * (long)Tin + q0) * 4u;
+      s.woff[h] = (unsigned)(rr * 2 * r + s.p[0]) * 4u;
+      s.woff_last[h] = (unsigned)(rl * 2 * r + s.p[0]) * 4u;
+      s.hoff[h] = (unsigned)(b * K + rr) * 4u;
+      s.hoff_last[h] = (unsigned)(b * K + rl) * 4u;
+      s.sc_last[h] = rr < krem ? 1.f : 0.f;
+    }
+    return s;
+  }
+  __device__ Raw fetch(const State& s, int kt, bool last, int h) const {
+    const char* sx = reinterpret_cast<const char*>(x) + (size_t)kt * ((size_t)BK * (size_t)Tin * 4u);   // uniform
+    const char* sw = reinterpret_cast<const char*>(w) + (size_t)kt * ((size_t)BK * 2u * (size_t)r * 4u);
+    const unsigned xo = last ? s.xoff_last[h] : s.xoff[h];
+    const unsigned wo = last ? s.woff_last[h] : s.woff[h];
+    Raw v;
+    if (R == 8 || R == 4) {
+      v.wa = *reinterpret_cast<const f32x4*>(sw + wo);
+      v.wb = *reinterpret_cast<const f32x4*>(sw + wo + R * 4);
+    } else if (R == 2) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + wo);     // p0 == 0: taps (w0,w1 | w2,w3)
+      v.wa = f32x4{t4.x, t4.y, t4.x, t4.y};
+      v.wb = f32x4{t4.z, t4.w, t4.z, t4.w};
+    } else {
+      const float* wr = reinterpret_cast<const float*>(sw + wo) - s.p[0];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v.wa[e] = wr[s.p[e]];
+        v.wb[e] = wr[s.p[e] + r];
+      }
+    }
+    const float* xp = reinterpret_cast<const float*>(sx + xo);
+    v.x0 = xp[0];
+    v.xp = xp[s.has_next ? 1 : 0];
+    if (HIST) {
+      const char* sh = reinterpret_cast<const char*>(hist) + (size_t)kt * ((size_t)BK * 4u);
+      const float* hp = reinterpret_cast<const float*>(sh + (last ? s.hoff_last[h] : s.hoff[h]));
+      v.xm = *(s.has_prev ? xp - 1 : hp);
+    } else {
+      v.xm = xp[s.has_prev ? -1 : 0];
+    }
+    return v;
+  }
+  __device__ float act(float v) const {
+    const float t = v * in_scale;
+    return ELU ? elu_fast(t) : t;
+  }
+  __device__ f32x4 xform(const State& s, const Raw& v, bool last, int h) const {
+    float a0 = s.has_prev ? act(v.xm) : (HIST && s.ok ? v.xm : 0.f);   // the cache holds activated samples
+    float a1 = s.ok ? act(v.x0) : 0.f;
+    float a2 = s.has_next ? act(v.xp) : 0.f;
+    if (last) { a0 *= s.sc_last[h]; a1 *= s.sc_last[h]; a2 *= s.sc_last[h]; }   // rows >= K contribute zero
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool nx = (R == 8 || R == 4) ? false : (R == 2) ? (e >= 2) : (s.dq[e] != 0);
+      const float cur = nx ? a2 : a1;
+      const float prev = nx ? a1 : a0;
+      o[e] = fmaf(v.wa[e], cur, v.wb[e] * prev);     // same expression as hilc_dw_convtr
+    }
+    return o;
+  }
+};
+
+template <int MB, class BOp, class Epilogue>
+__global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ wt, int M, int K, int ldw, long ntiles,
+                                                      int mtiles, BOp bop, Epilogue ep) {
   constexpr int BM = 32 * MB;
   constexpr int AG = BK * BM / 4;
   constexpr int AP = (AG + NT - 1) / NT;
@@ -78,7 +228,7 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
   const int ktiles = (K + BK - 1) / BK;
   const int krem = K - (ktiles - 1) * BK;          // rows of the last slice (1..BK)
 
-  // ---- loop-invariant per-thread byte offsets
+  // ---- loop-invariant per-thread byte offsets of the weight slice
   unsigned aoff[AP], aoff_last[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
@@ -90,19 +240,8 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
     aoff[p] = (unsigned)(kr * ldw + col) * 4u;
     aoff_last[p] = (unsigned)(krl * ldw + col) * 4u;
   }
-  const LinCol lc = cols.at(ntile, (tid & 31) * 4);
-  unsigned boff[BP], boff_last[BP];
-  float sc_last[BP];
-#pragma unroll
-  for (int h = 0; h < BP; ++h) {
-    const int r = (tid >> 5) + 8 * h;
-    const int rl = r < krem ? r : krem - 1;
-    boff[h] = lc.ok ? (lc.off + (unsigned)r * (unsigned)T) * 4u : 0u;
-    boff_last[h] = lc.ok ? (lc.off + (unsigned)rl * (unsigned)T) * 4u : 0u;
-    sc_last[h] = r < krem ? in_scale : 0.f;
-  }
   const unsigned a_slice = (unsigned)BK * (unsigned)ldw * 4u;   // bytes per K slice
-  const size_t b_slice = (size_t)BK * (size_t)T * 4u;
+  const typename BOp::State bs = bop.init(ntile, tid, krem);
 
   f32x16 acc[MB];
 #pragma unroll
@@ -110,14 +249,14 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  f32x4 ra[AP], rb[BP];
+  f32x4 ra[AP];
+  typename BOp::Raw rb[BP];
   auto fetch = [&](int kt, bool last) {
     const char* sa = reinterpret_cast<const char*>(wt) + (size_t)kt * a_slice;   // uniform
-    const char* sb = reinterpret_cast<const char*>(x) + (size_t)kt * b_slice;
 #pragma unroll
     for (int p = 0; p < AP; ++p) ra[p] = *reinterpret_cast<const f32x4*>(sa + (last ? aoff_last[p] : aoff[p]));
 #pragma unroll
-    for (int h = 0; h < BP; ++h) rb[h] = *reinterpret_cast<const f32x4*>(sb + (last ? boff_last[h] : boff[h]));
+    for (int h = 0; h < BP; ++h) rb[h] = bop.fetch(bs, kt, last, h);
   };
   auto stage = [&](int buf, bool last) {
 #pragma unroll
@@ -129,17 +268,8 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
       }
     }
 #pragma unroll
-    for (int h = 0; h < BP; ++h) {
-      f32x4 v = rb[h];
-      if (Cols::kZeroInvalid) v = zero_unless(lc.ok, v);
-      const float sc = last ? sc_last[h] : in_scale;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float s = v[e] * sc;
-        v[e] = ELU ? elu_fast(s) : s;
-      }
-      *reinterpret_cast<f32x4*>(&Bs[buf][(tid >> 5) + 8 * h][(tid & 31) * 4]) = v;
-    }
+    for (int h = 0; h < BP; ++h)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(tid >> 5) + 8 * h][(tid & 31) * 4]) = bop.xform(bs, rb[h], last, h);
   };
 
   const int kh = lane >> 5, l31 = lane & 31;
@@ -175,10 +305,8 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
   ep.template run<MB>(acc, smem, m0, ntile, wave, lane, tid);
 }
 
-// x must be 16-B aligned, T % 4 == 0, the tensor < 4 GiB (32-bit byte offsets); the caller checks.
-template <class Cols, class Epilogue>
-int launch_gemm_lin(const float* wt, const float* x, int M, int K, int ldw, int T, long ntiles, float in_scale,
-                    bool in_elu, const Cols& cols, const Epilogue& ep, hipStream_t s) {
+template <class BOp, class Epilogue>
+int launch_lin(const float* wt, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep, hipStream_t s) {
   int m32 = (M + 31) / 32;
   int MB;
   if (m32 % 4 == 0) MB = 4;
@@ -196,26 +324,28 @@ int launch_gemm_lin(const float* wt, const float* x, int M, int K, int ldw, int 
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   dim3 grid((unsigned)blocks), block(NT);
   HILC_CLEAR_ERROR();
-#define HILC_LIN(MBV, E) \
-  hipLaunchKernelGGL((gemm_lin_kernel<MBV, E, Cols, Epilogue>), grid, block, 0, s, wt, x, M, K, ldw, T, ntiles, mtiles, in_scale, cols, ep)
-  if (in_elu) {
-    switch (MB) {
-      case 1: HILC_LIN(1, true); break;
-      case 2: HILC_LIN(2, true); break;
-      case 3: HILC_LIN(3, true); break;
-      default: HILC_LIN(4, true); break;
-    }
-  } else {
-    switch (MB) {
-      case 1: HILC_LIN(1, false); break;
-      case 2: HILC_LIN(2, false); break;
-      case 3: HILC_LIN(3, false); break;
-      default: HILC_LIN(4, false); break;
-    }
+  switch (MB) {
+    case 1: hipLaunchKernelGGL((gemm_lin_kernel<1, BOp, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, bop, ep); break;
+    case 2: hipLaunchKernelGGL((gemm_lin_kernel<2, BOp, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, bop, ep); break;
+    case 3: hipLaunchKernelGGL((gemm_lin_kernel<3, BOp, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, bop, ep); break;
+    default: hipLaunchKernelGGL((gemm_lin_kernel<4, BOp, Epilogue>), grid, block, 0, s, wt, M, K, ldw, ntiles, mtiles, bop, ep); break;
   }
-#undef HILC_LIN
   HILC_CHECK_LAUNCH();
   return HILC_OK;
+}
+
+// x must be 16-B aligned, T % 4 == 0, the tensor < 4 GiB (32-bit byte offsets); the caller checks.
+template <class Cols, class Epilogue>
+int launch_gemm_lin(const float* wt, const float* x, int M, int K, int ldw, int T, long ntiles, float in_scale,
+                    bool in_elu, const Cols& cols, const Epilogue& ep, hipStream_t s) {
+  if (in_elu) {
+    RowsB<Cols, true> b;
+    b.x = x; b.T = T; b.in_scale = in_scale; b.cols = cols;
+    return launch_lin(wt, M, K, ldw, ntiles, b, ep, s);
+  }
+  RowsB<Cols, false> b;
+  b.x = x; b.T = T; b.in_scale = in_scale; b.cols = cols;
+  return launch_lin(wt, M, K, ldw, ntiles, b, ep, s);
 }
 
 }  // namespace hilc
