@@ -429,26 +429,46 @@ struct DwStrideEpilogue {
   int M, To, tiles, r, H, n_out;
   template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
 
-  template <int MB>
-  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
-    long b = ntile / tiles;
-    int tix = (int)(ntile - b * tiles);
-    int o0 = tix * n_out;
-    const int k = 2 * r;
+  // One wave = one row at a time (row = wave + 4*s is wave-uniform, so the 2r taps and the bias come through
+  // scalar loads), lane = output i of the tile (n_out <= 64): no index division, coalesced stores, taps unrolled
+  // for the strides the codec uses.
+  template <int MB, int KR>
+  __device__ void rows(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane) const {
+    const long b = ntile / tiles;
+    const int o0 = (int)(ntile - b * tiles) * n_out;
+    const int k = KR > 0 ? KR : 2 * r;
+    const int o = o0 + lane;
+    const bool live = lane < n_out && o < To;
 #pragma unroll
     for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
       const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
-      for (int idx = tid; idx < 32 * nblk * n_out; idx += NT) {
-        int row = idx / n_out, i = idx - row * n_out;
-        int m = m0 + ch * CH * 32 + row, o = o0 + i;
-        if (m >= M || o >= To) continue;
-        const float* h = smem + row * HS + (H - r) + i * r;
+      for (int s = 0; s < 8 * nblk; ++s) {
+        const int row = __builtin_amdgcn_readfirstlane(wave + 4 * s);
+        const int m = m0 + ch * CH * 32 + row;
+        if (m >= M) break;                      // uniform
         const float* w = dw_w + (long)m * k;
+        const float* h = smem + row * HS + (H - r) + (live ? lane : 0) * r;
         float a = 0.f;
-        for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+        if (KR > 0) {
+#pragma unroll
+          for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(w[j], h[j], a);
+        } else {
+          for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+        }
         if (dw_b) a = __fadd_rn(a, dw_b[m]);
-        y[(b * M + m) * (long)To + o] = a;
+        if (live) y[(b * M + m) * (long)To + o] = a;
       }
+    }
+  }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int) const {
+    switch (r) {                                 // uniform
+      case 2: rows<MB, 4>(acc, smem, m0, ntile, wave, lane); break;
+      case 4: rows<MB, 8>(acc, smem, m0, ntile, wave, lane); break;
+      case 5: rows<MB, 10>(acc, smem, m0, ntile, wave, lane); break;
+      case 8: rows<MB, 16>(acc, smem, m0, ntile, wave, lane); break;
+      default: rows<MB, 0>(acc, smem, m0, ntile, wave, lane); break;
     }
   }
 };
