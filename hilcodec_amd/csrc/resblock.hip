@@ -59,38 +59,66 @@ struct ResArgs {
 
 unsigned long long* g_dbg = nullptr;
 
+// Weight operands of one GEMM phase.  DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the
+// shadow of the MFMAs of slice kt; the first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise
+// phase that precedes the GEMM (P0 / P3), so that their L2 round trip (~2.5 k cycles, otherwise exposed at the
+// head of every GEMM phase) overlaps that phase.  C = 192 runs one workgroup per CU and gets two slices of lead.
+// The weight pointers go through an empty asm (LICM fence, see resblock_kernel) and come back without their
+// address space: loads through them would be FLAT instructions (LDS-or-global check, both wait counters).  This
+// type puts them back into the global address space -> global_load.
+typedef const __attribute__((address_space(1))) float* gptr_t;
+
+template <int C>
+struct WeightPipe {
+  static constexpr int CB = C / 32;
+  static constexpr int DEPTH = C >= 192 ? 3 : 2;
+  float a[DEPTH][8][CB];
+  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
+    gptr_t wl = (gptr_t)(wt + (long)(lane >> 5) * C + (lane & 31));   // this lane's A column: wt[(2j+kh)*C + 32i + l31]
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < CB; ++i) a[d][j][i] = wl[(long)(d * 16 + 2 * j) * C + 32 * i];
+  }
+};
+
 template <int C>
 __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[C / 32],
-                                           int wave, int lane) {
+                                           WeightPipe<C>& wp, int wave, int lane) {
   constexpr int CB = C / 32;
+  constexpr int DEPTH = WeightPipe<C>::DEPTH;
   const int kh = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int i = 0; i < CB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const float* wl = wt + (long)kh * C + l31;        // this lane's A column: wt[(2j+kh)*C + 32i + l31]
+  gptr_t wl = (gptr_t)(wt + (long)kh * C + l31);
   const float* xl = X + kh * XS + wave * 32 + l31;  // this lane's B column: X[(2j+kh)][32w + l31]
-  float a[2][8][CB], b[2][8];
-  auto load = [&](int slot, int kt) {
+  float b[DEPTH][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      b[slot][j] = xl[(kt * 16 + 2 * j) * XS];
+  for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
-      for (int i = 0; i < CB; ++i) a[slot][j][i] = wl[(long)(kt * 16 + 2 * j) * C + 32 * i];
-    }
-  };
-  load(0, 0);
+    for (int j = 0; j < 8; ++j) b[d][j] = xl[(d * 16 + 2 * j) * XS];
+  // Issue order, pinned: one weight load of slice kt+DEPTH-1 (and, once per k-pair, its LDS operand read) in the
+  // shadow of each MFMA of slice kt.  Left to itself hipcc sinks the loads next to their uses;
+  // sched_group_barrier lets the scheduler pick WHICH load fills a slot and it picks the consumer's own.
 #pragma unroll
   for (int kt = 0; kt < C / 16; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < C / 16) load(cur ^ 1, kt + 1);
-    __builtin_amdgcn_sched_barrier(0);   // keep the next slice's loads ahead of this slice's MFMAs
+    const int cur = kt % DEPTH, nxt = (kt + DEPTH - 1) % DEPTH;
+    const int kn = kt + DEPTH - 1;
+    const bool more = kn < C / 16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 8; ++j) {
+      if (more) b[nxt][j] = xl[(kn * 16 + 2 * j) * XS];
 #pragma unroll
-      for (int i = 0; i < CB; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < CB; ++i) {
+        if (more) wp.a[nxt][j][i] = wl[(long)(kn * 16 + 2 * j) * C + 32 * i];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 }
 
@@ -103,7 +131,7 @@ __device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[C / 32], float* X, 
 }
 
 template <int C, bool STREAM>
-__global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_kernel(ResArgs a) {
+__global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResArgs a) {
   constexpr int CB = C / 32;
   __shared__ __attribute__((aligned(16))) float X[C * XS];
   __shared__ float DW[C * DWS];
@@ -214,6 +242,8 @@ __global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_ke
       }
     }
   }
+  WeightPipe<C> wp;
+  wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
   // ---- P0: every row's 16-B load in flight at once, then the prologue
   {
     f32x4 v[RW];
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_ke
 
   f32x16 acc[CB];
   // ---- P1, P2
-  gemm_phase<C>(w1t, X, acc, wave, lane);
+  gemm_phase<C>(w1t, X, acc, wp, wave, lane);
   __syncthreads();
   STAMP(2);
   acc_to_x<C>(acc, X, wave, lane);
@@ -237,6 +267,7 @@ __global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_ke
   STAMP(3);
 
   // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place
+  wp.prefetch(w2t, lane);                  // GEMM2's first weight slices travel while P3 runs
   lane_columns();
 #pragma unroll 2
   for (int i = 0; i < RW; ++i) {
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(256, (STREAM && C == 128 ? 2 : 1)) void resblock_ke
   STAMP(4);
 
   // ---- P4
-  gemm_phase<C>(w2t, X, acc, wave, lane);
+  gemm_phase<C>(w2t, X, acc, wp, wave, lane);
   lane_columns();
   // shortcut samples for P6, PF rows at a time: the first chunk is issued here and lands under the
   // next two barriers, chunk n+1 is issued before chunk n is consumed
