@@ -28,6 +28,7 @@ SIGNATURES = {
     "hilc_resblock_supported": [_i, _i],
     "hilc_dws_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
+    "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

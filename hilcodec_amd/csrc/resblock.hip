@@ -54,6 +54,11 @@ struct ResArgs {
   const float* hist2;
   float* hist1_out;
   float* hist2_out;
+  // optional dynamic tile scheduler: two ints, zero at launch and zero again at exit.  The two workgroups that
+  // share a CU do not share it fairly (the older one wins issue arbitration: lifetimes 4.7 M vs 7.0 M cycles for
+  // the same 100 tiles at C = 96), so with static tile lists a third of the kernel runs at half occupancy; with
+  // tickets the faster workgroup simply takes more tiles.
+  int* sched;
   unsigned long long* dbg;   // optional [blocks][8] s_memtime stamps (tools/res_phase_times.py)
 };
 
@@ -156,9 +161,12 @@ __global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResAr
   // persistent: this workgroup walks tiles blockIdx.x, +gridDim.x, ... ; while tile i is in its second
   // GEMM the x rows of tile i+gridDim.x are touched so that its P0 finds them in this XCD's L2.
   float touch = 0.f;
-  for (long tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+  __shared__ long s_next;
+  long tile = blockIdx.x;
+  while (tile < a.total_tiles) {
   stamp_tile = tile;
   STAMP(0);
+  if (a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
   // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 8*i), lane = 4 adjacent
   // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
   // wave instruction, so the in-place update of P3 needs no barrier.
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResAr
   }
   __syncthreads();
   STAMP(1);
+  const long next = a.sched != nullptr ? s_next : tile + gridDim.x;
 
   f32x16 acc[CB];
   // ---- P1, P2
@@ -324,10 +333,10 @@ __global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResAr
   constexpr int NTOUCH = (C * 4 + 255) / 256;
   float tv[NTOUCH];
   {
-    const long nt = tile + gridDim.x < a.total_tiles ? tile + gridDim.x : tile;
+    const long nt = next < a.total_tiles ? next : tile;
     // (these loads also keep hipcc from hoisting P6's shortcut loads above the GEMM: without them, or with
     // per-lane clip indices here, the kernel needs ~130 more VGPRs)
-    const bool have = tile + gridDim.x < a.total_tiles;
+    const bool have = next < a.total_tiles;
     long nb;
     int nt0;
     if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
@@ -399,6 +408,13 @@ __global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResAr
   for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
   STAMP(7);
   __syncthreads();   // the next tile's P0 overwrites X
+  tile = next;
+  }
+  if (a.sched != nullptr && tid == 0) {          // last workgroup out re-arms the scheduler for the next launch
+    if (atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) {
+      a.sched[0] = 0;
+      a.sched[1] = 0;
+    }
   }
   if (touch == 1.2345678e-30f) a.y[0] = touch;   // keeps the touch loads alive; never true in practice
 #undef STAMP
@@ -442,7 +458,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
 namespace {
 int resblock_entry(bool streaming, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                    const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
-                   float* hist1_out, float* hist2_out, float* y, int B, int C, int T, float pre_scale,
+                   float* hist1_out, float* hist2_out, float* y, int* sched, int B, int C, int T, float pre_scale,
                    float out_scale, void* stream) {
   if (!x || !w1t || !dw1_w || !dw1_b || !w2t || !dw2_w || !dw2_b || !y) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
@@ -453,6 +469,7 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
   a.x = x; a.w1t = w1t; a.dw1_w = dw1_w; a.dw1_b = dw1_b; a.w2t = w2t; a.dw2_w = dw2_w; a.dw2_b = dw2_b;
   a.y = y; a.T = T; a.tiles = (T + TO - 1) / TO; a.pre_scale = pre_scale; a.out_scale = out_scale;
   a.hist1 = hist1; a.hist2 = hist2; a.hist1_out = hist1_out; a.hist2_out = hist2_out;
+  a.sched = sched;
   a.dbg = g_dbg;
   if (streaming) {
     if ((hist1 && hist1 == hist1_out) || (hist2 && hist2 == hist2_out)) return HILC_ERR_UNSUPPORTED;   // first / last tiles of a clip race
@@ -478,16 +495,25 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
 extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                              const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,
                              int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, B, C, T,
-                        pre_scale, out_scale, stream);
+  return resblock_entry(false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, nullptr,
+                        B, C, T, pre_scale, out_scale, stream);
 }
 
 extern "C" int hilc_resblock_stream(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                                     const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
                                     const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C,
                                     int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(true, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, B, C, T,
-                        pre_scale, out_scale, stream);
+  return resblock_entry(true, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, nullptr,
+                        B, C, T, pre_scale, out_scale, stream);
+}
+
+extern "C" int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                                      const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
+                                      const float* hist2, float* hist1_out, float* hist2_out, float* y, int* sched,
+                                      int streaming, int B, int C, int T, float pre_scale, float out_scale,
+                                      void* stream) {
+  return resblock_entry(streaming != 0, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y,
+                        sched, B, C, T, pre_scale, out_scale, stream);
 }
 
 extern "C" void hilc_debug_set_stamp_buffer(unsigned long long* p) { g_dbg = p; }

@@ -154,6 +154,20 @@ def resblock_supported(C: int, T: int) -> bool:
     return bool(lib.hilc_resblock_supported(C, T))
 
 
+_SCHED = {}
+
+
+def _sched_buffer(device) -> Tensor:
+    """Two zeroed ints per (device, stream) for the residual-block kernel's ticket scheduler; the kernel re-arms
+    them itself, so the buffer is written by the host only once."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCHED.get(key)
+    if buf is None:
+        buf = torch.zeros(2, dtype=torch.int32, device=device)
+        _SCHED[key] = buf
+    return buf
+
+
 def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, dw2_w: Tensor, dw2_b: Tensor,
              pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None):
     """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`.
@@ -162,17 +176,20 @@ def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, 
     y = torch.empty_like(x)
     if hist is None:
         with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
-            check(lib.hilc_resblock(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w), _ptr(dw2_b),
-                                    _ptr(y), B, Cc, T, pre_scale, out_scale, _stream()), "hilc_resblock")
+            check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
+                                             _ptr(dw2_b), None, None, None, None, _ptr(y),
+                                             _ptr(_sched_buffer(x.device), torch.int32), 0, B, Cc, T, pre_scale,
+                                             out_scale, _stream()), "hilc_resblock")
         return y
     h1, h2 = hist
     if tuple(h1.shape) != (B, Cc, 4) or tuple(h2.shape) != (B, Cc, 4):
         raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h1.shape)} / {tuple(h2.shape)}")
     o1, o2 = torch.empty_like(h1), torch.empty_like(h2)
     with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} stream"):
-        check(lib.hilc_resblock_stream(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
-                                       _ptr(dw2_b), _ptr(h1), _ptr(h2), _ptr(o1), _ptr(o2), _ptr(y), B, Cc, T,
-                                       pre_scale, out_scale, _stream()), "hilc_resblock_stream")
+        check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
+                                         _ptr(dw2_b), _ptr(h1), _ptr(h2), _ptr(o1), _ptr(o2), _ptr(y),
+                                         _ptr(_sched_buffer(x.device), torch.int32), 1, B, Cc, T, pre_scale,
+                                         out_scale, _stream()), "hilc_resblock_stream")
     return y, [o1, o2]
 
 

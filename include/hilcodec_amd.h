@@ -107,6 +107,17 @@ int hilc_resblock_stream(const float* x, const float* w1t, const float* dw1_w, c
                          const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C, int T,
                          float pre_scale, float out_scale, void* stream);
 
+/* Same kernels with a caller-owned dynamic tile scheduler: `sched` = two ints in device memory that are ZERO at
+ * launch; the kernel leaves them zero again (the last workgroup re-arms them), so one buffer per stream can be
+ * reused by every call on that stream.  Workgroups take tiles by ticket instead of from static lists — the
+ * workgroups that share a CU are not served equally, and static lists leave a third of the kernel at half
+ * occupancy.  streaming = 0: hilc_resblock semantics (hist* ignored and may be NULL); 1: hilc_resblock_stream.
+ * sched == NULL: static lists. */
+int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+                           const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
+                           const float* hist2, float* hist1_out, float* hist2_out, float* y, int* sched,
+                           int streaming, int B, int C, int T, float pre_scale, float out_scale, void* stream);
+
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)
  * y[b,c,o] = post((sum_j w[c][j] * xe[b,c,o*stride - pad + j] + bias[c]) * out_scale + res[b,c,o])
