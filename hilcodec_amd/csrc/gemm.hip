@@ -336,6 +336,62 @@ __device__ __forceinline__ int acc_chunk_to_lds(const f32x16 (&acc)[MB], float* 
   return nblk;
 }
 
+// Pointwise epilogue through LDS (T % 4 == 0, 16-B aligned y / res): the accumulator layout gives every lane 16
+// scattered rows of one column (64 dword stores + 64 dword residual loads per lane and tile); transposed through
+// LDS a thread owns 16 consecutive columns of one row: 4 x 16-B stores / loads.  Same arithmetic as PwEpilogue.
+struct PwLdsEpilogue {
+  float* y;
+  const float* bias;
+  const float* res;
+  int M, T;
+  long ncols;
+  unsigned t_magic, t_shift;   // n / T for n < 2^31
+  float out_scale;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int seg = tid + NT * s;
+        const int row = seg >> 3, c0 = (seg & 7) * 16;
+        const int m = m0 + ch * CH * 32 + row;
+        if (row >= nblk * 32 || m >= M) continue;
+        const float bv = bias != nullptr ? bias[m] : 0.f;
+        const long n0 = ntile * BN + c0;
+        unsigned b = __umulhi((unsigned)(n0 < ncols ? n0 : 0), t_magic) >> t_shift;
+        int t = (int)((n0 < ncols ? n0 : 0) - (long)b * T);
+        const float* hrow = smem + row * HS + c0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (n0 + 4 * g < ncols) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(hrow + 4 * g);
+            const long off = ((long)b * M + m) * (long)T + t;
+            // separate roundings, like the reference's `y.mul_(scale)` then `x.add_(y)` (no FMA contraction)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = v[e];
+              if (bias != nullptr) a = __fadd_rn(a, bv);
+              v[e] = __fmul_rn(a, out_scale);
+            }
+            if (res != nullptr) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], rr[e]);
+            }
+            *reinterpret_cast<f32x4*>(y + off) = v;
+          }
+          t += 4;
+          if (t >= T) { t = 0; ++b; }
+        }
+      }
+    }
+  }
+};
+
 // depthwise causal conv, k = 5, stride 1, on the GEMM tile: column c <-> time t0 + c, t0 = tix*124 - 4;
 // output column c >= 4 reads columns c-4..c.  Thread = (row, 16-column segment).
 struct Dw5Epilogue {
@@ -629,6 +685,15 @@ struct Dw5SegEpilogue {
 // the linear-addressing core (gemm_lin.h) uses 32-bit byte offsets into x
 static bool lin_ok(int B, int K, int T) { return (long)B * K * T * 4 < (1L << 32); }
 
+// n / d for n < 2^31 as __umulhi(n, magic) >> shift (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l)/d); d >= 2
+static void div_magic(int d, unsigned& m, unsigned& sh) {
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  if (l < 1) l = 1;
+  m = (unsigned)(((1ULL << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+  sh = (unsigned)(l - 1);
+}
+
 extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
                             int B, int K, int M, int T, float in_scale, int in_elu, float out_scale,
                             void* stream) {
@@ -644,6 +709,12 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   if (ld.vec && lin_ok(B, K, T)) {
     FlatCols cols;
     cols.K = K; cols.T = T; cols.tile_cols = BN; cols.ncols = ncols;
+    if (ncols < (1L << 31) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0) {
+      PwLdsEpilogue el;
+      el.y = y; el.bias = bias; el.res = res; el.M = M; el.T = T; el.ncols = ncols; el.out_scale = out_scale;
+      div_magic(T, el.t_magic, el.t_shift);
+      return launch_gemm_lin(wt, x, M, K, M, T, (ncols + BN - 1) / BN, in_scale, in_elu != 0, cols, el, (hipStream_t)stream);
+    }
     return launch_gemm_lin(wt, x, M, K, M, T, (ncols + BN - 1) / BN, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
   }
   return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
@@ -684,9 +755,14 @@ extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* his
     return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
   };
   if (lin_ok(B, K, Tin)) {   // linear-addressing core (gemm_lin.h): same arithmetic, far fewer VALU per K slice
+    const bool lds_epi = ncols < (1L << 31) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    PwLdsEpilogue el;
+    el.y = y; el.bias = bias; el.res = nullptr; el.M = M; el.T = (int)Tout; el.ncols = ncols; el.out_scale = 1.0f;
+    div_magic((int)Tout, el.t_magic, el.t_shift);
     auto lin = [&](auto bop) {
       bop.x = x; bop.w = tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
       bop.in_scale = in_scale;
+      if (lds_epi) return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, el, (hipStream_t)stream);
       return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, ep, (hipStream_t)stream);
     };
     const int rsel = !w_aligned ? 0 : stride == 8 ? 8 : stride == 4 ? 4 : stride == 2 ? 2 : 0;
