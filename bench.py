@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="streaming mode: replay each hop as one HIP graph "
+                    "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--cpu-clips", type=int, default=16)
     a = ap.parse_args()
     if a.mode == "offline":
@@ -135,6 +137,14 @@ def main():
             wav, state["cd"] = model.decoder(q, *state["cd"])
             return idx, wav
 
+        if args.graph:
+            from hilcodec_amd.graph_step import GraphedHop
+            hopper = GraphedHop(model, hi - lo, hop, nq, dev)
+            args.no_launch_timing = True
+
+            def step(i):                                   # noqa: F811
+                return hopper.step(xs[i % nbuf])
+
     with torch.no_grad():
         for i in range(args.warmup):
             idx, wav = step(i)
@@ -165,7 +175,7 @@ def main():
                         f"(BASELINE configs[{cfg_ix}])")
         else:
             workload = (f"{name} streaming, hop=320, {B} concurrent streams per GPU, Nq={nq}, 22+30 caches per stream "
-                        f"resident in HBM (BASELINE configs[{cfg_ix}])")
+                        f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else ""))
         out = {
             "metric": "audio-seconds/sec (xRT) encode+RVQ+decode, 24 kHz batch=256",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,

@@ -178,3 +178,36 @@ def test_stream_driver_protocol(tmp_path):
     SD.write_wav(wav_path, w1[0, 0].cpu().numpy(), 24000)
     back = SD.read_wav(wav_path, 24000)
     assert back.shape == (4800,) and np.abs(back - w1[0, 0].cpu().numpy()).max() < 1.0 / 32767 + 1e-6
+
+
+def test_graphed_hop_equals_eager():
+    """One HIP-graph replay per hop (hilcodec_amd/graph_step.py) against the eager loop: bit-identical indices, wav
+    and caches over several hops, after a reset, and resumed from saved caches."""
+    from hilcodec_amd.graph_step import GraphedHop
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming()
+    B, hops = 5, 4
+    x = synth.synth_clips(B, 320 * hops, seed=77).to(dev)
+    ce, cd = model.initialize_cache(x)
+    eager = []
+    mid = None
+    with torch.no_grad():
+        for h in range(hops):
+            z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)].contiguous(), *ce)
+            idx = model.quantizer(z, 8)
+            wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+            eager.append((idx.clone(), wav.clone()))
+            if h == 1:
+                mid = ([c.clone() for c in ce], [c.clone() for c in cd])
+    g = GraphedHop(model, B, 320, 8, dev)
+    for rep in range(2):                       # second pass after reset(): the graph carries no hidden state
+        for h in range(hops):
+            idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])
+            assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1]), f"pass {rep} hop {h}"
+        for a, b in zip(g.cache_enc + g.cache_dec, list(ce) + list(cd)):
+            assert torch.equal(a, b)
+        g.reset()
+    g.reset(*mid)                               # resume after hop 1
+    for h in (2, 3):
+        idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])
+        assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1])
