@@ -24,10 +24,6 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
     }                                                         \
   } while (0)
 
-// ELU(alpha=1) exactly as the reference computes it on CPU: x > 0 ? x : expm1(x)
-// (torch's CPU ELU is bit-identical to expm1, SURVEY.md §7 "Transcendentals").
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
-
 // Hot-path ELU: x > 0 ? x : 2^(x*log2 e) - 1 with the hardware v_exp_f32 (1 ulp).  5 VALU instead of
 // ~32 + a divergent branch for expm1f.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1,
 // i.e. one fp32 ulp of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on
