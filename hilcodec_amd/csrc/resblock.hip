@@ -73,19 +73,28 @@ unsigned long long* g_dbg = nullptr;
 // type puts them back into the global address space -> global_load.
 typedef const __attribute__((address_space(1))) float* gptr_t;
 
+// Packed ("MFMA lane order") weights, produced by hilc_resblock_pack_weights from the k-major [K][C] matrix:
+//   packed[((kt * 2*CB + q) * 64 + lane) * 4 + e] = W[kt*16 + 2j + (lane >> 5)][32i + (lane & 31)],  q*4 + e = j*CB + i
+// i.e. the 8*CB operands a lane feeds to the MFMAs of K slice kt sit in 2*CB consecutive 16-B words per lane and a
+// wave's 64 lanes read 1 KiB contiguous per load: 2*CB vector loads per slice instead of 8*CB dword loads (every
+// VMEM instruction in these loops costs ~16 cycles of MFMA issue; +4-6 % at C <= 128).
 template <int C>
 struct WeightPipe {
   static constexpr int CB = C / 32;
   static constexpr int DEPTH = C >= 192 ? 3 : 2;
+  static constexpr int NQ = 2 * CB;            // 16-B words per lane and slice
   float a[DEPTH][8][CB];
+  __device__ __forceinline__ void load_word(gptr_t wp, int slot, int kt, int q, int lane) {
+    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+    const f32x4 v = *(gvec_t)(wp + ((long)(kt * NQ + q) * 64 + lane) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CB][(q * 4 + e) % CB] = v[e];
+  }
   __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
-    gptr_t wl = (gptr_t)(wt + (long)(lane >> 5) * C + (lane & 31));   // this lane's A column: wt[(2j+kh)*C + 32i + l31]
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < CB; ++i) a[d][j][i] = wl[(long)(d * 16 + 2 * j) * C + 32 * i];
+      for (int q = 0; q < NQ; ++q) load_word((gptr_t)wt, d, d, q, lane);
   }
 };
 
@@ -99,16 +108,15 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
   for (int i = 0; i < CB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  gptr_t wl = (gptr_t)(wt + (long)kh * C + l31);
   const float* xl = X + kh * XS + wave * 32 + l31;  // this lane's B column: X[(2j+kh)][32w + l31]
   float b[DEPTH][8];
 #pragma unroll
   for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[d][j] = xl[(d * 16 + 2 * j) * XS];
-  // Issue order, pinned: one weight load of slice kt+DEPTH-1 (and, once per k-pair, its LDS operand read) in the
-  // shadow of each MFMA of slice kt.  Left to itself hipcc sinks the loads next to their uses;
-  // sched_group_barrier lets the scheduler pick WHICH load fills a slot and it picks the consumer's own.
+  // Issue order, pinned: the 2*CB weight words of slice kt+DEPTH-1 are spread over the 8*CB MFMAs of slice kt (one
+  // every fourth MFMA), its LDS operand reads one per k-pair.  Left to itself hipcc sinks the loads next to their
+  // uses; sched_group_barrier lets the scheduler pick WHICH load fills a slot and it picks the consumer's own.
 #pragma unroll
   for (int kt = 0; kt < C / 16; ++kt) {
     const int cur = kt % DEPTH, nxt = (kt + DEPTH - 1) % DEPTH;
@@ -119,12 +127,24 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
       if (more) b[nxt][j] = xl[(kn * 16 + 2 * j) * XS];
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
-        if (more) wp.a[nxt][j][i] = wl[(long)(kn * 16 + 2 * j) * C + 32 * i];
+        const int n = j * CB + i;                    // MFMA index inside the slice
+        if (more && n % 4 == 0) wp.load_word((gptr_t)wt, nxt, kn, n / 4, lane);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed`
+  if (idx >= C * C) return;
+  const int CB = C / 32, NQ = 2 * CB;
+  const int e = idx & 3, lane = (idx >> 2) & 63, w = idx >> 8;
+  const int q = w % NQ, kt = w / NQ;
+  const int v = q * 4 + e, j = v / CB, i = v % CB;
+  const int k = kt * 16 + 2 * j + (lane >> 5), m = 32 * i + (lane & 31);
+  packed[idx] = wt[(long)k * C + m];
 }
 
 template <int C>
@@ -491,6 +511,16 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
   }
 }
 }  // namespace
+
+extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C, void* stream) {
+  if (!wt || !packed) return HILC_ERR_NULL;
+  if (!(C == 64 || C == 96 || C == 128 || C == 192)) return HILC_ERR_UNSUPPORTED;
+  if (wt == packed) return HILC_ERR_UNSUPPORTED;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, packed, C);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
 
 extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                              const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,

@@ -155,6 +155,25 @@ def resblock_supported(C: int, T: int) -> bool:
 
 
 _SCHED = {}
+_PACKED = {}
+
+
+def resblock_pack(wt: Tensor) -> Tensor:
+    """k-major `[C,C]` pointwise weights -> the fused block's packed layout (hilc_resblock_pack_weights), cached per
+    weight tensor (same storage and version => same packed copy)."""
+    key = (wt.data_ptr(), wt._version, tuple(wt.shape), wt.device.index)
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0]() is wt:
+        return hit[1]
+    Cc = wt.shape[0]
+    out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
+    check(lib.hilc_resblock_pack_weights(_ptr(wt), _ptr(out), Cc, _stream()), "hilc_resblock_pack_weights")
+    if len(_PACKED) > 256:
+        _PACKED.clear()
+    import weakref
+    _PACKED[key] = (weakref.ref(wt), out)
+    return out
+
 
 
 def _sched_buffer(device) -> Tensor:
@@ -174,6 +193,7 @@ def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, 
     Streaming: hist = (cache of depthwise 1, cache of depthwise 2), each `[B,C,4]` -> (y, [new caches])."""
     B, Cc, T = x.shape
     y = torch.empty_like(x)
+    w1t, w2t = resblock_pack(w1t), resblock_pack(w2t)
     if hist is None:
         with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
             check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),

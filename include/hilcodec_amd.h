@@ -90,13 +90,20 @@ int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, con
 /* ---- fully fused residual block (narrow, long layers: C in {64, 96, 128, 192}, T % 4 == 0) --------
  * y = x + out_scale * (dw2(pw2(ELU(dw1(pw1(ELU(pre_scale * x))) + dw1_b))) + dw2_b)
  * One HBM read of x and one write of y per block; both pointwise outputs and the mid activation
- * stay in LDS.  w1t / w2t are `[C][C]` k-major, dw*_w `[C][5]`.  y must not alias x.
+ * stay in LDS.  w1t / w2t are the two `[C][C]` pointwise matrices in the PACKED layout written by
+ * hilc_resblock_pack_weights (below), dw*_w `[C][5]`.  y must not alias x.
  * Replaces: SEANetResnetBlock.forward (`seanet.py:129-148`) with skip='identity', kernel 5.
  * hilc_resblock_supported(C, T) tells the caller whether this specialisation exists. */
 int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b, const float* w2t,
                   const float* dw2_w, const float* dw2_b, float* y, int B, int C, int T, float pre_scale,
                   float out_scale, void* stream);
 int hilc_resblock_supported(int C, int T);
+
+/* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv
+ * takes) into "MFMA lane order": the operands one lane feeds to the matrix pipe for a 16-deep K slice become
+ * consecutive 16-B words, so the fused block streams its weights with a quarter of the load instructions.
+ * packed: `C*C` floats, must not alias wt.  C in {64, 96, 128, 192}. */
+int hilc_resblock_pack_weights(const float* wt, float* packed, int C, void* stream);
 
 /* Streaming form of the same block (`streaming.py:195-276` ResBlock with two DWSBlock caches,
  * `causal_layers.py:147-167`): hist1 / hist2 `[B][C][4]` = the last 4 samples of the two depthwise convs'
