@@ -28,6 +28,8 @@ SIGNATURES = {
     "hilc_resblock_supported": [_i, _i],
     "hilc_resblock_pack_weights": [_p, _p, _i, _p],
     "hilc_dws_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
+    "hilc_up_conv_expand_taps": [_p, _p, _i, _i, _p],
+    "hilc_up_conv_expanded": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],

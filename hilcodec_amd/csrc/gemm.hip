@@ -729,9 +729,30 @@ __global__ __launch_bounds__(256) void up_hist_kernel(const float* x, float* his
 }
 }  // namespace
 
-extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* hist_out, const float* tr_w,
-                                   const float* wt, const float* bias, float* y, int B, int K, int M, int Tin,
-                                   int stride, float in_scale, int in_elu, void* stream) {
+namespace {
+// expanded[k][p0][e] = w[k][(p0+e) mod r], expanded[k][p0][4+e] = w[k][(p0+e) mod r + r]   (e < 4)
+__global__ __launch_bounds__(256) void expand_taps_kernel(const float* w, float* out, int K, int r) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= K * r * 8) return;
+  const int e = idx & 3, hi = (idx >> 2) & 1, p0 = (idx >> 3) % r, k = (idx >> 3) / r;
+  out[idx] = w[(long)k * 2 * r + (p0 + e) % r + hi * r];
+}
+}  // namespace
+
+extern "C" int hilc_up_conv_expand_taps(const float* tr_w, float* expanded, int K, int stride, void* stream) {
+  if (!tr_w || !expanded) return HILC_ERR_NULL;
+  if (K <= 0 || stride <= 0) return HILC_ERR_SHAPE;
+  if (tr_w == expanded) return HILC_ERR_UNSUPPORTED;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(expand_taps_kernel, dim3((unsigned)((K * stride * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     tr_w, expanded, K, stride);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+static int up_conv_entry(const float* x, const float* hist, float* hist_out, const float* tr_w, const float* tr_w_expanded,
+                         const float* wt, const float* bias, float* y, int B, int K, int M, int Tin, int stride,
+                         float in_scale, int in_elu, void* stream) {
   if (!x || !tr_w || !wt || !y) return HILC_ERR_NULL;
   if (B <= 0 || K <= 0 || M <= 0 || Tin <= 0 || stride <= 0) return HILC_ERR_SHAPE;
   if (M % 4 != 0 || ((long)Tin * stride) % 4 != 0) return HILC_ERR_UNSUPPORTED;
@@ -760,7 +781,7 @@ extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* his
     el.y = y; el.bias = bias; el.res = nullptr; el.M = M; el.T = (int)Tout; el.ncols = ncols; el.out_scale = 1.0f;
     div_magic((int)Tout, el.t_magic, el.t_shift);
     auto lin = [&](auto bop) {
-      bop.x = x; bop.w = tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
+      bop.x = x; bop.w = decltype(bop)::kExpanded ? tr_w_expanded : tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
       bop.in_scale = in_scale;
       if (lds_epi) return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, el, (hipStream_t)stream);
       return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, ep, (hipStream_t)stream);
@@ -774,6 +795,7 @@ extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* his
     if (rsel == 8) HILC_UP(8);
     if (rsel == 4) HILC_UP(4);
     if (rsel == 2) HILC_UP(2);
+    if (tr_w_expanded != nullptr && (reinterpret_cast<uintptr_t>(tr_w_expanded) & 15) == 0) HILC_UP(1);
     HILC_UP(0);
 #undef HILC_UP
   }
@@ -789,9 +811,21 @@ extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* his
   return go(UpLoader<0>{});
 }
 
+extern "C" int hilc_up_conv_stream(const float* x, const float* hist, float* hist_out, const float* tr_w,
+                                   const float* wt, const float* bias, float* y, int B, int K, int M, int Tin,
+                                   int stride, float in_scale, int in_elu, void* stream) {
+  return up_conv_entry(x, hist, hist_out, tr_w, nullptr, wt, bias, y, B, K, M, Tin, stride, in_scale, in_elu, stream);
+}
+
+extern "C" int hilc_up_conv_expanded(const float* x, const float* hist, float* hist_out, const float* tr_w,
+                                     const float* tr_w_expanded, const float* wt, const float* bias, float* y, int B,
+                                     int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream) {
+  return up_conv_entry(x, hist, hist_out, tr_w, tr_w_expanded, wt, bias, y, B, K, M, Tin, stride, in_scale, in_elu, stream);
+}
+
 extern "C" int hilc_up_conv(const float* x, const float* tr_w, const float* wt, const float* bias, float* y,
                             int B, int K, int M, int Tin, int stride, float in_scale, int in_elu, void* stream) {
-  return hilc_up_conv_stream(x, nullptr, nullptr, tr_w, wt, bias, y, B, K, M, Tin, stride, in_scale, in_elu, stream);
+  return up_conv_entry(x, nullptr, nullptr, tr_w, nullptr, wt, bias, y, B, K, M, Tin, stride, in_scale, in_elu, stream);
 }
 
 extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b,

@@ -96,12 +96,16 @@ struct RowsB {
 
 // Up-sampling front-end (see UpLoader in gemm.hip for the math): B = depthwise transposed conv (k = 2r, stride r)
 // of pro(x), computed from x[q-1], x[q], x[q+1] and the 2r taps of the channel.  R = 8 / 4: the four columns of a
-// group share one q (no selects); R = 2: columns map to q0,q0,q0+1,q0+1; R = 0: any stride, per-thread selects.
+// group share one q (no selects); R = 2: columns map to q0,q0,q0+1,q0+1; R = 0: any stride, per-thread selects and
+// eight scalar tap loads per row; R = 1: any stride with the EXPANDED tap table of hilc_up_conv_expand_taps
+// (`[K][r][8]`: for each phase p0 = t mod r of a 4-column group its eight taps as two 16-B words) — two vector loads
+// per row like R = 8 / 4 (every VMEM instruction in this loop costs ~16 cycles of MFMA issue).
 template <int R, bool ELU, bool HIST>
 struct UpB {
   const float* x;      // [B][K][Tin]
-  const float* w;      // [K][2r]
+  const float* w;      // [K][2r], or [K][r][8] for R == 1
   const float* hist;   // [B][K] activated x[-1] (HIST)
+  static constexpr bool kExpanded = R == 1;
   int K, Tin, r;
   long ncols;          // B * Tin * r
   float in_scale;
@@ -139,8 +143,8 @@ struct UpB {
       const int rl = rr < krem ? rr : krem - 1;
       s.xoff[h] = (unsigned)((b * K + rr) * (long)Tin + q0) * 4u;
       s.xoff_last[h] = (unsigned)((b * K + rl) * (long)Tin + q0) * 4u;
-      s.woff[h] = (unsigned)(rr * 2 * r + s.p[0]) * 4u;
-      s.woff_last[h] = (unsigned)(rl * 2 * r + s.p[0]) * 4u;
+      s.woff[h] = R == 1 ? (unsigned)((rr * r + s.p[0]) * 8) * 4u : (unsigned)(rr * 2 * r + s.p[0]) * 4u;
+      s.woff_last[h] = R == 1 ? (unsigned)((rl * r + s.p[0]) * 8) * 4u : (unsigned)(rl * 2 * r + s.p[0]) * 4u;
       s.hoff[h] = (unsigned)(b * K + rr) * 4u;
       s.hoff_last[h] = (unsigned)(b * K + rl) * 4u;
       s.sc_last[h] = rr < krem ? 1.f : 0.f;
@@ -149,13 +153,16 @@ struct UpB {
   }
   __device__ Raw fetch(const State& s, int kt, bool last, int h) const {
     const char* sx = reinterpret_cast<const char*>(x) + (size_t)kt * ((size_t)BK * (size_t)Tin * 4u);   // uniform
-    const char* sw = reinterpret_cast<const char*>(w) + (size_t)kt * ((size_t)BK * 2u * (size_t)r * 4u);
+    const char* sw = reinterpret_cast<const char*>(w) + (size_t)kt * ((size_t)BK * (R == 1 ? 8u : 2u) * (size_t)r * 4u);
     const unsigned xo = last ? s.xoff_last[h] : s.xoff[h];
     const unsigned wo = last ? s.woff_last[h] : s.woff[h];
     Raw v;
     if (R == 8 || R == 4) {
       v.wa = *reinterpret_cast<const f32x4*>(sw + wo);
       v.wb = *reinterpret_cast<const f32x4*>(sw + wo + R * 4);
+    } else if (R == 1) {
+      v.wa = *reinterpret_cast<const f32x4*>(sw + wo);
+      v.wb = *reinterpret_cast<const f32x4*>(sw + wo + 16);
     } else if (R == 2) {
       const f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + wo);     // p0 == 0: taps (w0,w1 | w2,w3)
       v.wa = f32x4{t4.x, t4.y, t4.x, t4.y};
@@ -237,8 +244,10 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
     int col = m0 + m4;
     col = col < ldw - 4 ? col : ldw - 4;           // rows >= M only feed accumulator rows that are never stored
     const int krl = kr < krem ? kr : krem - 1;
-    aoff[p] = (unsigned)(kr * ldw + col) * 4u;
-    aoff_last[p] = (unsigned)(krl * ldw + col) * 4u;
+    // threads beyond the slice (AG < NT, i.e. MB = 1 or 3) load nothing they keep: point them at row 0 of the slice,
+    // their natural row index would run up to 16 rows past it (past the end of the matrix at the last slices)
+    aoff[p] = g < AG ? (unsigned)(kr * ldw + col) * 4u : 0u;
+    aoff_last[p] = g < AG ? (unsigned)(krl * ldw + col) * 4u : 0u;
   }
   const unsigned a_slice = (unsigned)BK * (unsigned)ldw * 4u;   // bytes per K slice
   const typename BOp::State bs = bop.init(ntile, tid, krem);

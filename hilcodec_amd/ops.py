@@ -128,6 +128,27 @@ def dws_conv_stream(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor],
     return y, hout
 
 
+_TAPS = {}
+
+
+def up_conv_taps(tr_w: Tensor, stride: int) -> Optional[Tensor]:
+    """Expanded tap table for strides without a vector tap path (hilc_up_conv_expand_taps), cached per weight tensor."""
+    if stride in (2, 4, 8):
+        return None
+    key = (tr_w.data_ptr(), tr_w._version, tuple(tr_w.shape), tr_w.device.index)
+    hit = _TAPS.get(key)
+    if hit is not None and hit[0]() is tr_w:
+        return hit[1]
+    K = tr_w.shape[0]
+    out = torch.empty(K * stride * 8, device=tr_w.device, dtype=torch.float32)
+    check(lib.hilc_up_conv_expand_taps(_ptr(tr_w), _ptr(out), K, stride, _stream()), "hilc_up_conv_expand_taps")
+    if len(_TAPS) > 64:
+        _TAPS.clear()
+    import weakref
+    _TAPS[key] = (weakref.ref(tr_w), out)
+    return out
+
+
 def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
             in_elu: bool = True, hist: Optional[Tensor] = None, want_hist: bool = False):
     """Fused [Scale, ELU, depthwise transposed conv (k=2*stride), pointwise conv + bias]:
@@ -136,17 +157,19 @@ def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride:
     B, K, Tin = x.shape
     M = wt.shape[1]
     y = torch.empty(B, M, Tin * stride, device=x.device, dtype=torch.float32)
+    taps = up_conv_taps(tr_w, stride)
     if hist is None and not want_hist:
         with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride}"):
-            check(lib.hilc_up_conv(_ptr(x), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y), B, K, M, Tin, stride,
-                                   in_scale, int(in_elu), _stream()), "hilc_up_conv")
+            check(lib.hilc_up_conv_expanded(_ptr(x), None, None, _ptr(tr_w), _ptr(taps), _ptr(wt), _ptr(bias), _ptr(y),
+                                            B, K, M, Tin, stride, in_scale, int(in_elu), _stream()), "hilc_up_conv")
         return y
     if hist is not None and hist.numel() != B * K:
         raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(hist.shape)}")
     hout = torch.empty(B, K, 1, device=x.device, dtype=torch.float32) if want_hist else None
     with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride} stream"):
-        check(lib.hilc_up_conv_stream(_ptr(x), _ptr(hist), _ptr(hout), _ptr(tr_w), _ptr(wt), _ptr(bias), _ptr(y),
-                                      B, K, M, Tin, stride, in_scale, int(in_elu), _stream()), "hilc_up_conv_stream")
+        check(lib.hilc_up_conv_expanded(_ptr(x), _ptr(hist), _ptr(hout), _ptr(tr_w), _ptr(taps), _ptr(wt), _ptr(bias),
+                                        _ptr(y), B, K, M, Tin, stride, in_scale, int(in_elu), _stream()),
+              "hilc_up_conv_stream")
     return (y, hout) if want_hist else y
 
 

@@ -79,6 +79,15 @@ int hilc_up_conv_stream(const float* x, const float* hist, float* hist_out, cons
                         const float* bias, float* y, int B, int K, int M, int Tin, int stride, float in_scale,
                         int in_elu, void* stream);
 
+/* Strides other than 2 / 4 / 8 (the codec's 5): with `tr_w_expanded` = the table written by hilc_up_conv_expand_taps
+ * (`[K][stride][8]` floats, 16-B aligned: for each phase p0 = t mod stride of a 4-column group its eight taps as two
+ * 16-B words) the loader issues two vector tap loads per row instead of eight scalar ones.  hist / hist_out /
+ * tr_w_expanded may be NULL (then this is hilc_up_conv_stream). */
+int hilc_up_conv_expand_taps(const float* tr_w, float* expanded, int K, int stride, void* stream);
+int hilc_up_conv_expanded(const float* x, const float* hist, float* hist_out, const float* tr_w,
+                          const float* tr_w_expanded, const float* wt, const float* bias, float* y, int B, int K,
+                          int M, int Tin, int stride, float in_scale, int in_elu, void* stream);
+
 /* Streaming hop of hilc_dws_conv for the wide layers (DWSBlock.forward `streaming.py:160-192`, CausalConv1d
  * `causal_layers.py:147-165`): T <= 128 samples per stream and call, T % stride == 0, any ksize >= stride.
  * hist `[B][M][ksize-stride]` = the last pointwise outputs of the previous hop (NULL = zeros), hist_out receives
