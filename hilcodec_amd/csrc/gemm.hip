@@ -315,6 +315,39 @@ struct StftEpilogue {
   }
 };
 
+// the same for per-clip column tiles (tile = frames [128*tix, +128) of clip b), used with StftSegB
+struct StftClipEpilogue {
+  float* spec;
+  int nbins, Tf, tiles;
+  float mean, stdv;
+  int normalize;
+  template <int MB> static constexpr int lds_floats() { return 0; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    const long b = ntile / tiles;
+    const int f = (int)(ntile - b * tiles) * BN + wave * 32 + (lane & 31);
+    if (f >= Tf) return;
+    const long colbase = b * (long)nbins * Tf + f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = m0 + i * 32 + acc_row(r, lane);
+        const int bin = row >> 1;
+        if (bin < nbins) {
+          const float re = acc[i][r], im = acc[i][r + 1];
+          const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // conv.py:357, no FMA contraction
+          float v = sqrtf(fmaxf(p, 1e-12f));
+          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
+          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
+          spec[colbase + (long)bin * Tf] = v;
+        }
+      }
+    }
+  }
+};
+
 constexpr int HS = 132;  // LDS row stride of the post-GEMM tile: 128 columns + 4, keeps float4 alignment
 
 constexpr int CH = 2;    // the post-GEMM tile goes through LDS in chunks of CH 32-row blocks (33 KB)
@@ -935,5 +968,20 @@ extern "C" int hilc_stft_logmag(const float* wav, const float* hist, int hist_le
   StftEpilogue ep;
   ep.spec = spec; ep.nbins = n_fft / 2 + 1; ep.Tf = Tf; ep.ncols = ncols; ep.mean = mean; ep.stdv = stdv;
   ep.normalize = normalize;
+  // offline, long clips: per-clip tiles whose waveform segment is staged once in LDS (gemm_lin.h, StftSegB)
+  const int seg_len = ((BN - 1) * hop + n_fft) * 17 / 16 + 1;   // with one pad word per 16 samples
+  if (hist == nullptr && n_fft % BK == 0 && Tf >= 4 * BN && seg_len <= 6144) {
+    const int tiles = (Tf + BN - 1) / BN;
+    StftClipEpilogue ec;
+    ec.spec = spec; ec.nbins = n_fft / 2 + 1; ec.Tf = Tf; ec.tiles = tiles; ec.mean = mean; ec.stdv = stdv;
+    ec.normalize = normalize;
+    auto go = [&](auto bop) {
+      bop.wav = wav; bop.T = T; bop.Tf = Tf; bop.n_fft = n_fft; bop.hop = hop; bop.tiles = tiles;
+      return launch_lin(basis_t, M, n_fft, m_pad, (long)B * tiles, bop, ec, (hipStream_t)stream);
+    };
+    if (seg_len <= 512) return go(StftSegB<512>{});
+    if (seg_len <= 1536) return go(StftSegB<1536>{});
+    return go(StftSegB<6144>{});
+  }
   return launch_gemm(basis_t, M, n_fft, m_pad, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }

@@ -208,6 +208,56 @@ struct UpB {
   }
 };
 
+// Implicit im2col of the waveform for the causal STFT-as-GEMM (offline form, zero history).  Column = frame f of one
+// clip (per-clip tiles of 128 frames), row k = sample k of the window, element = wav[b, f*hop - (n_fft-1) + k].
+// The 127*hop + n_fft samples a tile touches are staged ONCE into LDS (zero outside [0, T)); a B element is then
+// an LDS read at a loop-invariant offset + 16*kt — no per-element address arithmetic, no guards, and LDS reads
+// instead of 8 scalar global loads per slice (a VMEM instruction costs ~16 cycles of MFMA issue here).
+// Lanes read at a stride of 4*hop samples, so the segment is stored with one pad word per 16 samples
+// (index u -> u + (u >> 4)): at most 2-way bank conflicts for every hop of the codec, and a K slice (16 samples) is
+// still a constant step (17 words).  n_fft % 16 == 0;  SEG >= (127*hop + n_fft) * 17 / 16.
+template <int SEG>
+struct StftSegB {
+  const float* wav;
+  int T, Tf, n_fft, hop, tiles;   // tiles per clip = ceil(Tf / 128)
+  typedef f32x4 Raw;
+  struct State {
+    const float* seg;
+    int off[4][BP];
+  };
+  __device__ State init(long ntile, int tid, int) const {
+    __shared__ float seg[SEG];
+    const long b = ntile / tiles;
+    const int f0 = (int)(ntile - b * tiles) * BN;
+    const int s0 = f0 * hop - (n_fft - 1);
+    const int len = (BN - 1) * hop + n_fft;
+    const float* wb = wav + b * (long)T;
+    for (int i = tid; i < len; i += NT) {
+      const int t = s0 + i;
+      seg[i + (i >> 4)] = (t >= 0 && t < T) ? wb[t] : 0.f;
+    }
+    __syncthreads();
+    State s;
+    s.seg = seg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int h = 0; h < BP; ++h) {
+        const int u = ((tid & 31) * 4 + e) * hop + (tid >> 5) + 8 * h;
+        s.off[e][h] = u + (u >> 4);
+      }
+    return s;
+  }
+  __device__ Raw fetch(const State& s, int kt, bool, int h) const {
+    const float* p = s.seg + kt * (BK + 1);   // uniform: 16 samples + their pad word
+    Raw v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = p[s.off[e][h]];
+    return v;
+  }
+  __device__ f32x4 xform(const State&, Raw v, bool, int) const { return v; }
+};
+
 template <int MB, class BOp, class Epilogue>
 __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ wt, int M, int K, int ldw, long ntiles,
                                                       int mtiles, BOp bop, Epilogue ep) {
