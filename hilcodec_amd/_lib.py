@@ -49,7 +49,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HilcodecLibraryError(RuntimeError):

@@ -36,7 +36,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 1
+#define HILC_ABI_VERSION 2   /* 2: the fused residual block takes packed weights (hilc_resblock_pack_weights) */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
