@@ -122,7 +122,10 @@ def test_golden_resblock_modules(env, golden):
 
 
 @pytest.mark.parametrize("B,K,M,Tn", [(3, 64, 64, 1000), (2, 96, 96, 601), (2, 33, 64, 75), (1, 1024, 128, 75),
-                                      (2, 128, 1536, 75), (2, 257, 512, 40), (1, 768, 384, 360), (5, 192, 192, 128)])
+                                      (2, 128, 1536, 75), (2, 257, 512, 40), (1, 768, 384, 360), (5, 192, 192, 128),
+                                      # linear-addressing core (T % 4 == 0): ragged K tails with every row-tile height
+                                      (2, 33, 64, 1000), (1, 65, 96, 400), (4, 129, 160, 128), (2, 40, 192, 64),
+                                      (1, 16, 32, 4), (3, 17, 128, 2048), (1, 513, 1024, 76)])
 def test_pw_conv_vs_oracle(env, B, K, M, Tn):
     ops, fold, O, dev = env
     x = rnd(B * 7 + K, B, K, Tn)
@@ -235,7 +238,9 @@ def test_errors(env):
 
 
 @pytest.mark.parametrize("B,K,M,Tn", [(2, 64, 64, 1000), (2, 96, 96, 372), (1, 192, 192, 601), (2, 128, 1536, 75),
-                                      (1, 768, 768, 600), (3, 256, 256, 124), (2, 384, 384, 125)])
+                                      (1, 768, 768, 600), (3, 256, 256, 124), (2, 384, 384, 125),
+                                      # linear core with ragged K and 1 / 2 / 3-block row tiles
+                                      (2, 33, 96, 248), (1, 70, 160, 128), (3, 129, 64, 8), (1, 16, 32, 4)])
 def test_dws_conv_k5_vs_oracle(env, B, K, M, Tn):
     """fused pointwise -> depthwise k5 (both residual-block halves) against the two-step oracle"""
     ops, fold, O, dev = env
@@ -336,6 +341,7 @@ def test_elu_fast_error(env):
 
 
 @pytest.mark.parametrize("K,M,Tin,r", [(1536, 768, 75, 8), (768, 384, 60, 5), (384, 192, 301, 4), (192, 96, 1000, 2),
+                                       (40, 64, 24, 5), (24, 32, 16, 3), (33, 96, 8, 4),
                                        (64, 32, 4, 5)])
 def test_up_conv_vs_oracle(env, K, M, Tin, r):
     """fused [Scale, ELU, depthwise ConvTranspose k=2r, 1x1 conv + bias] against the three-step oracle"""
