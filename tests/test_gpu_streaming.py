@@ -211,3 +211,31 @@ def test_graphed_hop_equals_eager():
     for h in (2, 3):
         idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])
         assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1])
+
+
+@pytest.mark.parametrize("name,n,hop_frames", [("hil_music", 12, 1), ("hil_speech", 8, 3), ("hil_music", 5, 2)])
+def test_streaming_vs_oracle_other_configs(name, n, hop_frames):
+    """hil_music (Nq = 12) and multi-frame hops (test_onnx.py `num_frames` > 1: 640 / 960 samples per call) against
+    the oracle's streaming model; multi-frame hops take the flat-tiled fused block and the whole-clip wide kernels
+    at other T than the single-frame goldens."""
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming(seed=13, name=name)
+    p = O.stream_prepare(sd, mk)
+    B, hops, L = 2, 3, 320 * hop_frames
+    x = synth.synth_clips(B, L * hops, seed=21)
+    ce, cd = model.initialize_cache(x.to(dev))
+    oe, od = O.stream_init_cache(mk, B)
+    for h in range(hops):
+        xin = x[:, :, L * h: L * (h + 1)]
+        z, ce = model.encoder(xin.to(dev), *ce)
+        zo, oe = O.stream_encoder(p, mk, xin, oe)
+        assert z.shape == (B, hop_frames, 128) and (z.cpu() - zo).abs().max() < 2e-5
+        idx = model.quantizer(z, n)
+        io = O.stream_quantize(p, zo, n)
+        assert torch.equal(idx.cpu(), io)
+        w, cd = model.decoder(model.dequantizer(idx, n), *cd)
+        wo, od = O.stream_decoder(p, mk, O.stream_dequantize(p, io, n), od)
+        assert w.shape == (B, 1, L) and (w.cpu() - wo).abs().max() < 1e-4
+        for a, b in zip(list(ce) + list(cd), list(oe) + list(od)):
+            assert (a.cpu() - b).abs().max() < 5e-5
