@@ -147,12 +147,14 @@ struct PostArgs {
   int in_elu;
   float out_scale;
   int do_tanh;
+  unsigned tblocks;   // blocks of 256 samples per clip; blockIdx.x = b * tblocks + tb (flat: no 65535 limit on either)
 };
 
 // Cout = 1: one thread per output sample, channels reduced sequentially (c = 0..C-1, then taps).
 __global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
-  long b = blockIdx.x;
-  int t = blockIdx.y * 256 + threadIdx.x;
+  const long b = blockIdx.x / a.tblocks;
+  const unsigned tb = blockIdx.x - (unsigned)b * a.tblocks;
+  int t = tb * 256 + threadIdx.x;
   if (t >= a.T) return;
   const int pad = a.ksize - 1;
   float acc = 0.f;
@@ -180,9 +182,10 @@ __global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
 // channel order of the reduction is c ascending within a wave, then wave 0..3 — fixed.
 __global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
   __shared__ float part[4][256];
-  const long b = blockIdx.x;
+  const long b = blockIdx.x / a.tblocks;
+  const unsigned tb = blockIdx.x - (unsigned)b * a.tblocks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = (blockIdx.y * 64 + lane) * 4;
+  const int t = (tb * 64 + lane) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (t < a.T) {
     for (int c = wave; c < a.C; c += 4) {
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[wave][lane * 4 + e] = acc[e];
   __syncthreads();
-  const int tt = blockIdx.y * 256 + threadIdx.x;
+  const int tt = tb * 256 + threadIdx.x;
   if (tt < a.T) {
     float s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
     if (a.bias) s = __fadd_rn(s, a.bias[0]);
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
 }
 
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* x, float* y, int C, int T, float eps,
-                                                     float scale, int channel_last_out) {
-  long b = blockIdx.x;
-  int t = blockIdx.y * 256 + threadIdx.x;
+                                                     float scale, int channel_last_out, unsigned tblocks) {
+  const long b = blockIdx.x / tblocks;
+  int t = (blockIdx.x - (unsigned)b * tblocks) * 256 + threadIdx.x;
   if (t >= T) return;
   const float* xb = x + b * (long)C * T + t;
   float ss = 0.f;
@@ -317,7 +320,9 @@ extern "C" int hilc_conv_post(const float* x, const float* hist, const float* w,
   PostArgs a;
   a.x = x; a.hist = hist; a.w = w; a.bias = bias; a.y = y; a.C = C; a.T = T; a.ksize = ksize;
   a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.do_tanh = do_tanh;
-  dim3 grid((unsigned)B, (unsigned)ceil_div(T, 256));
+  a.tblocks = (unsigned)ceil_div(T, 256);
+  if ((long)B * a.tblocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+  dim3 grid((unsigned)((long)B * a.tblocks));
   const bool fast = ksize == 5 && T % 4 == 0 && hist == nullptr && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   HILC_CLEAR_ERROR();
   if (fast) hipLaunchKernelGGL(conv_post_k5_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -340,8 +345,10 @@ extern "C" int hilc_l2norm(const float* x, float* y, int B, int C, int T, float 
                            int channel_last_out, void* stream) {
   if (!x || !y) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
-  dim3 grid((unsigned)B, (unsigned)ceil_div(T, 256));
-  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, T, eps, scale, channel_last_out);
+  const unsigned tblocks = (unsigned)ceil_div(T, 256);
+  if ((long)B * tblocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+  dim3 grid((unsigned)((long)B * tblocks));
+  HILC_CLEAR_ERROR(); hipLaunchKernelGGL(l2norm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, T, eps, scale, channel_last_out, tblocks);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

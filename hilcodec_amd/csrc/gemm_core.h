@@ -159,7 +159,6 @@ int launch_gemm(const float* wt, int M, int K, int ldw, long ntiles, bool lds_ep
   // workgroup — per-output arithmetic (k order) is unchanged
   long groups = (ntiles + 7) / 8;
   while (MB > 1 && groups * 8 * ((m32 + MB - 1) / MB) < 128) --MB;
-  if (const char* e = getenv("HILC_MB")) { int v = atoi(e); if (v >= 1 && v <= 4) MB = v; }   // tuning aid
   int mtiles = (m32 + MB - 1) / MB;
   long blocks = groups * 8 * mtiles;
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;

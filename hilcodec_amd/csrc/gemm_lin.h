@@ -377,7 +377,6 @@ int launch_lin(const float* wt, int M, int K, int ldw, long ntiles, const BOp& b
   }
   long groups = (ntiles + 7) / 8;
   while (MB > 1 && groups * 8 * ((m32 + MB - 1) / MB) < 128) --MB;
-  if (const char* e = getenv("HILC_MB")) { int v = atoi(e); if (v >= 1 && v <= 4) MB = v; }   // tuning aid
   int mtiles = (m32 + MB - 1) / MB;
   long blocks = groups * 8 * mtiles;
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;

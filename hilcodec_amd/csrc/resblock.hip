@@ -26,6 +26,8 @@
 // store the new caches.  Per-column arithmetic is identical, so hop-by-hop output == offline output bit for bit.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm_core.h"
 
 using namespace hilc;
@@ -62,7 +64,9 @@ struct ResArgs {
   unsigned long long* dbg;   // optional [blocks][8] s_memtime stamps (tools/res_phase_times.py)
 };
 
-unsigned long long* g_dbg = nullptr;
+#ifdef HILC_DEBUG_STAMPS
+unsigned long long* g_dbg = nullptr;   // tools/res_phase_times.py builds its own copy of the library with this
+#endif
 
 // Weight operands of one GEMM phase.  DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the
 // shadow of the MFMAs of slice kt; the first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise
@@ -454,18 +458,22 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
   a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
   // persistent grid = exactly what can be resident (a surplus workgroup would only start after a
   // resident one has walked its whole tile list)
-  static int per_cu = 0, n_cu = 0;
-  if (per_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return HILC_ERR_LAUNCH;
-    int occ = 0;
+  // immutable per-device facts, looked up once per device (a process may drive several GPUs)
+  constexpr int MAXDEV = 64;
+  static std::atomic<int> resident_cache[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return HILC_ERR_LAUNCH;
+  int cached = dev >= 0 && dev < MAXDEV ? resident_cache[dev].load(std::memory_order_relaxed) : 0;
+  if (cached == 0) {
+    int n_cu = 0, occ = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
+      return HILC_ERR_LAUNCH;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM>, 256, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
-    n_cu = prop.multiProcessorCount;
-    per_cu = occ;
+    cached = n_cu * occ;
+    if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
   }
-  const long resident = (long)n_cu * per_cu;
+  const long resident = cached;
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL((resblock_kernel<C, STREAM>), dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -490,7 +498,11 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
   a.y = y; a.T = T; a.tiles = (T + TO - 1) / TO; a.pre_scale = pre_scale; a.out_scale = out_scale;
   a.hist1 = hist1; a.hist2 = hist2; a.hist1_out = hist1_out; a.hist2_out = hist2_out;
   a.sched = sched;
+#ifdef HILC_DEBUG_STAMPS
   a.dbg = g_dbg;
+#else
+  a.dbg = nullptr;
+#endif
   if (streaming) {
     if ((hist1 && hist1 == hist1_out) || (hist2 && hist2 == hist2_out)) return HILC_ERR_UNSUPPORTED;   // first / last tiles of a clip race
     if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
@@ -546,7 +558,9 @@ extern "C" int hilc_resblock_balanced(const float* x, const float* w1t, const fl
                         sched, B, C, T, pre_scale, out_scale, stream);
 }
 
+#ifdef HILC_DEBUG_STAMPS
 extern "C" void hilc_debug_set_stamp_buffer(unsigned long long* p) { g_dbg = p; }
+#endif
 
 extern "C" int hilc_resblock_supported(int C, int T) {
   return (C == 64 || C == 96 || C == 128 || C == 192) && T % 4 == 0;

@@ -70,7 +70,7 @@ class ResidualVQ(_CodebookStack):
 
     def forward(self, x: Tensor, n: int) -> Tensor:
         sp = self._tables(x.device)
-        if isinstance(n, int) or (isinstance(n, Tensor) and n.dim() == 0):
+        if ops.is_scalar_n(n):
             n = min(int(n), len(self.layers))           # reference: `self.layers[:n]`
             if n < 1:
                 raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
@@ -107,7 +107,7 @@ class Dequantizer(_CodebookStack):
         sp = self._tables(indices.device)
         if indices.dtype != torch.int64:
             indices = indices.long()                   # test_onnx.py stores int16 (:96-100)
-        if isinstance(n, int) or (isinstance(n, Tensor) and n.dim() == 0):
+        if ops.is_scalar_n(n):
             n = int(n)
         return ops.rvq_decode(indices.contiguous(), sp.codebooks, n, channel_last=True, stage_major=True)
 

@@ -166,9 +166,10 @@ class ResidualVQ(nn.Module):
                 raise RuntimeError("codebook not initialised (kmeans_init=True and no checkpoint loaded); the "
                                    "reference would silently run k-means on this input (vector_quantize.py:139-140)")
         num_replaces = np.zeros(len(self.layers), dtype=np.int64)
-        if n is not None and not isinstance(n, int):
+        if n is not None and not ops.is_scalar_n(n):
             high = n       # one n per clip (mixed-bitrate batch); ops.per_clip_n applies the assert per entry
         elif n is not None:
+            n = int(n)
             assert 1 <= n <= len(self.layers), f"'n' must be in range of 1 <= n <= {len(self.layers)}"
             high = n
         else:

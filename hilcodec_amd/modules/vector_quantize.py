@@ -1,73 +1,152 @@
-"""The older residual VQ named by the north star (`modules/vector_quantize.py` of the reference):
-`EuclideanCodebook` / `VectorQuantize` / `ResidualVQ`, eval branch, same kernel.  Codebooks live at
-`.layers[i]._codebook.embed`; `forward(x [B,C,T], n=None) -> (quantized, num_replaces, loss)`.
-`ShapeGainCodebook` / `ResidualShapeGainVQ` are unused by HILCodec and out of scope."""
+"""The older residual VQ named by the north star (`modules/vector_quantize.py` of the reference) on the gfx950 RVQ
+kernels (`csrc/rvq.hip`): `EuclideanCodebook` / `VectorQuantize` / `ResidualVQ` with the reference's constructor
+signatures, buffer names (`initted`, `embed`, `ema_embed`, `ema_num` — a reference `state_dict` loads with
+`load_state_dict(strict=True)`) and return contracts:
+
+  EuclideanCodebook.forward(x [..., dim])                          -> (quantize [..., dim], num_replace)
+  VectorQuantize.forward(x, calculate_commitment_loss=False)       -> (quantize, num_replace, commit_loss | None)
+  ResidualVQ.forward(x, n=None)                                    -> (quantized_out, num_replaces np.int64[Nq], mse loss)
+
+Eval = the forward hot path (one fused launch for all stages in `ResidualVQ`).  The training branch
+(`modules/vector_quantize.py:167-195`: EMA statistics, Laplace smoothing, dead-code replacement) runs the code search
+and the cluster statistics on the kernels and the (tiny, once-per-step) table update as torch ops on the same device;
+it updates codebooks only — nothing here builds an autograd graph.  Options this path does not implement raise:
+`use_shape_gain` (`ShapeGainCodebook` / `ResidualShapeGainVQ` are unused by HILCodec), k-means initialisation
+(an un-initialised codebook raises instead of silently quantising against zeros)."""
 from __future__ import annotations
 
+import random
 import typing as tp
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .. import engine, fold, ops
+from .. import distributed, engine, fold, ops
 
 
 class EuclideanCodebook(nn.Module):
-    """`modules/vector_quantize.py:76-195` (buffers `embed`, `embed_avg`, `cluster_size`, `initted`)."""
+    """`modules/vector_quantize.py:76-195`."""
 
-    def __init__(self, dim: int, codebook_size: int, kmeans_init: bool = False, kmeans_iters: int = 10,
-                 decay: float = 0.8, eps: float = 1e-5, threshold_ema_dead_code: float = 2.0, **_ignored):
+    def __init__(self, dim: int, codebook_size: int, kmeans_init: bool = False, kmeans_iters: int = 20,
+                 decay: float = 0.8, eps: float = 1e-7, ema_num_threshold: float = 0.0,
+                 ema_num_initial: float = 1.0):
         super().__init__()
         self.decay = decay
         embed = (torch.randn if not kmeans_init else torch.zeros)(codebook_size, dim)
         self.codebook_size = codebook_size
         self.kmeans_iters = kmeans_iters
         self.eps = eps
-        self.threshold_ema_dead_code = threshold_ema_dead_code
-        self.register_buffer("initted", torch.Tensor([not kmeans_init]))
-        self.register_buffer("cluster_size", torch.zeros(codebook_size))
+        self.ema_num_threshold = ema_num_threshold
+        self.ema_num_initial = ema_num_initial
+        self.register_buffer("initted", Tensor([not kmeans_init]))
         self.register_buffer("embed", embed)
-        self.register_buffer("embed_avg", embed.clone())
+        self.register_buffer("ema_embed", embed.clone() * ema_num_initial)
+        self.register_buffer("ema_num", torch.ones(codebook_size) * ema_num_initial)
+
+    def _require_initted(self) -> None:
+        if not bool(self.initted):
+            raise RuntimeError("codebook not initialised (kmeans_init=True and no checkpoint loaded): the reference "
+                               "would run k-means on this input (modules/vector_quantize.py:149-150), which this "
+                               "path does not implement; load or set the codebook first")
+
+    @torch.no_grad()
+    def replace(self, samples: Tensor, mask: Tensor) -> int:
+        """`:119-128`: expired codes <- random vectors of the batch; rank 0's choice is broadcast."""
+        idx = torch.nonzero(mask).squeeze(1)
+        num, ns = idx.size(0), samples.shape[0]
+        if ns >= num:
+            pick = torch.randperm(ns, device=samples.device)[:num]
+        else:
+            pick = torch.randint(0, ns, (num,), device=samples.device)
+        new_embed = distributed.broadcast_(samples[pick].detach().float().contiguous(), 0).to(self.embed.device)
+        tgt = idx.to(self.embed.device)
+        self.embed[tgt, :] = new_embed
+        self.ema_embed[tgt, :] = new_embed * self.ema_num_initial
+        self.ema_num[tgt] = self.ema_num_initial
+        return num
+
+    @torch.no_grad()
+    def expire_codes_(self, batch_samples: Tensor) -> int:
+        """`:130-138`."""
+        if self.ema_num_threshold == 0.0:
+            return 0
+        expired = self.ema_num < self.ema_num_threshold
+        if not torch.any(expired):
+            return 0
+        return self.replace(batch_samples.reshape(-1, batch_samples.shape[-1]), expired)
 
     @torch.no_grad()
     def forward(self, x: Tensor) -> tp.Tuple[Tensor, int]:
-        if self.training:
-            raise NotImplementedError("EMA codebook training is outside the MI355X forward hot path")
+        """x `[..., dim]` (channel-last, as `VectorQuantize` hands it over)."""
+        self._require_initted()
         shape = x.shape
-        flat = x.reshape(1, -1, shape[-1]).contiguous().float()
-        cb, cbt, norms = fold.codebook_tables([self.embed])
         dev = x.device
-        _, q, _ = ops.rvq_encode(flat, cb.to(dev), cbt.to(dev), norms.to(dev), 1, channel_last=True,
-                                 stage_major=True, want_q=True)
-        return q.view(shape), 0
+        flat = x.reshape(1, -1, shape[-1]).contiguous().float()        # [1, N, dim]
+        cb, cbt, norms = (t.to(dev) for t in fold.codebook_tables([self.embed]))
+        idx, q, _ = ops.rvq_encode(flat, cb, cbt, norms, 1, channel_last=True, stage_major=True, want_q=True)
+        quantize = q.view(shape)
+        num_replace = 0
+        if self.training:
+            # `:167-193`: counts and per-code sums of this batch (deterministic kernel, fixed frame order), summed
+            # over ranks in one bucket, EMA, (Laplace-smoothed) normalisation, dead-code replacement
+            K, C = self.embed.shape
+            bucket = ops.rvq_ema_stats(flat, cb, idx, 1, channel_last=True, stage_major=True)
+            distributed.all_reduce_sum_(bucket)
+            ema_num_new = bucket[0, :K].to(self.ema_num.device)
+            ema_embed_new = bucket[0, K:].view(K, C).to(self.ema_embed.device)
+            self.ema_num.mul_(self.decay).add_(ema_num_new, alpha=1 - self.decay)
+            self.ema_embed.mul_(self.decay).add_(ema_embed_new, alpha=1 - self.decay)
+            if self.ema_num_threshold <= 0.0:
+                ema_num = (self.ema_num + self.eps) / (self.ema_num.sum() + self.codebook_size * self.eps) \
+                    * self.ema_num.sum()
+            else:
+                ema_num = self.ema_num
+            self.embed.copy_(self.ema_embed / ema_num.unsqueeze(1))
+            num_replace = self.expire_codes_(x)
+        return quantize, num_replace
 
 
 class VectorQuantize(nn.Module):
-    """`modules/vector_quantize.py:376-419`: x `[B,C,T]` -> (quantize `[B,C,T]`, num_replace)."""
+    """`modules/vector_quantize.py:376-419`."""
 
-    def __init__(self, dim: int, codebook_size: int, **kwargs):
+    def __init__(self, commitment: float = 1., use_shape_gain: bool = False, channel_last: bool = False,
+                 gradient_flow: bool = True, **kwargs):
         super().__init__()
-        self._codebook = EuclideanCodebook(dim=dim, codebook_size=codebook_size, **kwargs)
+        if use_shape_gain:
+            raise NotImplementedError("ShapeGainCodebook (modules/vector_quantize.py:198-372) is not part of the "
+                                      "HILCodec path")
+        self.commitment = commitment
+        self.use_shape_gain = use_shape_gain
+        self.channel_last = channel_last
+        self._codebook = EuclideanCodebook(**kwargs)      # unknown kwargs raise TypeError, as in the reference
+        self.gradient_flow = gradient_flow
 
-    @property
-    def codebook(self):
-        return self._codebook.embed
-
-    def forward(self, x: Tensor) -> tp.Tuple[Tensor, int]:
-        q, nr = self._codebook(x.transpose(1, 2).contiguous())
-        return q.transpose(1, 2).contiguous(), nr
+    def forward(self, x: Tensor, calculate_commitment_loss: bool = False):
+        if not self.channel_last:
+            x = x.transpose(1, 2)                          # [B,C,T] -> [B,T,C]
+        quantize, num_replace = self._codebook(x)
+        commit_loss = F.mse_loss(quantize.detach(), x) * self.commitment if calculate_commitment_loss else None
+        if self.gradient_flow and self.training:
+            quantize = x + quantize - x.detach()
+        if not self.channel_last:
+            quantize = quantize.transpose(1, 2)
+        return quantize, num_replace, commit_loss
 
 
 class ResidualVQ(nn.Module):
     """`modules/vector_quantize.py:471-516`."""
 
-    def __init__(self, *, num_quantizers: int, dropout: bool = False,
+    def __init__(self, num_quantizers: int, dropout: bool = False,
                  dropout_index: tp.Optional[tp.List[int]] = None, **kwargs):
         super().__init__()
-        self.layers = nn.ModuleList([VectorQuantize(**kwargs) for _ in range(num_quantizers)])
+        self.layers = nn.ModuleList([VectorQuantize(gradient_flow=False, **kwargs) for _ in range(num_quantizers)])
         self.dropout = dropout
+        if dropout_index is None:
+            dropout_index = list(range(1, num_quantizers + 1))
         self.dropout_index = dropout_index
+        self.use_shape_gain = self.layers[0].use_shape_gain
         self._key = None
         self._spec = None
 
@@ -81,13 +160,29 @@ class ResidualVQ(nn.Module):
         return self._spec
 
     def forward(self, x: Tensor, n: tp.Optional[int] = None):
-        if self.training:
-            raise NotImplementedError("training-mode RVQ is outside the forward hot path")
         num_replaces = np.zeros(len(self.layers), dtype=np.int64)
-        high = len(self.layers) if n is None else n
         if n is not None:
             assert 1 <= n <= len(self.layers), f"'n' must be in range of 1 <= n <= {len(self.layers)}"
+            high = int(n)
+        elif self.training and self.dropout:
+            high = random.sample(self.dropout_index, 1)[0]
+        else:
+            high = len(self.layers)
+        if self.training:
+            # the reference's stage loop: every stage updates its own table after its search (`:501-505`)
+            quantized_out = 0.
+            residual = x.detach()
+            for i, layer in enumerate(self.layers[:high]):
+                quantized, num_replace, _ = layer(residual, calculate_commitment_loss=False)
+                num_replaces[i] = num_replace
+                residual = residual - quantized
+                quantized_out = quantized_out + quantized
+            loss = F.mse_loss(x, quantized_out)
+            return quantized_out + x - x.detach(), num_replaces, loss
+        for l in self.layers[:high]:
+            l._codebook._require_initted()
         sp = self.spec(x.device)
         _, q, loss = ops.rvq_encode(x.contiguous().float(), sp.codebooks, sp.codebooks_t, sp.norms, high,
-                                    channel_last=False, stage_major=False, want_q=True, want_loss=True)
+                                    channel_last=self.layers[0].channel_last, stage_major=False, want_q=True,
+                                    want_loss=True)
         return q, num_replaces, loss

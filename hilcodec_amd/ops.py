@@ -5,8 +5,10 @@ hand-written gfx950 kernels of `csrc/`.  All tensors must be fp32 (indices int64
 GPU; anything else raises — there is deliberately no fallback path."""
 from __future__ import annotations
 
+import numbers
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -324,11 +326,16 @@ def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: 
     return y
 
 
+def is_scalar_n(n) -> bool:
+    """anything integer-like (python / numpy ints, 0-dim arrays and tensors) is ONE n for the whole batch"""
+    return isinstance(n, numbers.Integral) or (isinstance(n, (Tensor, np.ndarray)) and n.ndim == 0)
+
+
 def per_clip_n(n, B: int, Nq: int, device):
     """`n` as the reference takes it (one int for the whole batch) or one int per clip (mixed-bitrate batch).
     Returns (rows, int32 [B] device tensor or None).  Every entry obeys the reference's assert
     (`models/hilcodec/vector_quantize.py:213-214`)."""
-    if isinstance(n, (int,)) or (isinstance(n, Tensor) and n.dim() == 0):
+    if is_scalar_n(n):
         return int(n), None
     host = torch.as_tensor(n).detach().to("cpu", torch.int64).reshape(-1)
     if host.numel() != B:

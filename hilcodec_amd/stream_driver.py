@@ -5,7 +5,7 @@ MI355X kernels instead of ONNXRuntime sessions:
                  -> indices int16 `[n, B, T]` saved as `{name}_quantized.npy`        (test_onnx.py:50-100)
   decoder pass : indices -> `num_frames` at a time -> Dequantizer -> decoder(+caches) -> waveform
                                                                                      (test_onnx.py:103-139)
-  Timer        : per-stage wall time and RTF = audio seconds / wall seconds (↑)      (test_onnx.py:20-47)
+  StageClock   : per-stage RTF = audio seconds / stage seconds (HIP events)          (test_onnx.py:20-47)
 
     python -m hilcodec_amd.stream_driver -n hil_speech -q 8 -f 1 --enc --dec --input in.wav --outdir out/
 
@@ -15,8 +15,8 @@ generator used by the tests (there are no trained encoder/decoder weights in the
 from __future__ import annotations
 
 import argparse
+import contextlib
 import os
-import time
 import wave
 from typing import List, Optional, Sequence, Tuple
 
@@ -27,50 +27,59 @@ from torch import Tensor
 from . import synth, wire
 
 
-class Timer:
-    """`test_onnx.py:20-47`."""
+class StageClock:
+    """Per-stage real-time factor of a streaming run — what `test_onnx.py:20-47` reports (RTF = audio seconds per
+    wall second of a stage), measured the GPU way: a stage is bracketed by two HIP events on the launch stream and
+    the host only synchronises once, when the figures are read, so timing a run does not serialise its hops."""
 
-    def __init__(self, sr: int):
-        self.sr = sr
-        self.enc_time = 0.0
-        self.dec_time = 0.0
-        self.start_time = time.perf_counter()
-        self.wav_len = 0
+    STAGES = ("encoder", "decoder")
 
-    def tic(self):
-        torch.cuda.synchronize()
-        self.start_time = time.perf_counter()
+    def __init__(self, sample_rate: int):
+        self.sample_rate = sample_rate
+        self.samples = 0                      # audio samples the run covered (set by encode_stream / decode_stream)
+        self._spans = {s: [] for s in self.STAGES}
 
-    def encoder_time(self):
-        torch.cuda.synchronize()
-        et = time.perf_counter()
-        self.enc_time += et - self.start_time
-        self.start_time = et
+    class _Span:
+        def __init__(self, spans):
+            self._spans = spans
 
-    def decoder_time(self):
-        torch.cuda.synchronize()
-        et = time.perf_counter()
-        self.dec_time += et - self.start_time
-        self.start_time = et
+        def __enter__(self):
+            self.begin = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.begin.record()
+            return self
+
+        def __exit__(self, *exc):
+            self.end.record()
+            self._spans.append((self.begin, self.end))
+            return False
+
+    def stage(self, name: str) -> "StageClock._Span":
+        return StageClock._Span(self._spans[name])
+
+    def seconds(self, name: str) -> float:
+        spans = self._spans[name]
+        if spans:
+            spans[-1][1].synchronize()
+        return sum(b.elapsed_time(e) for b, e in spans) * 1e-3
 
     def report(self) -> dict:
-        wav_time = self.wav_len / self.sr
-        out = {"wav_seconds": wav_time}
-        if self.enc_time > 0:
-            out["encoder_seconds"] = self.enc_time
-            out["encoder_rtf"] = wav_time / self.enc_time
-        if self.dec_time > 0:
-            out["decoder_seconds"] = self.dec_time
-            out["decoder_rtf"] = wav_time / self.dec_time
+        audio = self.samples / self.sample_rate
+        out = {"wav_seconds": audio}
+        for name in self.STAGES:
+            sec = self.seconds(name)
+            if sec > 0:
+                out[f"{name}_seconds"] = sec
+                out[f"{name}_rtf"] = audio / sec
         return out
 
-    def print(self):
+    def summary(self) -> str:
         r = self.report()
-        print(f"\rwav length: {r['wav_seconds']:.1f} s")
-        if "encoder_rtf" in r:
-            print(f"encoder: {self.enc_time:.1f} s / rtf: {r['encoder_rtf']:.4f} (↑)")
-        if "decoder_rtf" in r:
-            print(f"decoder: {self.dec_time:.1f} s / rtf: {r['decoder_rtf']:.4f} (↑)")
+        lines = [f"audio {r['wav_seconds']:.2f} s"]
+        for name in self.STAGES:
+            if f"{name}_rtf" in r:
+                lines.append(f"{name:8s} {r[name + '_seconds'] * 1e3:9.2f} ms   {r[name + '_rtf']:10.1f} x real time")
+        return "\n".join(lines)
 
 
 def read_wav(path: str, sr: int) -> np.ndarray:
@@ -97,7 +106,7 @@ def write_wav(path: str, wav: np.ndarray, sr: int) -> None:
 
 @torch.no_grad()
 def encode_stream(model, wav: Tensor, num_quantizers: int, num_frames: int = 1, hop_size: int = 320,
-                  cache_enc: Optional[Sequence[Tensor]] = None, timer: Optional[Timer] = None
+                  cache_enc: Optional[Sequence[Tensor]] = None, timer: Optional[StageClock] = None
                   ) -> Tuple[Tensor, List[Tensor]]:
     """wav `[B,1,L]` on the GPU -> (indices int16 `[n,B,L//320]`, final encoder caches).  The tail that does
     not fill a chunk is dropped, like `length = len(wav) // hop_size * hop_size` (test_onnx.py:53)."""
@@ -107,20 +116,18 @@ def encode_stream(model, wav: Tensor, num_quantizers: int, num_frames: int = 1, 
     cache = list(cache_enc) if cache_enc is not None else model.encoder.initialize_cache(wav)
     chunks = []
     if timer:
-        timer.wav_len = length
-        timer.tic()
-    for i in range(0, length, hop):
-        x, cache = model.encoder(wav[:, :, i:i + hop].contiguous(), *cache)
-        chunks.append(model.quantizer(x, num_quantizers))            # [n,B,F]
-    if timer:
-        timer.encoder_time()
+        timer.samples = length
+    with (timer.stage("encoder") if timer else contextlib.nullcontext()):
+        for i in range(0, length, hop):
+            x, cache = model.encoder(wav[:, :, i:i + hop].contiguous(), *cache)
+            chunks.append(model.quantizer(x, num_quantizers))            # [n,B,F]
     idx = torch.cat(chunks, dim=2) if chunks else torch.zeros(num_quantizers, wav.shape[0], 0, dtype=torch.int64)
     return idx.to(torch.int16), cache
 
 
 @torch.no_grad()
 def decode_stream(model, indices: Tensor, num_quantizers: int, num_frames: int = 1,
-                  cache_dec: Optional[Sequence[Tensor]] = None, timer: Optional[Timer] = None
+                  cache_dec: Optional[Sequence[Tensor]] = None, timer: Optional[StageClock] = None
                   ) -> Tuple[Tensor, List[Tensor]]:
     """indices `[n,B,T]` (int16 or int64) -> (wav `[B,1,320*T]`, final decoder caches)."""
     dev = next(model.parameters()).device
@@ -128,17 +135,14 @@ def decode_stream(model, indices: Tensor, num_quantizers: int, num_frames: int =
     cache = list(cache_dec) if cache_dec is not None else model.decoder.initialize_cache(
         torch.zeros(indices.shape[1], 1, device=dev))
     outs = []
-    if timer:
-        timer.tic()
-    for i in range(0, indices.shape[2], num_frames):
-        q = model.dequantizer(indices[:num_quantizers, :, i:i + num_frames].contiguous(), num_quantizers)
-        w, cache = model.decoder(q, *cache)
-        outs.append(w)
-    if timer:
-        timer.decoder_time()
+    with (timer.stage("decoder") if timer else contextlib.nullcontext()):
+        for i in range(0, indices.shape[2], num_frames):
+            q = model.dequantizer(indices[:num_quantizers, :, i:i + num_frames].contiguous(), num_quantizers)
+            w, cache = model.decoder(q, *cache)
+            outs.append(w)
     wav = torch.cat(outs, dim=2)
     if timer:
-        timer.wav_len = wav.shape[-1]
+        timer.samples = wav.shape[-1]
     return wav, cache
 
 
@@ -172,7 +176,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     model = build_streaming_model(a.name, a.checkpoint, dev)
-    timer = Timer(a.sr)
+    timer = StageClock(a.sr)
     qpath = os.path.join(a.outdir, f"{a.name}_quantized.npy")
     if a.enc:
         wav = read_wav(a.input, a.sr) if a.input else synth.sweep_clip(a.sr * 2, a.sr).numpy().reshape(-1)
@@ -183,7 +187,7 @@ def main(argv=None):
         idx = wire.load_indices_npy(qpath)
         wav, _ = decode_stream(model, idx, a.num_quantizers, a.num_frames, timer=timer)
         write_wav(os.path.join(a.outdir, f"{a.name}_output.wav"), wav[0, 0].cpu().numpy(), a.sr)
-    timer.print()
+    print(timer.summary())
     return timer.report()
 
 

@@ -8,7 +8,8 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in this repo);
- *    the library allocates nothing, keeps no global state, and is re-entrant;
+ *    the library allocates nothing, keeps no mutable global state (only a per-device cache of immutable
+ *    occupancy facts), and is re-entrant;
  *  - tensors are dense fp32, channel-major `[B][C][T]` (time contiguous) unless stated;
  *  - `stream` is a `hipStream_t` passed as `void*`; all work is enqueued on it, nothing syncs;
  *  - return value: HILC_OK (0) or a negative HILC_ERR_* code; nothing is launched on error;

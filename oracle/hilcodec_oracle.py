@@ -316,6 +316,50 @@ def rvq_train_step(state: Dict[str, Tensor], z: Tensor, n: Optional[int], num_qu
     return out, loss, torch.stack(indices, dim=1), torch.stack(expired)
 
 
+def legacy_rvq_train_step(state: Dict[str, Tensor], z: Tensor, n: Optional[int], num_quantizers: int, decay: float,
+                          eps: float = 1e-7, ema_num_threshold: float = 0.0, bucket_hook=None
+                          ) -> Tuple[Tensor, Tensor, Tensor]:
+    """Training branch of the OLDER stack: `EuclideanCodebook.forward` `modules/vector_quantize.py:141-195` inside
+    `ResidualVQ.forward` `:487-516` (channel_last=False, `gradient_flow=False` layers), single process, expiry only
+    reported.  Differences to `rvq_train_step`: argmax of the negated distance (`:152-158`), and with
+    `ema_num_threshold <= 0` the counts are Laplace-smoothed before the division (`:183-190`).
+    `state`: `layers.{i}.embed / ema_embed / ema_num`, updated in place.
+    Returns `(values of the straight-through output [B,C,T], loss, expired masks [n,K])`."""
+    high = n if n is not None else num_quantizers
+    residual = z.detach()
+    out = 0.
+    expired = []
+    for i in range(high):
+        embed = state[f"layers.{i}.embed"]
+        x = residual.transpose(1, 2)                                  # VectorQuantize: 'b c t -> b t c' (`:402-404`)
+        flatten = x.reshape(-1, x.shape[-1])
+        ind = codebook_argmax_neg(flatten, embed)
+        onehot = F.one_hot(ind, embed.shape[0]).type(embed.dtype)
+        q = F.embedding(ind.view(*x.shape[:-1]), embed)
+        num_new = onehot.sum(dim=0)
+        embed_new = flatten.t().float() @ onehot                      # [C, K] (`:178`)
+        if bucket_hook is not None:
+            bucket = torch.cat([num_new, embed_new.reshape(-1)])
+            bucket_hook(bucket)
+            num_new = bucket[:embed.shape[0]]
+            embed_new = bucket[embed.shape[0]:].reshape(embed.shape[1], embed.shape[0])
+        ema_num, ema_embed = state[f"layers.{i}.ema_num"], state[f"layers.{i}.ema_embed"]
+        ema_num.mul_(decay).add_(num_new, alpha=(1 - decay))
+        ema_embed.mul_(decay).add_(embed_new.t(), alpha=(1 - decay))
+        if ema_num_threshold <= 0.0:
+            denom = (ema_num + eps) / (ema_num.sum() + embed.shape[0] * eps) * ema_num.sum()
+        else:
+            denom = ema_num
+        embed.copy_(ema_embed / denom.unsqueeze(1))
+        expired.append(ema_num < ema_num_threshold if ema_num_threshold != 0.0
+                       else torch.zeros_like(ema_num, dtype=torch.bool))
+        q = q.transpose(1, 2)
+        residual = residual - q
+        out = out + q
+    loss = F.mse_loss(z, out)
+    return out + z - z.detach(), loss, torch.stack(expired)
+
+
 def rvq_gaps_fp64(sd: SD, z: Tensor, indices: Tensor, prefix: str = "quantizer.layers.{i}.embed") -> Tensor:
     """fp64 best-vs-second-best distance gap per (b, stage, t) along the *given* index path
     (used by the parity tests to tell a genuine mismatch from a sub-ulp near-tie)."""

@@ -129,3 +129,72 @@ def test_streaming_module_tree_and_mapping():
     assert torch.equal(m.decoder.conv_post.weight.data, p["dec.post.weight"])
     assert torch.equal(m.decoder.conv_post.bias.data, p["dec.post.bias"])
     assert torch.equal(m.dequantizer.layers[3].embed, sd["quantizer.layers.3.embed"])
+
+
+def test_legacy_rvq_matches_reference_constructor_and_state_dict():
+    """`modules/vector_quantize.py` (row a9): same ctor signatures, buffers and return arity as the reference; a real
+    reference state_dict loads strictly when the checkout is present (build container), and the key/shape contract is
+    checked against a literal everywhere else."""
+    from hilcodec_amd.modules.vector_quantize import EuclideanCodebook, ResidualVQ, VectorQuantize
+    kw = dict(num_quantizers=3, dropout=True, dropout_index=[1, 3], dim=16, codebook_size=32, kmeans_init=False,
+              kmeans_iters=20, decay=0.9, eps=1e-7, ema_num_threshold=0.5, ema_num_initial=2.0, commitment=0.25,
+              channel_last=False)
+    own = ResidualVQ(**kw)
+    keys = {k: tuple(v.shape) for k, v in own.state_dict().items()}
+    want = {}
+    for i in range(3):
+        for name, shape in (("initted", (1,)), ("embed", (32, 16)), ("ema_embed", (32, 16)), ("ema_num", (32,))):
+            want[f"layers.{i}._codebook.{name}"] = shape
+    assert keys == want
+    cbk = own.layers[0]._codebook
+    assert torch.equal(cbk.ema_embed, cbk.embed * 2.0) and torch.equal(cbk.ema_num, torch.full((32,), 2.0))
+    assert own.layers[0].commitment == 0.25 and own.layers[0].gradient_flow is False and own.dropout_index == [1, 3]
+    # options this path does not implement are refused, unknown ones are a TypeError as in the reference
+    with pytest.raises(NotImplementedError):
+        VectorQuantize(use_shape_gain=True, dim=16, codebook_size=32)
+    with pytest.raises(TypeError):
+        VectorQuantize(dim=16, codebook_size=32, threshold_ema_dead_code=2.0)
+    with pytest.raises(TypeError):
+        EuclideanCodebook(16, 32, bogus=1)
+    # un-initialised k-means codebooks never quantise against zeros silently
+    lazy = ResidualVQ(num_quantizers=2, dim=16, codebook_size=32, kmeans_init=True).eval()
+    assert not bool(lazy.layers[0]._codebook.initted)
+    with pytest.raises(RuntimeError, match="not initialised"):
+        lazy(torch.zeros(1, 16, 4))
+    with pytest.raises(AssertionError):
+        own.eval()(torch.zeros(1, 16, 4), 4)
+    from oracle import refimport
+    if refimport.reference_available():
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "_ref_legacy_vq", os.path.join(refimport.REFERENCE_ROOT, "modules", "vector_quantize.py"))
+        ref_mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_mod)
+        ref = ref_mod.ResidualVQ(**kw)
+        res = own.load_state_dict(ref.state_dict(), strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert torch.equal(own.layers[2]._codebook.embed, ref.layers[2]._codebook.embed)
+        ref.load_state_dict(own.state_dict(), strict=True)
+        import inspect
+        for a, b in ((EuclideanCodebook, ref_mod.EuclideanCodebook), (VectorQuantize, ref_mod.VectorQuantize),
+                     (ResidualVQ, ref_mod.ResidualVQ)):
+            pa, pb = inspect.signature(a.__init__).parameters, inspect.signature(b.__init__).parameters
+            assert list(pa) == list(pb), (a.__name__, list(pa), list(pb))
+            assert all(pa[k].default == pb[k].default for k in pa if k not in ("self", "kwargs")), a.__name__
+        assert list(inspect.signature(VectorQuantize.forward).parameters) == \
+            list(inspect.signature(ref_mod.VectorQuantize.forward).parameters)
+
+
+def test_scalar_n_accepts_any_integer_like():
+    """`n` from config arithmetic (numpy ints, 0-dim arrays / tensors) is a scalar n, not a per-clip list."""
+    from hilcodec_amd import ops
+    for n in (3, np.int64(3), np.int32(3), np.array(3), torch.tensor(3), True + 2):
+        assert ops.per_clip_n(n, 5, 8, torch.device("cpu")) == (3, None)
+    rows, per = ops.per_clip_n([1, 2, 8, 2, 1], 5, 8, torch.device("cpu"))
+    assert rows == 8 and per.dtype == torch.int32 and per.tolist() == [1, 2, 8, 2, 1]
+    rows, per = ops.per_clip_n(np.array([4]), 1, 8, torch.device("cpu"))       # a 1-element LIST is per-clip (B = 1)
+    assert rows == 4 and per.tolist() == [4]
+    with pytest.raises(AssertionError):
+        ops.per_clip_n([1, 9], 2, 8, torch.device("cpu"))
+    with pytest.raises(RuntimeError):
+        ops.per_clip_n([1, 2], 3, 8, torch.device("cpu"))

@@ -276,3 +276,64 @@ def test_rvq_training_stats_and_expiry_vs_oracle():
     sd = {f"quantizer.layers.{i}.embed": rvq.layers[i].embed.cpu() for i in range(nq)}
     _, _, _, idx_o = O.rvq_forward(sd, z, None, nq)
     assert check_indices(O, sd, z, idx_eval.cpu(), idx_o) <= 1
+
+
+def test_legacy_rvq_contracts_and_training_vs_oracle():
+    """Row a9 (`modules/vector_quantize.py`): VectorQuantize's 3-tuple and kwargs, channel_last honoured (not
+    transposed behind the caller's back), and the train-mode EMA update against the pinned oracle restatement."""
+    from hilcodec_amd.modules.vector_quantize import ResidualVQ, VectorQuantize
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    D, K, nq, decay, init = 128, 1024, 3, 0.9, 0.5
+    embeds = [torch.from_numpy(synth.normalish(820 + i, K * D) * np.float32(0.3)).view(K, D) for i in range(nq)]
+    sd = {f"quantizer.layers.{i}.embed": e for i, e in enumerate(embeds)}
+    z = torch.from_numpy(synth.normalish(75, 2 * D * 40)).view(2, D, 40)
+    # single layer: (quantize, num_replace, commit_loss)
+    vq = VectorQuantize(dim=D, codebook_size=K, commitment=0.25).eval().to(dev)
+    vq._codebook.embed.copy_(embeds[0])
+    q, nr, cl = vq(z.to(dev))
+    qo, _, _, _ = O.rvq_forward(sd, z, 1, nq, variant="legacy")
+    assert torch.equal(q.cpu(), qo) and nr == 0 and cl is None
+    q, nr, cl = vq(z.to(dev), calculate_commitment_loss=True)
+    assert abs(float(cl) - 0.25 * float(torch.nn.functional.mse_loss(qo, z))) < 1e-6
+    # channel_last=True takes [B,T,C] and returns [B,T,C]
+    vq_cl = VectorQuantize(dim=D, codebook_size=K, channel_last=True).eval().to(dev)
+    vq_cl._codebook.embed.copy_(embeds[0])
+    q_cl, _, _ = vq_cl(z.transpose(1, 2).contiguous().to(dev))
+    assert q_cl.shape == (2, 40, D) and torch.equal(q_cl.transpose(1, 2).cpu(), qo)
+    rvq_cl = ResidualVQ(num_quantizers=nq, dim=D, codebook_size=K, channel_last=True).eval().to(dev)
+    for l, e in zip(rvq_cl.layers, embeds):
+        l._codebook.embed.copy_(e)
+    q3, nr3, loss3 = rvq_cl(z.transpose(1, 2).contiguous().to(dev), 2)
+    q3o, _, loss3o, _ = O.rvq_forward(sd, z, 2, nq, variant="legacy")
+    assert torch.equal(q3.transpose(1, 2).cpu(), q3o) and abs(float(loss3) - float(loss3o)) < 1e-6 * float(loss3o)
+    # training: three EMA steps, Laplace-smoothed division (no threshold)
+    rvq = ResidualVQ(num_quantizers=nq, dim=D, codebook_size=K, decay=decay, ema_num_initial=init).train().to(dev)
+    st = {}
+    for i, (l, e) in enumerate(zip(rvq.layers, embeds)):
+        l._codebook.embed.copy_(e)
+        l._codebook.ema_embed.copy_(e * init)
+        st[f"layers.{i}.embed"], st[f"layers.{i}.ema_embed"], st[f"layers.{i}.ema_num"] = e.clone(), e * init, torch.ones(K) * init
+    for step in range(3):
+        zs = torch.from_numpy(synth.normalish(75 + step, 2 * D * 40)).view(2, D, 40)
+        q, nr, loss = rvq(zs.to(dev), 2)
+        qo, losso, _ = O.legacy_rvq_train_step(st, zs, 2, nq, decay)
+        assert (q.cpu() - qo).abs().max() < 1e-6 and abs(float(loss) - float(losso)) < 1e-6 * float(losso)
+        assert nr.dtype == np.int64 and not nr.any()
+        for i in range(nq):
+            cbk = rvq.layers[i]._codebook
+            assert torch.equal(cbk.ema_num.cpu(), st[f"layers.{i}.ema_num"])
+            assert (cbk.embed.cpu() - st[f"layers.{i}.embed"]).abs().max() < 1e-5
+    assert torch.equal(rvq.layers[2]._codebook.embed.cpu(), embeds[2])        # n = 2: the third table is untouched
+    # expiry with a threshold: codes below it are replaced by batch vectors and their EMA state is re-initialised
+    rvq_t = ResidualVQ(num_quantizers=1, dim=D, codebook_size=K, decay=0.5, ema_num_threshold=0.3,
+                       ema_num_initial=init).train().to(dev)
+    rvq_t.layers[0]._codebook.embed.copy_(embeds[0])
+    rvq_t.layers[0]._codebook.ema_embed.copy_(embeds[0] * init)
+    _, nr, _ = rvq_t(z.to(dev))
+    cbk = rvq_t.layers[0]._codebook
+    assert nr[0] > 0 and int((cbk.ema_num == init).sum()) >= nr[0]
+    flat = z.transpose(1, 2).reshape(-1, D)
+    replaced = (cbk.ema_num.cpu() == init).nonzero().squeeze(1)[:8]
+    for r in replaced.tolist():
+        assert (flat == cbk.embed[r].cpu()).all(dim=1).any()                   # a vector of this very batch

@@ -161,7 +161,7 @@ def test_stream_driver_protocol(tmp_path):
     path = str(tmp_path / "hil_speech_quantized.npy")
     wire.save_indices_npy(path, idx1)
     assert np.load(path).dtype == np.int16
-    timer = SD.Timer(24000)
+    timer = SD.StageClock(24000)
     w1, _ = SD.decode_stream(model, wire.load_indices_npy(path), 8, num_frames=1, timer=timer)
     w3, _ = SD.decode_stream(model, idx1, 8, num_frames=3)
     assert w1.shape == (2, 1, 4800) and (w1 - w3).abs().max() < 2e-6

@@ -126,3 +126,39 @@ def test_rvq_training_branch(ref):
         for i in range(2):
             assert torch.equal(expired[i], rvq.layers[i].ema_num < 0.46)
     assert expired.any()          # after three steps at decay 0.9 unused codes have dropped below 0.46
+
+
+@pytest.mark.parametrize("threshold", [0.0, 0.46])
+def test_legacy_rvq_training_branch(ref, threshold):
+    """oracle.legacy_rvq_train_step vs the reference's older ResidualVQ in train mode: Laplace-smoothed division
+    without an expiry threshold, plain division + expiry masks with one."""
+    D, K, nq, decay, init = 128, 1024, 3, 0.9, 0.5
+    rvq = ref.vq_old.ResidualVQ(num_quantizers=nq, dropout=False, dim=D, codebook_size=K, kmeans_init=False,
+                                decay=decay, ema_num_threshold=0.0, ema_num_initial=init).train()
+    st = {}
+    for i in range(nq):
+        e = torch.from_numpy(synth.normalish(820 + i, K * D) * np.float32(0.3)).view(K, D)
+        cbk = rvq.layers[i]._codebook
+        cbk.embed.copy_(e)
+        cbk.ema_embed.copy_(e * init)
+        st[f"layers.{i}.embed"] = e.clone()
+        st[f"layers.{i}.ema_embed"] = e * init
+        st[f"layers.{i}.ema_num"] = torch.ones(K) * init
+    for step in range(3):
+        z = torch.from_numpy(synth.normalish(75 + step, 2 * D * 40)).view(2, D, 40)
+        q, nr, loss = rvq(z, 2)
+        # the reference runs without a threshold (its replacement vectors are random); the oracle's division rule
+        # follows `threshold`, so the smoothed form is compared at 0.0 and only the masks at 0.46
+        qo, losso, expired = O.legacy_rvq_train_step(st if threshold == 0.0 else {k: v.clone() for k, v in st.items()},
+                                                     z, 2, nq, decay, ema_num_threshold=threshold)
+        if threshold == 0.0:
+            assert torch.equal(q, qo) and float(loss) == float(losso)
+            for i in range(nq):
+                assert torch.equal(rvq.layers[i]._codebook.embed, st[f"layers.{i}.embed"])
+                assert torch.equal(rvq.layers[i]._codebook.ema_num, st[f"layers.{i}.ema_num"])
+        else:
+            for i in range(nq):           # keep the oracle's state in lock-step with the reference's buffers
+                for k in ("embed", "ema_embed", "ema_num"):
+                    st[f"layers.{i}.{k}"] = getattr(rvq.layers[i]._codebook, k).clone()
+            for i in range(2):
+                assert torch.equal(expired[i], rvq.layers[i]._codebook.ema_num < 0.46)

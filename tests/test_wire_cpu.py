@@ -12,18 +12,23 @@ REF_ONNX = "/root/reference/onnx"
 
 
 def test_index_npy_roundtrip(tmp_path):
-    idx = torch.randint(0, 1024, (8, 3, 17))
+    idx = torch.randint(0, 1024, (8, 3, 17), generator=torch.Generator().manual_seed(11))
     p = str(tmp_path / "q.npy")
     wire.save_indices_npy(p, idx)
     raw = np.load(p)
     assert raw.dtype == np.int16 and raw.shape == (8, 3, 17)          # test_onnx.py:96-100
     assert torch.equal(wire.load_indices_npy(p), idx)
+    bad = idx.clone()
+    bad[0, 0, 0] = -1                                                  # explicit out-of-range entries, both ends
     with pytest.raises(ValueError):
-        wire.save_indices_npy(p, idx - 5)
+        wire.save_indices_npy(p, bad)
+    bad[0, 0, 0] = 1 << 15
+    with pytest.raises(ValueError):
+        wire.save_indices_npy(p, bad)
 
 
 def test_10bit_packing():
-    idx = torch.randint(0, 1024, (12, 2, 75))
+    idx = torch.randint(0, 1024, (12, 2, 75), generator=torch.Generator().manual_seed(12))
     blob = wire.pack_indices_10bit(idx)
     assert len(blob) == 12 + (12 * 2 * 75 * 10 + 7) // 8               # 0.75 kbps per codebook at 75 frames/s
     assert torch.equal(wire.unpack_indices_10bit(blob), idx)

@@ -1,7 +1,16 @@
 #!/usr/bin/env python
 """Per-phase s_memtime stamps of hilc_resblock (debug aid): median cycles per phase over all workgroups."""
-import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the stamp hook is compiled out of the product library (it would be process-global state): build a debug copy
+DBG = os.path.join(ROOT, "gpurun_out", "libhilcodec_amd_stamps.so")
+if not os.path.isfile(DBG):
+    os.makedirs(os.path.dirname(DBG), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                    "-DHILC_DEBUG_STAMPS", "-o", DBG] + sorted(glob.glob(os.path.join(ROOT, "hilcodec_amd", "csrc", "*.hip"))),
+                   check=True)
+os.environ["HILC_LIB"] = DBG
 import torch
 from hilcodec_amd import ops
 from hilcodec_amd._lib import lib
