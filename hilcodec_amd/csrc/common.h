@@ -29,6 +29,9 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
 // i.e. one fp32 ulp of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on
 // a dense grid) — relative accuracy near 0- is given up, which a following dot product cannot see.
 __device__ __forceinline__ float elu_fast(float x) {
+#ifdef HILC_ELU_EXPM1
+  return x > 0.0f ? x : expm1f(x);   // A/B build for the parity census (tools/census_run.sh): torch's own ELU form
+#endif
   const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f);
   return x > 0.0f ? x : e - 1.0f;
 }

@@ -39,6 +39,8 @@ class ResBlockSpec:
     dw2_b: Optional[Tensor]
     pre_scale: float        # (1 + idx*res_scale^2)^-1/2  (seanet.py:84), 1.0 in the streaming decoder
     out_scale: float        # res_scale * res_scale_param (seanet.py:144-148); 1.0 when merged into dw2
+    pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec), C <= 192 only
+    pw2_packed: Optional[Tensor] = None
 
 
 @dataclass
@@ -88,6 +90,7 @@ class DecStageSpec:
     pw_wt: Tensor
     pw_b: Optional[Tensor]
     blocks: List[ResBlockSpec]
+    taps: Optional[Tensor] = None         # expanded tap table for strides without a vector tap path (finalize_spec)
 
 
 @dataclass
@@ -114,6 +117,39 @@ class RvqSpec:
         return self.codebooks.shape[0]
 
 
+def finalize_block(rb: "ResBlockSpec") -> "ResBlockSpec":
+    c = rb.pw1_wt.shape[0]
+    if (rb.pw1_packed is None and rb.pw1_wt.device.type in ("cuda", "meta") and rb.pw1_wt.shape[1] == c and c <= FUSE_RESBLOCK_MAX_C
+            and ops.resblock_supported(c, 4)):
+        rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
+        rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
+    return rb
+
+
+def finalize_spec(spec):
+    """Device-side, one-off derived tables of an Encoder/DecoderSpec whose tensors already live on the GPU: packed
+    pointwise weights of the fused residual blocks, expanded up-sampling taps.  (They used to be hidden caches keyed
+    by data_ptr inside the op wrappers; as part of the spec they are plain graph inputs for torch.compile.)"""
+    for st in spec.stages:
+        for rb in st.blocks:
+            finalize_block(rb)
+        if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
+            st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
+    return spec
+
+
+def spec_to(spec, device):
+    """Copy of a spec (any of the dataclasses above, nested) with every tensor moved to `device`."""
+    import dataclasses
+    if isinstance(spec, Tensor):
+        return spec.to(device)
+    if isinstance(spec, list):
+        return [spec_to(v, device) for v in spec]
+    if dataclasses.is_dataclass(spec):
+        return type(spec)(**{f.name: spec_to(getattr(spec, f.name), device) for f in dataclasses.fields(spec)})
+    return spec
+
+
 def _to(dev, *ts):
     return [None if t is None else t.to(device=dev, dtype=torch.float32).contiguous() for t in ts]
 
@@ -121,82 +157,100 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
-def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list]) -> Tensor:
-    """Returns the block output (x itself, updated in place, on the un-fused / two-launch paths)."""
-    if (caches is None and FUSE_RESBLOCK and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-            and rb.dw1_b is not None and rb.dw2_b is not None
-            and x.shape[1] <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(x.shape[1], x.shape[2])):
+def _fusable(rb: ResBlockSpec, x: Tensor) -> bool:
+    return (FUSE_RESBLOCK and rb.pw1_packed is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
+            and rb.dw1_b is not None and rb.dw2_b is not None and x.shape[1] <= FUSE_RESBLOCK_MAX_C
+            and ops.resblock_supported(x.shape[1], x.shape[2]))
+
+
+def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list],
+              outs: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """One residual block; streaming: `caches` = its two depthwise caches, `outs` = where the next hop's caches go
+    (persistent state block) or None (fresh tensors, the reference's protocol)."""
+    o0, o1 = (outs[0], outs[1]) if outs is not None else (None, None)
+    if caches is None and _fusable(rb, x):
         # one launch per block: x is read once, y written once, everything else stays in LDS
-        return ops.resblock(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, rb.pw2_wt, rb.dw2_w, rb.dw2_b,
+        return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
-    if (caches is not None and FUSE_RESBLOCK and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-            and rb.dw1_b is not None and rb.dw2_b is not None and x.shape[2] >= 4
-            and x.shape[1] <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(x.shape[1], x.shape[2])):
+    if caches is not None and x.shape[2] >= 4 and _fusable(rb, x):
         # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns
-        y, cs = ops.resblock(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, rb.pw2_wt, rb.dw2_w, rb.dw2_b,
-                             rb.pre_scale, rb.out_scale, hist=(caches[0].contiguous(), caches[1].contiguous()))
+        y, cs = ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
+                             rb.pre_scale, rb.out_scale, hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
         return y
     if (caches is not None and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], rb.dw1_w.shape[1], 1)
             and ops.dws_conv_stream_profitable(x.shape[2], rb.dw2_w.shape[1], 1)):
         # wide layers of a streaming hop (T <= 128): two launches, whole-clip tiles, caches read/written in the epilogue
-        g, c0 = ops.dws_conv_stream(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, caches[0].contiguous(), in_scale=rb.pre_scale,
-                                    in_elu=True, out_elu=True)
-        y, c1 = ops.dws_conv_stream(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, caches[1].contiguous(), res=x,
-                                    out_scale=rb.out_scale, out=x)
+        g, c0 = ops.dws_conv_stream(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, caches[0], in_scale=rb.pre_scale,
+                                    in_elu=True, out_elu=True, hist_out=o0)
+        y, c1 = ops.dws_conv_stream(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, caches[1], res=x,
+                                    out_scale=rb.out_scale, hist_out=o1)
         new_caches.extend([c0, c1])
         return y
     if caches is None and FUSE_DWS and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5:
         # two launches per block: [ELU, pw, dw, ELU] and [pw, dw, *scale + shortcut]; the pointwise
         # outputs never leave LDS
         g = ops.dws_conv(x, rb.pw1_wt, rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
-        return ops.dws_conv(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x)
+        return ops.dws_conv(g, rb.pw2_wt, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
     h = ops.pw_conv(x, rb.pw1_wt, in_scale=rb.pre_scale, in_elu=True)
     if caches is None:
-        g = ops.dw_conv(h, rb.dw1_w, rb.dw1_b)            # a depthwise conv must not run in place (halo reads)
-        h2 = ops.pw_conv(g, rb.pw2_wt, in_scale=1.0, in_elu=True, out=h)
-        ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x)
-    else:
-        g, c0 = ops.dw_conv(h, rb.dw1_w, rb.dw1_b, hist=caches[0], want_hist=True)
+        g = ops.dw_conv(h, rb.dw1_w, rb.dw1_b)
         h2 = ops.pw_conv(g, rb.pw2_wt, in_scale=1.0, in_elu=True)
-        _, c1 = ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, out=x,
-                            hist=caches[1], want_hist=True)
-        new_caches.extend([c0, c1])
-    return x
+        return ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
+    g, c0 = ops.dw_conv(h, rb.dw1_w, rb.dw1_b, hist=caches[0], want_hist=True, hist_out=o0)
+    h2 = ops.pw_conv(g, rb.pw2_wt, in_scale=1.0, in_elu=True)
+    y, c1 = ops.dw_conv(h2, rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale, hist=caches[1], want_hist=True,
+                        hist_out=o1)
+    new_caches.extend([c0, c1])
+    return y
 
 
 def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
     s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
-    return ops.pw_conv(s, sb.wt, sb.bias, res=x, out=x, out_scale=sb.out_scale)
+    return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
+
+
+def _contig(caches: Optional[Sequence[Tensor]]):
+    return None if caches is None else [c.contiguous() for c in caches]
 
 
 def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]] = None,
-                channel_last_out: bool = False):
-    """wav `[B,1,T]` -> z `[B,dim,ceil(T/hop)]` (or `[B,T',dim]`), and the new cache list if streaming."""
+                channel_last_out: bool = False, caches_out: Optional[Sequence[Tensor]] = None):
+    """wav `[B,1,T]` -> z `[B,dim,ceil(T/hop)]` (or `[B,T',dim]`), and the new cache list if streaming.
+    `caches_out` (streaming, optional): persistent buffers, same shapes as `caches` and distinct from them, that
+    receive the next hop's caches (ping-pong state block); without it every cache is a fresh tensor, which is the
+    reference's protocol (`streaming.py:482-517`: cache_out never aliases cache_in)."""
     if wav.dim() != 3 or wav.shape[1] != 1:
         raise RuntimeError(f"expected [B,1,T] waveform, got {tuple(wav.shape)}")
     wav = wav.contiguous().float()
     streaming = caches is not None
+    caches = _contig(caches)
     new_caches: Optional[list] = [] if streaming else None
+
+    def out(i):
+        return caches_out[i] if caches_out is not None else None
+
     wav_hist = None
     ci = 0
     if streaming:
-        wav_hist = caches[0].contiguous()
-        new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len))
+        wav_hist = caches[0]
+        new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
         ci = 1
     x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
     for st in es.stages:
         x = _spec_block(st.spec, x, wav, wav_hist)
         for rb in st.blocks:
-            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
+            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
+                          caches_out[ci:ci + 2] if caches_out is not None else None)
             ci += 2
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
-            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci].contiguous(),
-                                       stride=st.ratio, in_scale=st.down_in_scale, in_elu=True)
+            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci],
+                                       stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
         elif streaming:
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
-            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True)
+            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True,
+                               hist_out=out(ci))
             new_caches.append(c)
         elif FUSE_DWS and st.down_dw_w.shape[1] == 2 * st.ratio:
             x = ops.dws_conv(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, stride=st.ratio,
@@ -207,7 +261,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         ci += 1
     x = _spec_block(es.spec_post, x, wav, wav_hist)
     if streaming:
-        h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True)
+        h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)
     else:
         h = ops.dw_conv(x, es.post_dw_w, None, in_elu=True)
@@ -219,18 +273,25 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
     return (z, new_caches) if streaming else z
 
 
-def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] = None):
-    """q `[B,dim,F]` (channel-major) -> wav `[B,1,F*hop]`, and the new cache list if streaming."""
+def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] = None,
+                caches_out: Optional[Sequence[Tensor]] = None):
+    """q `[B,dim,F]` (channel-major) -> wav `[B,1,F*hop]`, and the new cache list if streaming (`caches_out` as in
+    run_encoder)."""
     streaming = caches is not None
+    caches = _contig(caches)
     new_caches: Optional[list] = [] if streaming else None
+
+    def out(i):
+        return caches_out[i] if caches_out is not None else None
+
     q = q.contiguous().float()
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
-        x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0].contiguous())
+        x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
         new_caches.append(c)
     elif streaming:
         h = ops.pw_conv(q, ds.pre_pw_wt)
-        x, c = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b, hist=caches[0], want_hist=True)
+        x, c = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b, hist=caches[0], want_hist=True, hist_out=out(0))
         new_caches.append(c)
     elif FUSE_DWS and ds.pre_dw_w.shape[1] == 5:
         x = ops.dws_conv(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b)
@@ -239,30 +300,31 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         x = ops.dw_conv(h, ds.pre_dw_w, ds.pre_dw_b)
     ci = 1
     for st in ds.stages:
+        fused_up = FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0
         if streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
             x, c = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True,
-                               hist=caches[ci].contiguous(), want_hist=True)
+                               hist=caches[ci], want_hist=True, taps=st.taps, hist_out=out(ci))
             new_caches.append(c)
-            u = x                # already through the pointwise conv
         elif streaming:
             u, c = ops.dw_convtr(x, st.tr_w, st.ratio, hist=caches[ci], want_hist=True,
-                                 in_scale=st.in_scale, in_elu=True)
+                                 in_scale=st.in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
-        elif FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0:
-            u = None     # the up-sampled tensor only exists inside the GEMM's loader
+            x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        elif fused_up:
+            # the up-sampled tensor only exists inside the GEMM's loader
+            x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True, taps=st.taps)
         else:
             u = ops.dw_convtr(x, st.tr_w, st.ratio, in_scale=st.in_scale, in_elu=True)
-        ci += 1
-        if u is None:
-            x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True)
-        elif u is not x:
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        ci += 1
         for rb in st.blocks:
-            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches)
+            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
+                          caches_out[ci:ci + 2] if caches_out is not None else None)
             ci += 2
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
-                               out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True)
+                               out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True,
+                               hist_out=out(ci))
         new_caches.append(c)
         return wav, new_caches
     return ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,

@@ -1,12 +1,16 @@
-"""HIP-graph replay of one streaming hop (encoder -> RVQ -> dequantiser -> decoder with all 52 caches).
+"""HIP-graph replay of one streaming hop (encoder -> RVQ -> dequantiser -> decoder with all 52 caches) over a
+persistent, ping-pong state block in HBM.
 
-A hop for 1024 streams is ~60 kernel launches of 30-400 us each: the GPU work is ~7.9 ms, the host needs another
-~0.3 ms to issue it and the gaps between short kernels are visible.  The hop is shape-static, so it is captured
-once into a graph whose inputs (the hop's samples, the caches) and outputs live at fixed addresses; a replay is one
-launch.  The caches written by the hop are copied back onto the input caches inside the graph (one multi-tensor
-copy), so consecutive replays chain exactly like the eager loop of `test_onnx.py:75-93,123-135`.
+A hop for 1024 streams is ~60 kernel launches of 30-400 us each; the hop is shape-static, so it is captured once into
+a graph whose inputs (the hop's samples, the caches) and outputs live at fixed addresses, and a replay is one launch.
 
-The captured kernels are the same launches the eager path issues (same C-ABI calls on the capture stream), so a
+State: every cache exists twice, as views into two contiguous HBM blocks A and B (22 + 30 caches per stream, 313 MB
+per block at 1024 streams).  The reference returns the new caches as fresh tensors (`streaming.py:482-517,619-648`);
+here the kernels of an even hop read A and write B, those of an odd hop read B and write A (`cache_out=` of the
+streaming Encoder / Decoder), so a hop moves no cache bytes beyond what its kernels read and write — no allocation, no
+copy-back.  Two graphs are captured (A->B and B->A) and replayed alternately.
+
+The captured kernels are the same launches the eager path issues (same custom ops on the capture stream), so a
 replayed hop is bit-identical to an eager hop (tests/test_gpu_streaming.py)."""
 from __future__ import annotations
 
@@ -16,51 +20,100 @@ import torch
 from torch import Tensor
 
 
+class StateBlock:
+    """The 22 + 30 caches of `batch` streams as views into ONE contiguous fp32 buffer (16-B aligned slices)."""
+
+    def __init__(self, model, batch: int, device: torch.device):
+        probe = torch.zeros(batch, 1, 1, device=device)
+        ce, cd = model.initialize_cache(probe)
+        shapes = [tuple(c.shape) for c in list(ce) + list(cd)]
+        offs, total = [], 0
+        for s in shapes:
+            offs.append(total)
+            n = 1
+            for d in s:
+                n *= d
+            total += (n + 3) // 4 * 4
+        self.buffer = torch.zeros(total, device=device, dtype=torch.float32)
+        views = []
+        for s, o in zip(shapes, offs):
+            n = 1
+            for d in s:
+                n *= d
+            views.append(self.buffer[o:o + n].view(s))
+        self.enc: List[Tensor] = views[:len(ce)]
+        self.dec: List[Tensor] = views[len(ce):]
+
+    def zero_(self) -> None:
+        self.buffer.zero_()
+
+    def load_(self, cache_enc: Optional[Sequence[Tensor]], cache_dec: Optional[Sequence[Tensor]]) -> None:
+        for dst, src in ((self.enc, cache_enc), (self.dec, cache_dec)):
+            for i, c in enumerate(dst):
+                c.zero_() if src is None else c.copy_(src[i])
+
+    @property
+    def nbytes(self) -> int:
+        return self.buffer.numel() * 4
+
+
 class GraphedHop:
     """model: `hilcodec_amd.models.hilcodec.streaming.HILCodec` (eval, reparameterisations removed).
     `step(x)` consumes `[B,1,hop]` samples (copied into the static input) and returns (indices `[n,B,T]`, wav `[B,1,hop]`)
-    as views of static buffers that the next `step` overwrites."""
+    as views of static buffers that a later `step` overwrites (each parity has its own pair)."""
 
-    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 3):
+    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 2):
         self.model, self.n = model, n
         self.device = device
         self.x = torch.zeros(batch, 1, hop, device=device)
-        ce, cd = model.initialize_cache(self.x)
-        self.cache_enc: List[Tensor] = [c.contiguous() for c in ce]
-        self.cache_dec: List[Tensor] = [c.contiguous() for c in cd]
-        self.idx: Optional[Tensor] = None
-        self.wav: Optional[Tensor] = None
+        self.state = (StateBlock(model, batch, device), StateBlock(model, batch, device))
+        self.parity = 0                       # the block holding the CURRENT caches (input of the next hop)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):          # builds every lazily cached table (folded weights, codebooks, scheduler words)
-                self._hop()
-            for c in self.cache_enc + self.cache_dec:
-                c.zero_()
+                self._hop(0)
+                self._hop(1)
+            self.state[0].zero_()
+            self.state[1].zero_()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.idx, self.wav = self._hop()
+        self.graphs, self.outs = [], []
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                out = self._hop(p)
+            self.graphs.append(g)
+            self.outs.append(out)
+        self.state[0].zero_()
+        self.state[1].zero_()
 
-    def _hop(self) -> Tuple[Tensor, Tensor]:
+    def _hop(self, p: int) -> Tuple[Tensor, Tensor]:
         m = self.model
-        z, ce = m.encoder(self.x, *self.cache_enc)
+        src, dst = self.state[p], self.state[p ^ 1]
+        z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
         idx = m.quantizer(z, self.n)
         q = m.dequantizer(idx, self.n)
-        wav, cd = m.decoder(q, *self.cache_dec)
-        torch._foreach_copy_(self.cache_enc + self.cache_dec, list(ce) + list(cd))
+        wav, _ = m.decoder(q, *src.dec, cache_out=dst.dec)
         return idx, wav
+
+    @property
+    def cache_enc(self) -> List[Tensor]:
+        return self.state[self.parity].enc
+
+    @property
+    def cache_dec(self) -> List[Tensor]:
+        return self.state[self.parity].dec
 
     def reset(self, cache_enc: Optional[Sequence[Tensor]] = None, cache_dec: Optional[Sequence[Tensor]] = None) -> None:
         """zero history, or resume from caches saved earlier (`wire.save_cache` / `e_in*`, `d_in*`)"""
         with torch.no_grad():
-            for i, c in enumerate(self.cache_enc):
-                c.zero_() if cache_enc is None else c.copy_(cache_enc[i])
-            for i, c in enumerate(self.cache_dec):
-                c.zero_() if cache_dec is None else c.copy_(cache_dec[i])
+            self.parity = 0
+            self.state[0].load_(cache_enc, cache_dec)
 
     def step(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         self.x.copy_(x)
-        self.graph.replay()
-        return self.idx, self.wav
+        self.graphs[self.parity].replay()
+        out = self.outs[self.parity]
+        self.parity ^= 1
+        return out

@@ -106,8 +106,8 @@ class SEANetResnetBlock(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def forward(self, x: Tensor) -> Tensor:
-        sp = self._cache.get((str(x.device), self._key()), lambda: self.spec(x.device))
-        return engine._resblock(sp, x.contiguous().float().clone(), None, None)
+        sp = self._cache.get((str(x.device), self._key()), lambda: engine.finalize_block(self.spec(x.device)))
+        return engine._resblock(sp, x.contiguous().float(), None, None)
 
 
 class L2Norm(nn.Module):
@@ -183,11 +183,23 @@ class _PlanModule(nn.Module):
         return (str(dev),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def plan(self, dev):
+        if torch.compiler.is_compiling():
+            # inside torch.compile the folded plan is a constant of the graph: fold (host work, data_ptr keys) cannot be
+            # traced, so it must exist already — `prepare(device)` or any earlier eager call builds it
+            cached = getattr(self, "_plan_cache", None)
+            if cached is None:
+                raise RuntimeError("call .prepare(device) (or run the module once eagerly) before torch.compile")
+            return cached
         key = self._plan_key(dev)
         if getattr(self, "_plan_cache_key", None) != key:
-            self._plan_cache = self.build_spec(dev)
+            self._plan_cache = engine.finalize_spec(self.build_spec(dev))
             self._plan_cache_key = key
         return self._plan_cache
+
+    def prepare(self, dev):
+        """Fold the weights for `dev` now (otherwise done lazily by the first forward)."""
+        self.plan(torch.device(dev))
+        return self
 
 
 class SEANetEncoder(_PlanModule):

@@ -52,6 +52,10 @@ class EuclideanCodebook(nn.Module):
 
 class _CodebookStack(nn.Module):
     def _tables(self, dev) -> engine.RvqSpec:
+        if torch.compiler.is_compiling():      # the device tables are constants of a compiled graph (see _PlanModule.plan)
+            if getattr(self, "_spec", None) is None:
+                raise RuntimeError("run the quantizer once eagerly before torch.compile")
+            return self._spec
         key = (str(dev),) + tuple((l.embed.data_ptr(), l.embed._version) for l in self.layers)
         if getattr(self, "_key", None) != key:
             cb, cbt, norms = fold.codebook_tables([l.embed for l in self.layers])
@@ -174,7 +178,7 @@ class ResBlock(nn.Module):
 
     def forward(self, x: Tensor, cache: tp.List[Tensor]) -> tp.Tuple[Tensor, tp.List[Tensor]]:
         new_cache: tp.List[Tensor] = []
-        y = engine._resblock(self.spec(x.device), x.contiguous().float().clone(), cache, new_cache)
+        y = engine._resblock(engine.finalize_block(self.spec(x.device)), x.contiguous().float(), cache, new_cache)
         return y, new_cache
 
 
@@ -344,10 +348,13 @@ class Encoder(_PlanModule):
         flags = (self.merged,) + tuple(m.merged for m in self.modules() if isinstance(m, (ResBlock, SpecBlock)))
         return super()._plan_key(dev) + flags
 
-    def forward(self, x: Tensor, *args) -> tp.Tuple[Tensor, tp.List[Tensor]]:
+    def forward(self, x: Tensor, *args, cache_out: tp.Optional[tp.Sequence[Tensor]] = None
+                ) -> tp.Tuple[Tensor, tp.List[Tensor]]:
+        """`cache_out` (extension): persistent buffers that receive the new caches (ping-pong state block in HBM);
+        without it the new caches are fresh tensors, as in the reference."""
         if len(args) != self.num_cache:
             raise RuntimeError(f"expected {self.num_cache} cache tensors, got {len(args)}")
-        return engine.run_encoder(self.plan(x.device), x, list(args), channel_last_out=True)
+        return engine.run_encoder(self.plan(x.device), x, list(args), channel_last_out=True, caches_out=cache_out)
 
 
 class Decoder(_PlanModule):
@@ -430,9 +437,10 @@ class Decoder(_PlanModule):
         flags = (self.merged,) + tuple(m.merged for m in self.modules() if isinstance(m, ResBlock))
         return super()._plan_key(dev) + flags
 
-    def forward(self, x: Tensor, *args) -> tp.Tuple[Tensor, tp.List[Tensor]]:
+    def forward(self, x: Tensor, *args, cache_out: tp.Optional[tp.Sequence[Tensor]] = None
+                ) -> tp.Tuple[Tensor, tp.List[Tensor]]:
         q = x.float().transpose(1, 2).contiguous()       # [B,T',C] -> [B,C,T'] (layout copy only)
-        return engine.run_decoder(self.plan(x.device), q, list(args))
+        return engine.run_decoder(self.plan(x.device), q, list(args), caches_out=cache_out)
 
 
 class HILCodec(nn.Module):

@@ -98,6 +98,10 @@ class ResidualVQ(nn.Module):
         self._spec = None
 
     def spec(self, dev) -> engine.RvqSpec:
+        if torch.compiler.is_compiling():      # the device tables are constants of a compiled graph (see _PlanModule.plan)
+            if getattr(self, "_spec", None) is None:
+                raise RuntimeError("run the quantizer once eagerly before torch.compile")
+            return self._spec
         key = (str(dev),) + tuple((l.embed.data_ptr(), l.embed._version) for l in self.layers)
         if key != self._key:
             cb, cbt, norms = fold.codebook_tables([l.embed for l in self.layers])

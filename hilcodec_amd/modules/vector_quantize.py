@@ -151,6 +151,10 @@ class ResidualVQ(nn.Module):
         self._spec = None
 
     def spec(self, dev) -> engine.RvqSpec:
+        if torch.compiler.is_compiling():      # the device tables are constants of a compiled graph (see _PlanModule.plan)
+            if getattr(self, "_spec", None) is None:
+                raise RuntimeError("run the quantizer once eagerly before torch.compile")
+            return self._spec
         embeds = [l._codebook.embed for l in self.layers]
         key = (str(dev),) + tuple((e.data_ptr(), e._version) for e in embeds)
         if key != self._key:

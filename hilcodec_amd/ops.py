@@ -1,18 +1,28 @@
-"""Thin Python wrappers: torch CUDA(HIP) tensors -> device pointers -> C ABI (`include/hilcodec_amd.h`).
+"""PyTorch-ROCm custom ops (`torch.ops.hilcodec.*`) over the C ABI of `include/hilcodec_amd.h`.
 
-PyTorch is used for device memory and the current stream only; every arithmetic step runs in the
-hand-written gfx950 kernels of `csrc/`.  All tensors must be fp32 (indices int64), contiguous, on a
-GPU; anything else raises — there is deliberately no fallback path."""
+Every entry point of the hot path is registered with the dispatcher through `torch.library`:
+  * schema + a CUDA(HIP) implementation = torch tensors -> device pointers -> the hand-written gfx950 kernels
+    (ctypes launch on the current HIP stream; PyTorch supplies memory and the stream, no arithmetic);
+  * a CPU implementation that raises (there is deliberately no fallback path);
+  * a fake (meta) implementation = the op's shape function,
+so the module classes are ordinary traceable `nn.Module`s like the reference's (`torch.compile(fullgraph=True)`,
+`torch.export`, HIP-graph capture all see plain ops).  All ops are functional (outputs are fresh tensors) except where
+a caller hands in persistent streaming state to be overwritten (`hist_out` arguments, declared as mutated).
+
+The public functions below are what `engine.py` and the module classes call; they only normalise arguments and
+dispatch through `torch.ops.hilcodec`.  All tensors must be fp32 (indices int64), contiguous, on a GPU."""
 from __future__ import annotations
 
 import numbers
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 from torch import Tensor
 
 from ._lib import check, lib
+
+_LIB = torch.library.Library("hilcodec", "DEF")
 
 
 def _ptr(t: Optional[Tensor], dtype=torch.float32) -> Optional[int]:
@@ -29,6 +39,10 @@ def _ptr(t: Optional[Tensor], dtype=torch.float32) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _new(ref: Tensor, *shape, dtype=torch.float32) -> Tensor:
+    return torch.empty(shape, device=ref.device, dtype=dtype)
 
 
 class LaunchTimer:
@@ -69,136 +83,118 @@ class _timed:
         return False
 
 
-def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
-            out: Optional[Tensor] = None, in_scale: float = 1.0, in_elu: bool = False,
-            out_scale: float = 1.0) -> Tensor:
-    """x `[B,K,T]`, wt `[K,M]` -> `[B,M,T]`; see hilc_pw_conv."""
+def _no_cpu(*_a, **_k):
+    raise RuntimeError("hilcodec_amd ops need GPU tensors (no CPU fallback)")
+
+
+def _register(name: str, schema: str, impl, fake) -> None:
+    _LIB.define(f"{name}{schema}")
+    _LIB.impl(name, impl, "CUDA")
+    _LIB.impl(name, _no_cpu, "CPU")
+    torch.library.register_fake(f"hilcodec::{name}", fake, lib=_LIB)
+
+
+# ======================================================================================================
+# GEMM family
+# ======================================================================================================
+def _pw_conv(x, wt, bias, res, in_scale, in_elu, out_scale):
     B, K, T = x.shape
     M = wt.shape[1]
-    assert wt.shape[0] == K
-    y = out if out is not None else torch.empty(B, M, T, device=x.device, dtype=torch.float32)
+    if wt.shape[0] != K:
+        raise RuntimeError(f"pw_conv: weight rows {wt.shape[0]} != input channels {K}")
+    y = _new(x, B, M, T)
     with _timed("pw_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T}"):
         check(lib.hilc_pw_conv(_ptr(x), _ptr(wt), _ptr(bias), _ptr(res), _ptr(y), B, K, M, T,
                                in_scale, int(in_elu), out_scale, _stream()), "hilc_pw_conv")
     return y
 
 
-def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None, res: Optional[Tensor] = None,
-             stride: int = 1, in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0,
-             out_elu: bool = False, out: Optional[Tensor] = None) -> Tensor:
-    """Fused pointwise -> depthwise causal conv (offline): x `[B,K,T]`, wt `[K,M]`, dw_w `[M,k]` ->
-    `[B,M,ceil(T/stride)]`; see hilc_dws_conv."""
+_register("pw_conv", "(Tensor x, Tensor wt, Tensor? bias, Tensor? res, float in_scale, bool in_elu, float out_scale)"
+          " -> Tensor", _pw_conv,
+          lambda x, wt, bias, res, in_scale, in_elu, out_scale: x.new_empty(x.shape[0], wt.shape[1], x.shape[2]))
+
+
+def _dws_conv(x, wt, dw_w, dw_b, res, stride, in_scale, in_elu, out_scale, out_elu):
     B, K, T = x.shape
-    M = wt.shape[1]
-    k = dw_w.shape[1]
+    M, k = wt.shape[1], dw_w.shape[1]
     To = (T + stride - 1) // stride
-    y = out if out is not None else torch.empty(B, M, To, device=x.device, dtype=torch.float32)
+    y = _new(x, B, M, To)
     with _timed("dws_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k{k} s{stride}"):
         check(lib.hilc_dws_conv(_ptr(x), _ptr(wt), _ptr(dw_w), _ptr(dw_b), _ptr(res), _ptr(y), B, K, M, T, k,
                                 stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()), "hilc_dws_conv")
     return y
 
 
-def dws_conv_stream_supported(T: int, k: int, stride: int) -> bool:
-    """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride"""
-    return T <= 128 and T % stride == 0 and stride <= k <= 32
+_register("dws_conv", "(Tensor x, Tensor wt, Tensor dw_w, Tensor? dw_b, Tensor? res, int stride, float in_scale, "
+          "bool in_elu, float out_scale, bool out_elu) -> Tensor", _dws_conv,
+          lambda x, wt, dw_w, dw_b, res, stride, in_scale, in_elu, out_scale, out_elu:
+          x.new_empty(x.shape[0], wt.shape[1], (x.shape[2] + stride - 1) // stride))
 
 
-def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
-    """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
-    --mode streaming): not for single-sample hops, whose depthwise taps are nearly all cache reads."""
-    return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
-
-
-def dws_conv_stream(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
-                    res: Optional[Tensor] = None, stride: int = 1, in_scale: float = 1.0, in_elu: bool = False,
-                    out_scale: float = 1.0, out_elu: bool = False, out: Optional[Tensor] = None):
-    """Streaming hop of a depthwise-separable block (hilc_dws_conv_stream): x `[B,K,T]`, T <= 128, cache
-    `[B,M,k-stride]` (last pointwise outputs of the previous hop) -> (y `[B,M,T/stride]`, new cache)."""
+def _dws_conv_stream(x, wt, dw_w, dw_b, hist, hist_out, res, stride, in_scale, in_elu, out_scale, out_elu):
     B, K, T = x.shape
-    M = wt.shape[1]
-    k = dw_w.shape[1]
+    M, k = wt.shape[1], dw_w.shape[1]
     pad = k - stride
-    if hist is not None and tuple(hist.shape) != (B, M, pad):
-        raise RuntimeError(f"cache must be [{B},{M},{pad}], got {tuple(hist.shape)}")
-    y = out if out is not None else torch.empty(B, M, T // stride, device=x.device, dtype=torch.float32)
-    hout = torch.empty(B, M, pad, device=x.device, dtype=torch.float32)
+    for h in (hist, hist_out):
+        if h is not None and tuple(h.shape) != (B, M, pad):
+            raise RuntimeError(f"cache must be [{B},{M},{pad}], got {tuple(h.shape)}")
+    y = _new(x, B, M, T // stride)
     with _timed("dws_conv", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k{k} s{stride} stream"):
-        check(lib.hilc_dws_conv_stream(_ptr(x), _ptr(wt), _ptr(dw_w), _ptr(dw_b), _ptr(hist), _ptr(hout), _ptr(res),
-                                       _ptr(y), B, K, M, T, k, stride, in_scale, int(in_elu), out_scale,
+        check(lib.hilc_dws_conv_stream(_ptr(x), _ptr(wt), _ptr(dw_w), _ptr(dw_b), _ptr(hist), _ptr(hist_out),
+                                       _ptr(res), _ptr(y), B, K, M, T, k, stride, in_scale, int(in_elu), out_scale,
                                        int(out_elu), _stream()), "hilc_dws_conv_stream")
-    return y, hout
+    return y
 
 
-_TAPS = {}
+_register("dws_conv_stream", "(Tensor x, Tensor wt, Tensor dw_w, Tensor? dw_b, Tensor? hist, Tensor(a!) hist_out, "
+          "Tensor? res, int stride, float in_scale, bool in_elu, float out_scale, bool out_elu) -> Tensor",
+          _dws_conv_stream,
+          lambda x, wt, dw_w, dw_b, hist, hist_out, res, stride, in_scale, in_elu, out_scale, out_elu:
+          x.new_empty(x.shape[0], wt.shape[1], x.shape[2] // stride))
 
 
-def up_conv_taps(tr_w: Tensor, stride: int) -> Optional[Tensor]:
-    """Expanded tap table for strides without a vector tap path (hilc_up_conv_expand_taps), cached per weight tensor."""
-    if stride in (2, 4, 8):
-        return None
-    key = (tr_w.data_ptr(), tr_w._version, tuple(tr_w.shape), tr_w.device.index)
-    hit = _TAPS.get(key)
-    if hit is not None and hit[0]() is tr_w:
-        return hit[1]
+def _up_conv_expand_taps(tr_w, stride):
     K = tr_w.shape[0]
-    out = torch.empty(K * stride * 8, device=tr_w.device, dtype=torch.float32)
+    out = _new(tr_w, K * stride * 8)
     check(lib.hilc_up_conv_expand_taps(_ptr(tr_w), _ptr(out), K, stride, _stream()), "hilc_up_conv_expand_taps")
-    if len(_TAPS) > 64:
-        _TAPS.clear()
-    import weakref
-    _TAPS[key] = (weakref.ref(tr_w), out)
     return out
 
 
-def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
-            in_elu: bool = True, hist: Optional[Tensor] = None, want_hist: bool = False):
-    """Fused [Scale, ELU, depthwise transposed conv (k=2*stride), pointwise conv + bias]:
-    x `[B,K,Tin]`, tr_w `[K,2*stride]`, wt `[K,M]` -> `[B,M,Tin*stride]`; see hilc_up_conv.
-    Streaming: hist `[B,K,1]` = the activated last input frame of the previous hop -> (y, new cache)."""
+_register("up_conv_expand_taps", "(Tensor tr_w, int stride) -> Tensor", _up_conv_expand_taps,
+          lambda tr_w, stride: tr_w.new_empty(tr_w.shape[0] * stride * 8))
+
+
+def _up_conv(x, hist, hist_out, tr_w, taps, wt, bias, stride, in_scale, in_elu):
     B, K, Tin = x.shape
     M = wt.shape[1]
-    y = torch.empty(B, M, Tin * stride, device=x.device, dtype=torch.float32)
-    taps = up_conv_taps(tr_w, stride)
-    if hist is None and not want_hist:
-        with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride}"):
-            check(lib.hilc_up_conv_expanded(_ptr(x), None, None, _ptr(tr_w), _ptr(taps), _ptr(wt), _ptr(bias), _ptr(y),
-                                            B, K, M, Tin, stride, in_scale, int(in_elu), _stream()), "hilc_up_conv")
-        return y
-    if hist is not None and hist.numel() != B * K:
-        raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(hist.shape)}")
-    hout = torch.empty(B, K, 1, device=x.device, dtype=torch.float32) if want_hist else None
-    with _timed("up_conv", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride} stream"):
-        check(lib.hilc_up_conv_expanded(_ptr(x), _ptr(hist), _ptr(hout), _ptr(tr_w), _ptr(taps), _ptr(wt), _ptr(bias),
-                                        _ptr(y), B, K, M, Tin, stride, in_scale, int(in_elu), _stream()),
-              "hilc_up_conv_stream")
-    return (y, hout) if want_hist else y
+    for h in (hist, hist_out):
+        if h is not None and h.numel() != B * K:
+            raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(h.shape)}")
+    y = _new(x, B, M, Tin * stride)
+    with _timed("up_conv", 2.0 * B * Tin * stride * K * M,
+                f"K{K} M{M} Tin{Tin} r{stride}" + (" stream" if hist is not None or hist_out is not None else "")):
+        check(lib.hilc_up_conv_expanded(_ptr(x), _ptr(hist), _ptr(hist_out), _ptr(tr_w), _ptr(taps), _ptr(wt),
+                                        _ptr(bias), _ptr(y), B, K, M, Tin, stride, in_scale, int(in_elu), _stream()),
+              "hilc_up_conv")
+    return y
 
 
-def resblock_supported(C: int, T: int) -> bool:
-    return bool(lib.hilc_resblock_supported(C, T))
+_register("up_conv", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor tr_w, Tensor? taps, Tensor wt, Tensor? bias, "
+          "int stride, float in_scale, bool in_elu) -> Tensor", _up_conv,
+          lambda x, hist, hist_out, tr_w, taps, wt, bias, stride, in_scale, in_elu:
+          x.new_empty(x.shape[0], wt.shape[1], x.shape[2] * stride))
 
 
-_SCHED = {}
-_PACKED = {}
-
-
-def resblock_pack(wt: Tensor) -> Tensor:
-    """k-major `[C,C]` pointwise weights -> the fused block's packed layout (hilc_resblock_pack_weights), cached per
-    weight tensor (same storage and version => same packed copy)."""
-    key = (wt.data_ptr(), wt._version, tuple(wt.shape), wt.device.index)
-    hit = _PACKED.get(key)
-    if hit is not None and hit[0]() is wt:
-        return hit[1]
+def _resblock_pack(wt):
     Cc = wt.shape[0]
-    out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
+    out = _new(wt, Cc * Cc)
     check(lib.hilc_resblock_pack_weights(_ptr(wt), _ptr(out), Cc, _stream()), "hilc_resblock_pack_weights")
-    if len(_PACKED) > 256:
-        _PACKED.clear()
-    import weakref
-    _PACKED[key] = (weakref.ref(wt), out)
     return out
 
+
+_register("resblock_pack", "(Tensor wt) -> Tensor", _resblock_pack, lambda wt: wt.new_empty(wt.shape[0] * wt.shape[0]))
+
+_SCHED = {}
 
 
 def _sched_buffer(device) -> Tensor:
@@ -212,69 +208,71 @@ def _sched_buffer(device) -> Tensor:
     return buf
 
 
-def resblock(x: Tensor, w1t: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2t: Tensor, dw2_w: Tensor, dw2_b: Tensor,
-             pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None):
-    """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`.
-    Streaming: hist = (cache of depthwise 1, cache of depthwise 2), each `[B,C,4]` -> (y, [new caches])."""
+def _resblock(x, w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale):
     B, Cc, T = x.shape
+    streaming = hist1_out is not None or hist1 is not None
+    for h in (hist1, hist2, hist1_out, hist2_out):
+        if h is not None and tuple(h.shape) != (B, Cc, 4):
+            raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h.shape)}")
     y = torch.empty_like(x)
-    w1t, w2t = resblock_pack(w1t), resblock_pack(w2t)
-    if hist is None:
-        with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}"):
-            check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
-                                             _ptr(dw2_b), None, None, None, None, _ptr(y),
-                                             _ptr(_sched_buffer(x.device), torch.int32), 0, B, Cc, T, pre_scale,
-                                             out_scale, _stream()), "hilc_resblock")
-        return y
-    h1, h2 = hist
-    if tuple(h1.shape) != (B, Cc, 4) or tuple(h2.shape) != (B, Cc, 4):
-        raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h1.shape)} / {tuple(h2.shape)}")
-    o1, o2 = torch.empty_like(h1), torch.empty_like(h2)
-    with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} stream"):
-        check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1t), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2t), _ptr(dw2_w),
-                                         _ptr(dw2_b), _ptr(h1), _ptr(h2), _ptr(o1), _ptr(o2), _ptr(y),
-                                         _ptr(_sched_buffer(x.device), torch.int32), 1, B, Cc, T, pre_scale,
-                                         out_scale, _stream()), "hilc_resblock_stream")
-    return y, [o1, o2]
+    with _timed("resblock", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}" + (" stream" if streaming else "")):
+        check(lib.hilc_resblock_balanced(_ptr(x), _ptr(w1p), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2p), _ptr(dw2_w),
+                                         _ptr(dw2_b), _ptr(hist1), _ptr(hist2), _ptr(hist1_out), _ptr(hist2_out),
+                                         _ptr(y), _ptr(_sched_buffer(x.device), torch.int32), int(streaming), B, Cc, T,
+                                         pre_scale, out_scale, _stream()), "hilc_resblock")
+    return y
 
 
-def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
-            stride: int = 1, hist: Optional[Tensor] = None, want_hist: bool = False,
-            in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False,
-            out: Optional[Tensor] = None):
-    """x `[B,C,T]`, w `[C,k]` -> `[B,C,ceil(T/stride)]` (+ new history `[B,C,k-stride]` if want_hist)."""
+_register("resblock", "(Tensor x, Tensor w1p, Tensor dw1_w, Tensor dw1_b, Tensor w2p, Tensor dw2_w, Tensor dw2_b, "
+          "Tensor? hist1, Tensor? hist2, Tensor(a!)? hist1_out, Tensor(b!)? hist2_out, float pre_scale, float out_scale)"
+          " -> Tensor", _resblock,
+          lambda x, w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale:
+          torch.empty_like(x))
+
+
+# ======================================================================================================
+# HBM-bound element-wise ops
+# ======================================================================================================
+def _dw_conv(x, hist, w, bias, res, hist_out, stride, in_scale, in_elu, out_scale, out_elu):
     B, Cc, T = x.shape
     k = w.shape[1]
     To = (T + stride - 1) // stride
-    y = out if out is not None else torch.empty(B, Cc, To, device=x.device, dtype=torch.float32)
-    hout = torch.empty(B, Cc, k - stride, device=x.device, dtype=torch.float32) if want_hist else None
+    y = _new(x, B, Cc, To)
     with _timed("dw_conv", 4.0 * B * Cc * (T + To * (2 if res is not None else 1)), f"C{Cc} T{T} k{k} s{stride}"):
-        check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hout),
+        check(lib.hilc_dw_conv(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), _ptr(hist_out),
                                B, Cc, T, k, stride, in_scale, int(in_elu), out_scale, int(out_elu), _stream()),
               "hilc_dw_conv")
-    return (y, hout) if want_hist else y
+    return y
 
 
-def dw_convtr(x: Tensor, w: Tensor, stride: int, hist: Optional[Tensor] = None, want_hist: bool = False,
-              in_scale: float = 1.0, in_elu: bool = False):
-    """x `[B,C,T]`, w `[C,2*stride]` -> `[B,C,T*stride]`."""
+_register("dw_conv", "(Tensor x, Tensor? hist, Tensor w, Tensor? bias, Tensor? res, Tensor(a!)? hist_out, int stride, "
+          "float in_scale, bool in_elu, float out_scale, bool out_elu) -> Tensor", _dw_conv,
+          lambda x, hist, w, bias, res, hist_out, stride, in_scale, in_elu, out_scale, out_elu:
+          x.new_empty(x.shape[0], x.shape[1], (x.shape[2] + stride - 1) // stride))
+
+
+def _dw_convtr(x, hist, w, hist_out, stride, in_scale, in_elu):
     B, Cc, T = x.shape
-    assert w.shape[1] == 2 * stride
-    y = torch.empty(B, Cc, T * stride, device=x.device, dtype=torch.float32)
-    hout = torch.empty(B, Cc, 1, device=x.device, dtype=torch.float32) if want_hist else None
+    if w.shape[1] != 2 * stride:
+        raise RuntimeError("dw_convtr: kernel size must be 2 * stride")
+    y = _new(x, B, Cc, T * stride)
     with _timed("dw_convtr", 4.0 * B * Cc * T * (1 + stride), f"C{Cc} T{T} r{stride}"):
-        check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hout), B, Cc, T, stride,
+        check(lib.hilc_dw_convtr(_ptr(x), _ptr(hist), _ptr(w), _ptr(y), _ptr(hist_out), B, Cc, T, stride,
                                  in_scale, int(in_elu), _stream()), "hilc_dw_convtr")
-    return (y, hout) if want_hist else y
+    return y
 
 
-def conv_pre(wav: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0,
-             hist: Optional[Tensor] = None) -> Tensor:
-    """wav `[B,1,T]`, w `[C,k]` -> `[B,C,T]`; hist `[B,1,L]` (L >= k-1) = waveform history."""
+_register("dw_convtr", "(Tensor x, Tensor? hist, Tensor w, Tensor(a!)? hist_out, int stride, float in_scale, bool in_elu)"
+          " -> Tensor", _dw_convtr,
+          lambda x, hist, w, hist_out, stride, in_scale, in_elu: x.new_empty(x.shape[0], x.shape[1], x.shape[2] * stride))
+
+
+def _conv_pre(wav, hist, w, bias, in_scale):
     B, one, T = wav.shape
-    assert one == 1
+    if one != 1:
+        raise RuntimeError("conv_pre expects a [B,1,T] waveform")
     Cc, k = w.shape
-    y = torch.empty(B, Cc, T, device=wav.device, dtype=torch.float32)
+    y = _new(wav, B, Cc, T)
     hl = hist.shape[-1] if hist is not None else 0
     with _timed("conv_pre", 4.0 * B * T * (1 + Cc)):
         check(lib.hilc_conv_pre(_ptr(wav), _ptr(hist), hl, _ptr(w), _ptr(bias), _ptr(y), B, Cc, T, k,
@@ -282,17 +280,283 @@ def conv_pre(wav: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1
     return y
 
 
-def conv_post(x: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0, in_elu: bool = True,
-              out_scale: float = 1.0, do_tanh: bool = True, hist: Optional[Tensor] = None,
-              want_hist: bool = False):
-    """x `[B,C,T]`, w `[C,k]` -> `[B,1,T]`."""
+_register("conv_pre", "(Tensor wav, Tensor? hist, Tensor w, Tensor? bias, float in_scale) -> Tensor", _conv_pre,
+          lambda wav, hist, w, bias, in_scale: wav.new_empty(wav.shape[0], w.shape[0], wav.shape[2]))
+
+
+def _conv_post(x, hist, w, bias, hist_out, in_scale, in_elu, out_scale, do_tanh):
     B, Cc, T = x.shape
     k = w.shape[1]
-    y = torch.empty(B, 1, T, device=x.device, dtype=torch.float32)
-    hout = torch.empty(B, Cc, k - 1, device=x.device, dtype=torch.float32) if want_hist else None
+    y = _new(x, B, 1, T)
     with _timed("conv_post", 4.0 * B * T * (1 + Cc)):
-        check(lib.hilc_conv_post(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(y), _ptr(hout), B, Cc, T, k,
+        check(lib.hilc_conv_post(_ptr(x), _ptr(hist), _ptr(w), _ptr(bias), _ptr(y), _ptr(hist_out), B, Cc, T, k,
                                  in_scale, int(in_elu), out_scale, int(do_tanh), _stream()), "hilc_conv_post")
+    return y
+
+
+_register("conv_post", "(Tensor x, Tensor? hist, Tensor w, Tensor? bias, Tensor(a!)? hist_out, float in_scale, "
+          "bool in_elu, float out_scale, bool do_tanh) -> Tensor", _conv_post,
+          lambda x, hist, w, bias, hist_out, in_scale, in_elu, out_scale, do_tanh: x.new_empty(x.shape[0], 1, x.shape[2]))
+
+
+def _stft_logmag(wav, hist, basis_t, n_fft, hop, mean, std, normalize):
+    B, one, T = wav.shape
+    Tf = (T - 1) // hop + 1
+    spec = _new(wav, B, n_fft // 2 + 1, Tf)
+    hl = hist.shape[-1] if hist is not None else 0
+    with _timed("stft", 2.0 * B * Tf * n_fft * (n_fft + 2), f"N{n_fft} hop{hop}"):
+        check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
+                                   mean, std, normalize, _stream()), "hilc_stft_logmag")
+    return spec
+
+
+_register("stft_logmag", "(Tensor wav, Tensor? hist, Tensor basis_t, int n_fft, int hop, float mean, float std, "
+          "int normalize) -> Tensor", _stft_logmag,
+          lambda wav, hist, basis_t, n_fft, hop, mean, std, normalize:
+          wav.new_empty(wav.shape[0], n_fft // 2 + 1, (wav.shape[2] - 1) // hop + 1))
+
+
+def _tail(x, hist, out):
+    B, Cc, T = x.shape
+    pad = out.shape[-1]
+    hl = hist.shape[-1] if hist is not None else 0
+    check(lib.hilc_tail(_ptr(x), _ptr(hist), _ptr(out), B * Cc, T, pad, hl, _stream()), "hilc_tail")
+
+
+_register("tail", "(Tensor x, Tensor? hist, Tensor(a!) out) -> ()", _tail, lambda x, hist, out: None)
+
+
+def _l2norm(x, eps, scale, channel_last_out):
+    B, Cc, T = x.shape
+    y = _new(x, *((B, T, Cc) if channel_last_out else (B, Cc, T)))
+    check(lib.hilc_l2norm(_ptr(x), _ptr(y), B, Cc, T, eps, scale, int(channel_last_out), _stream()), "hilc_l2norm")
+    return y
+
+
+_register("l2norm", "(Tensor x, float eps, float scale, bool channel_last_out) -> Tensor", _l2norm,
+          lambda x, eps, scale, channel_last_out:
+          x.new_empty(*((x.shape[0], x.shape[2], x.shape[1]) if channel_last_out else x.shape)))
+
+
+# ======================================================================================================
+# residual VQ
+# ======================================================================================================
+def _zct(z, channel_last):
+    if channel_last:
+        B, T, Cc = z.shape
+    else:
+        B, Cc, T = z.shape
+    return B, Cc, T
+
+
+def _rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss):
+    B, Cc, T = _zct(z, channel_last)
+    Nq, K, _ = codebooks.shape
+    rows = max(1, min(n, Nq))
+    idx = _new(z, *((rows, B, T) if stage_major else (B, rows, T)), dtype=torch.int64)
+    q = torch.empty_like(z) if want_q else None
+    ferr = _new(z, B * T) if want_loss else None
+    with _timed("rvq_encode", 2.0 * B * T * K * Cc * rows):
+        check(lib.hilc_rvq_encode_mixed(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
+                                        _ptr(n_clip, torch.int32), _ptr(idx, torch.int64), _ptr(q), _ptr(ferr),
+                                        B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
+              "hilc_rvq_encode")
+    loss = None
+    if want_loss:
+        loss = _new(z)
+        check(lib.hilc_mse_finalize(_ptr(ferr), _ptr(loss), B * T, float(B) * T * Cc, _stream()), "hilc_mse_finalize")
+    # the dispatcher wants real tensors for every declared output
+    return idx, (q if q is not None else _new(z, 0)), (loss if loss is not None else _new(z, 0))
+
+
+def _rvq_encode_fake(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss):
+    B, Cc, T = _zct(z, channel_last)
+    rows = max(1, min(n, codebooks.shape[0]))
+    idx = z.new_empty(*((rows, B, T) if stage_major else (B, rows, T)), dtype=torch.int64)
+    return idx, (torch.empty_like(z) if want_q else z.new_empty(0)), (z.new_empty(()) if want_loss else z.new_empty(0))
+
+
+_register("rvq_encode", "(Tensor z, Tensor codebooks, Tensor codebooks_t, Tensor norms, Tensor? n_clip, int n, "
+          "bool channel_last, bool stage_major, bool want_q, bool want_loss) -> (Tensor, Tensor, Tensor)",
+          _rvq_encode, _rvq_encode_fake)
+
+
+def _rvq_decode(indices, codebooks, n_clip, n, channel_last, stage_major):
+    if stage_major:
+        _, B, T = indices.shape
+    else:
+        B, _, T = indices.shape
+    Nq, K, Cc = codebooks.shape
+    q = _new(codebooks, *((B, T, Cc) if channel_last else (B, Cc, T)))
+    check(lib.hilc_rvq_decode_mixed(_ptr(indices, torch.int64), _ptr(codebooks), _ptr(n_clip, torch.int32), _ptr(q),
+                                    B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
+          "hilc_rvq_decode")
+    return q
+
+
+def _rvq_decode_fake(indices, codebooks, n_clip, n, channel_last, stage_major):
+    B, T = (indices.shape[1], indices.shape[2]) if stage_major else (indices.shape[0], indices.shape[2])
+    Cc = codebooks.shape[2]
+    return codebooks.new_empty(*((B, T, Cc) if channel_last else (B, Cc, T)))
+
+
+_register("rvq_decode", "(Tensor indices, Tensor codebooks, Tensor? n_clip, int n, bool channel_last, bool stage_major)"
+          " -> Tensor", _rvq_decode, _rvq_decode_fake)
+
+
+def _rvq_ema_stats(z, codebooks, indices, n, channel_last, stage_major):
+    B, Cc, T = _zct(z, channel_last)
+    Nq, K, _ = codebooks.shape
+    rows = indices.shape[0] if stage_major else indices.shape[1]
+    bucket = _new(z, n, K + K * Cc)
+    with _timed("rvq_ema_stats", 4.0 * B * T * Cc * n):
+        check(lib.hilc_rvq_ema_stats(_ptr(z), _ptr(codebooks), _ptr(indices, torch.int64), _ptr(bucket), B, Cc, T, K,
+                                     n, rows, int(channel_last), int(stage_major), _stream()), "hilc_rvq_ema_stats")
+    return bucket
+
+
+_register("rvq_ema_stats", "(Tensor z, Tensor codebooks, Tensor indices, int n, bool channel_last, bool stage_major)"
+          " -> Tensor", _rvq_ema_stats,
+          lambda z, codebooks, indices, n, channel_last, stage_major:
+          z.new_empty(n, codebooks.shape[1] * (1 + codebooks.shape[2])))
+
+
+def _rvq_ema_update(embed, ema_num, ema_embed, bucket, decay):
+    n, K, Cc = embed.shape
+    if tuple(ema_num.shape) != (n, K) or tuple(ema_embed.shape) != (n, K, Cc) or tuple(bucket.shape) != (n, K + K * Cc):
+        raise RuntimeError("rvq_ema_update: inconsistent shapes")
+    check(lib.hilc_rvq_ema_update(_ptr(embed), _ptr(ema_num), _ptr(ema_embed), _ptr(bucket), float(decay), K, Cc, n,
+                                  _stream()), "hilc_rvq_ema_update")
+
+
+_register("rvq_ema_update", "(Tensor(a!) embed, Tensor(b!) ema_num, Tensor(c!) ema_embed, Tensor bucket, float decay)"
+          " -> ()", _rvq_ema_update, lambda embed, ema_num, ema_embed, bucket, decay: None)
+
+_OPS = torch.ops.hilcodec
+
+
+# ======================================================================================================
+# public wrappers (traceable: arguments in, torch.ops.hilcodec.* out)
+# ======================================================================================================
+def pw_conv(x: Tensor, wt: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
+            in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0) -> Tensor:
+    """x `[B,K,T]`, wt `[K,M]` -> `[B,M,T]`; see hilc_pw_conv."""
+    return _OPS.pw_conv(x, wt, bias, res, float(in_scale), bool(in_elu), float(out_scale))
+
+
+def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None, res: Optional[Tensor] = None,
+             stride: int = 1, in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0,
+             out_elu: bool = False) -> Tensor:
+    """Fused pointwise -> depthwise causal conv (offline): x `[B,K,T]`, wt `[K,M]`, dw_w `[M,k]` ->
+    `[B,M,ceil(T/stride)]`; see hilc_dws_conv."""
+    return _OPS.dws_conv(x, wt, dw_w, dw_b, res, int(stride), float(in_scale), bool(in_elu), float(out_scale),
+                         bool(out_elu))
+
+
+def dws_conv_stream_supported(T: int, k: int, stride: int) -> bool:
+    """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride"""
+    return T <= 128 and T % stride == 0 and stride <= k <= 32
+
+
+def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
+    """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
+    --mode streaming): not for single-sample hops, whose depthwise taps are nearly all cache reads."""
+    return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
+
+
+def _state_out(given: Optional[Tensor], like: Tensor, *shape) -> Tensor:
+    """the next hop's cache: the caller's persistent buffer, or (reference protocol) a fresh tensor"""
+    return given if given is not None else torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def dws_conv_stream(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
+                    res: Optional[Tensor] = None, stride: int = 1, in_scale: float = 1.0, in_elu: bool = False,
+                    out_scale: float = 1.0, out_elu: bool = False, hist_out: Optional[Tensor] = None):
+    """Streaming hop of a depthwise-separable block (hilc_dws_conv_stream): x `[B,K,T]`, T <= 128, cache
+    `[B,M,k-stride]` (last pointwise outputs of the previous hop) -> (y `[B,M,T/stride]`, new cache)."""
+    hout = _state_out(hist_out, x, x.shape[0], wt.shape[1], dw_w.shape[1] - stride)
+    y = _OPS.dws_conv_stream(x, wt, dw_w, dw_b, hist, hout, res, int(stride), float(in_scale), bool(in_elu),
+                             float(out_scale), bool(out_elu))
+    return y, hout
+
+
+def up_conv_taps(tr_w: Tensor, stride: int) -> Optional[Tensor]:
+    """Expanded tap table for strides without a vector tap path (hilc_up_conv_expand_taps); built once per spec."""
+    if stride in (2, 4, 8):
+        return None
+    return _OPS.up_conv_expand_taps(tr_w, int(stride))
+
+
+def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
+            in_elu: bool = True, hist: Optional[Tensor] = None, want_hist: bool = False,
+            taps: Optional[Tensor] = None, hist_out: Optional[Tensor] = None):
+    """Fused [Scale, ELU, depthwise transposed conv (k=2*stride), pointwise conv + bias]:
+    x `[B,K,Tin]`, tr_w `[K,2*stride]`, wt `[K,M]` -> `[B,M,Tin*stride]`; see hilc_up_conv.
+    Streaming: hist `[B,K,1]` = the activated last input frame of the previous hop -> (y, new cache)."""
+    if taps is None and stride not in (2, 4, 8):
+        taps = up_conv_taps(tr_w, stride)
+    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], 1) if want_hist else None
+    y = _OPS.up_conv(x, hist, hout, tr_w, taps, wt, bias, int(stride), float(in_scale), bool(in_elu))
+    return (y, hout) if want_hist else y
+
+
+def resblock_supported(C: int, T: int) -> bool:
+    return bool(lib.hilc_resblock_supported(C, T))
+
+
+def resblock_pack(wt: Tensor) -> Tensor:
+    """k-major `[C,C]` pointwise weights -> the fused block's packed layout (hilc_resblock_pack_weights)."""
+    return _OPS.resblock_pack(wt)
+
+
+def resblock(x: Tensor, w1p: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2p: Tensor, dw2_w: Tensor, dw2_b: Tensor,
+             pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None,
+             hist_out: Optional[Sequence[Tensor]] = None):
+    """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`; w1p / w2p = PACKED
+    pointwise weights (`resblock_pack`).  Streaming: hist = (cache of depthwise 1, cache of depthwise 2), each
+    `[B,C,4]` -> (y, [new caches])."""
+    if hist is None:
+        return _OPS.resblock(x, w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, None, None, None, None, float(pre_scale),
+                             float(out_scale))
+    B, Cc, _ = x.shape
+    o1 = _state_out(hist_out[0] if hist_out is not None else None, x, B, Cc, 4)
+    o2 = _state_out(hist_out[1] if hist_out is not None else None, x, B, Cc, 4)
+    y = _OPS.resblock(x, w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, hist[0], hist[1], o1, o2, float(pre_scale),
+                      float(out_scale))
+    return y, [o1, o2]
+
+
+def dw_conv(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, res: Optional[Tensor] = None,
+            stride: int = 1, hist: Optional[Tensor] = None, want_hist: bool = False,
+            in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False,
+            hist_out: Optional[Tensor] = None):
+    """x `[B,C,T]`, w `[C,k]` -> `[B,C,ceil(T/stride)]` (+ new history `[B,C,k-stride]` if want_hist)."""
+    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], w.shape[1] - stride) if want_hist else None
+    y = _OPS.dw_conv(x, hist, w, bias, res, hout, int(stride), float(in_scale), bool(in_elu), float(out_scale),
+                     bool(out_elu))
+    return (y, hout) if want_hist else y
+
+
+def dw_convtr(x: Tensor, w: Tensor, stride: int, hist: Optional[Tensor] = None, want_hist: bool = False,
+              in_scale: float = 1.0, in_elu: bool = False, hist_out: Optional[Tensor] = None):
+    """x `[B,C,T]`, w `[C,2*stride]` -> `[B,C,T*stride]`."""
+    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], 1) if want_hist else None
+    y = _OPS.dw_convtr(x, hist, w, hout, int(stride), float(in_scale), bool(in_elu))
+    return (y, hout) if want_hist else y
+
+
+def conv_pre(wav: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0,
+             hist: Optional[Tensor] = None) -> Tensor:
+    """wav `[B,1,T]`, w `[C,k]` -> `[B,C,T]`; hist `[B,1,L]` (L >= k-1) = waveform history."""
+    return _OPS.conv_pre(wav, hist, w, bias, float(in_scale))
+
+
+def conv_post(x: Tensor, w: Tensor, bias: Optional[Tensor], in_scale: float = 1.0, in_elu: bool = True,
+              out_scale: float = 1.0, do_tanh: bool = True, hist: Optional[Tensor] = None,
+              want_hist: bool = False, hist_out: Optional[Tensor] = None):
+    """x `[B,C,T]`, w `[C,k]` -> `[B,1,T]`."""
+    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], w.shape[1] - 1) if want_hist else None
+    y = _OPS.conv_post(x, hist, w, bias, hout, float(in_scale), bool(in_elu), float(out_scale), bool(do_tanh))
     return (y, hout) if want_hist else y
 
 
@@ -300,30 +564,18 @@ def stft_logmag(wav: Tensor, basis_t: Tensor, n_fft: int, hop: int, mean: float 
                 normalize=True, hist: Optional[Tensor] = None) -> Tensor:
     """wav `[B,1,T]` -> `[B, n_fft/2+1, (T-1)//hop+1]`; normalize: False/0 log-mag, True/1 (log-mag - mean)/std,
     2 plain magnitude."""
-    B, one, T = wav.shape
-    Tf = (T - 1) // hop + 1
-    spec = torch.empty(B, n_fft // 2 + 1, Tf, device=wav.device, dtype=torch.float32)
-    hl = hist.shape[-1] if hist is not None else 0
-    with _timed("stft", 2.0 * B * Tf * n_fft * (n_fft + 2), f"N{n_fft} hop{hop}"):
-        check(lib.hilc_stft_logmag(_ptr(wav), _ptr(hist), hl, _ptr(basis_t), _ptr(spec), B, T, n_fft, hop,
-                                   mean, std, int(normalize), _stream()), "hilc_stft_logmag")
-    return spec
+    return _OPS.stft_logmag(wav, hist, basis_t, int(n_fft), int(hop), float(mean), float(std), int(normalize))
 
 
-def tail(x: Tensor, hist: Optional[Tensor], pad: int) -> Tensor:
+def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = None) -> Tensor:
     """Last `pad` samples of cat([hist, x], -1) along time; x `[B,C,T]`, hist `[B,C,L]`."""
-    B, Cc, T = x.shape
-    out = torch.empty(B, Cc, pad, device=x.device, dtype=torch.float32)
-    hl = hist.shape[-1] if hist is not None else 0
-    check(lib.hilc_tail(_ptr(x), _ptr(hist), _ptr(out), B * Cc, T, pad, hl, _stream()), "hilc_tail")
+    out = _state_out(out, x, x.shape[0], x.shape[1], pad)
+    _OPS.tail(x, hist, out)
     return out
 
 
 def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: bool = False) -> Tensor:
-    B, Cc, T = x.shape
-    y = torch.empty((B, T, Cc) if channel_last_out else (B, Cc, T), device=x.device, dtype=torch.float32)
-    check(lib.hilc_l2norm(_ptr(x), _ptr(y), B, Cc, T, eps, scale, int(channel_last_out), _stream()), "hilc_l2norm")
-    return y
+    return _OPS.l2norm(x, float(eps), float(scale), bool(channel_last_out))
 
 
 def is_scalar_n(n) -> bool:
@@ -350,64 +602,27 @@ def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor,
                want_loss: bool = False):
     """Returns (indices int64, q or None, loss 0-d or None).  `n`: int, or one int per clip (rows of `indices`
     beyond a clip's own n hold -1)."""
-    if channel_last:
-        B, T, Cc = z.shape
-    else:
-        B, Cc, T = z.shape
-    Nq, K, _ = codebooks.shape
-    n, n_clip = per_clip_n(n, B, Nq, z.device)
-    nn = max(1, min(n, Nq))
-    idx = torch.empty((nn, B, T) if stage_major else (B, nn, T), device=z.device, dtype=torch.int64)
-    q = torch.empty_like(z) if want_q else None
-    ferr = torch.empty(B * T, device=z.device, dtype=torch.float32) if want_loss else None
-    with _timed("rvq_encode", 2.0 * B * T * K * Cc * nn):
-        check(lib.hilc_rvq_encode_mixed(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
-                                        _ptr(n_clip, torch.int32), _ptr(idx, torch.int64), _ptr(q), _ptr(ferr),
-                                        B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
-              "hilc_rvq_encode")
-    loss = None
-    if want_loss:
-        loss = torch.empty((), device=z.device, dtype=torch.float32)
-        check(lib.hilc_mse_finalize(_ptr(ferr), _ptr(loss), B * T, float(B) * T * Cc, _stream()), "hilc_mse_finalize")
-    return idx, q, loss
+    B = z.shape[0]
+    n, n_clip = per_clip_n(n, B, codebooks.shape[0], z.device)
+    idx, q, loss = _OPS.rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, bool(channel_last), bool(stage_major),
+                                   bool(want_q), bool(want_loss))
+    return idx, (q if want_q else None), (loss if want_loss else None)
 
 
 def rvq_decode(indices: Tensor, codebooks: Tensor, n, channel_last: bool = True,
                stage_major: bool = True) -> Tensor:
-    if stage_major:
-        _, B, T = indices.shape
-    else:
-        B, _, T = indices.shape
-    Nq, K, Cc = codebooks.shape
-    n, n_clip = per_clip_n(n, B, Nq, indices.device)
-    q = torch.empty((B, T, Cc) if channel_last else (B, Cc, T), device=indices.device, dtype=torch.float32)
-    check(lib.hilc_rvq_decode_mixed(_ptr(indices, torch.int64), _ptr(codebooks), _ptr(n_clip, torch.int32), _ptr(q),
-                                    B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
-          "hilc_rvq_decode")
-    return q
+    B = indices.shape[1] if stage_major else indices.shape[0]
+    n, n_clip = per_clip_n(n, B, codebooks.shape[0], indices.device)
+    return _OPS.rvq_decode(indices, codebooks, n_clip, n, bool(channel_last), bool(stage_major))
 
 
 def rvq_ema_stats(z: Tensor, codebooks: Tensor, indices: Tensor, n: int, channel_last: bool = False,
                   stage_major: bool = False) -> Tensor:
     """Training-side cluster statistics of the first n stages: bucket `[n, K + K*C]` (counts | residual sums),
     the reference's per-stage all-reduce payload (`vector_quantize.py:155-162`) for all stages at once."""
-    if channel_last:
-        B, T, Cc = z.shape
-    else:
-        B, Cc, T = z.shape
-    Nq, K, _ = codebooks.shape
-    rows = indices.shape[0] if stage_major else indices.shape[1]
-    bucket = torch.empty(n, K + K * Cc, device=z.device, dtype=torch.float32)
-    with _timed("rvq_ema_stats", 4.0 * B * T * Cc * n):
-        check(lib.hilc_rvq_ema_stats(_ptr(z), _ptr(codebooks), _ptr(indices, torch.int64), _ptr(bucket), B, Cc, T, K,
-                                     n, rows, int(channel_last), int(stage_major), _stream()), "hilc_rvq_ema_stats")
-    return bucket
+    return _OPS.rvq_ema_stats(z, codebooks, indices, int(n), bool(channel_last), bool(stage_major))
 
 
 def rvq_ema_update(embed: Tensor, ema_num: Tensor, ema_embed: Tensor, bucket: Tensor, decay: float) -> None:
     """In place on stacked `[n,K,C]` / `[n,K]` tensors: EMA of counts and sums, embed = ema_embed / ema_num."""
-    n, K, Cc = embed.shape
-    if tuple(ema_num.shape) != (n, K) or tuple(ema_embed.shape) != (n, K, Cc) or tuple(bucket.shape) != (n, K + K * Cc):
-        raise RuntimeError("rvq_ema_update: inconsistent shapes")
-    check(lib.hilc_rvq_ema_update(_ptr(embed), _ptr(ema_num), _ptr(ema_embed), _ptr(bucket), float(decay), K, Cc, n,
-                                  _stream()), "hilc_rvq_ema_update")
+    _OPS.rvq_ema_update(embed, ema_num, ema_embed, bucket, float(decay))

@@ -1,0 +1,22 @@
+"""GPU, full size: EVERY RVQ index of the first 64 (hil_speech) / 32 (hil_music) clips of BASELINE's 256-clip batch
+against the CPU oracle (= the reference's arithmetic).  Bars (north_star): zero index mismatches that are not fp64
+near-ties, |dz| < 2e-5, decoded waveform within 1e-4 — on the reference's own indices for every clip and end to end on
+every clip without a near-tie flip.  The counts are printed (and land in profiles/ via tools/census_run.sh)."""
+import json
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,n_clips", [("hil_speech", 64), ("hil_music", 32)])
+def test_parity_census(name, n_clips):
+    from tests.census import run_census
+    r = run_census(name, n_clips)
+    print(json.dumps(r))
+    assert r["clips"] == n_clips and r["argmins"] == n_clips * (8 if name == "hil_speech" else 12) * 75
+    assert r["genuine_mismatches"] == 0, r["flips"]
+    assert r["near_tie_flips"] <= max(2, r["argmins"] // 20000), r["flips"]        # near-ties are rare events
+    assert r["dz_max"] < 2e-5
+    assert r["dwav_max_on_reference_indices"] < 1e-4
+    assert r["dwav_max_end_to_end"] is not None and r["dwav_max_end_to_end"] < 1e-4

@@ -239,3 +239,63 @@ def test_streaming_vs_oracle_other_configs(name, n, hop_frames):
         assert w.shape == (B, 1, L) and (w.cpu() - wo).abs().max() < 1e-4
         for a, b in zip(list(ce) + list(cd), list(oe) + list(od)):
             assert (a.cpu() - b).abs().max() < 5e-5
+
+
+def test_streaming_1024_streams_full_size(golden):
+    """BASELINE configs[3] at its REAL size (1024 concurrent streams, hop 320): the launch shapes of a full hop differ
+    from the small-batch tests (row-tile heights, frames per RVQ workgroup, flat tiles that straddle many streams), so
+    the same properties are checked there — stream 0 is the reference's golden stream, a stream's result does not
+    depend on the other 1023 (bit-exact against a 4-stream run), two half batches equal the whole (the multi-GPU
+    layout), and one HIP-graph replay per hop equals the eager loop."""
+    from hilcodec_amd.graph_step import GraphedHop
+    g = golden("stream_hil_speech")
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming(int(g["weight_seed"]))
+    B, hops = 1024, int(g["hops"])
+    x = synth.synth_clips(B, 320 * hops, seed=int(g["clip_seed"])).to(dev)       # stream 0 = the golden clip
+
+    def run(xs, graphed=False):
+        n = xs.shape[0]
+        hopper = GraphedHop(model, n, 320, 8, dev) if graphed else None
+        ce, cd = model.initialize_cache(xs)
+        zs, ids, ws = [], [], []
+        with torch.no_grad():
+            for h in range(hops):
+                xin = xs[:, :, 320 * h: 320 * (h + 1)].contiguous()
+                if graphed:
+                    idx, w = hopper.step(xin)
+                    ids.append(idx.clone()); ws.append(w.clone())
+                    continue
+                z, ce = model.encoder(xin, *ce)
+                idx = model.quantizer(z, 8)
+                w, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+                zs.append(z); ids.append(idx); ws.append(w)
+        caches = (hopper.cache_enc + hopper.cache_dec) if graphed else (list(ce) + list(cd))
+        return (torch.cat(zs, 1) if zs else None), torch.cat(ids, 2), torch.cat(ws, 2), caches
+
+    z, idx, wav, caches = run(x)
+    assert z.shape == (B, hops, 128) and idx.shape == (8, B, hops) and wav.shape == (B, 1, 320 * hops)
+    assert torch.isfinite(wav).all()
+    # (1) the golden stream inside the batch of 1024
+    assert (z[:1].cpu() - T(g["z"])).abs().max() < 2e-5
+    assert torch.equal(idx[:, :1].cpu(), T(g["indices"]).long())
+    assert (wav[:1].cpu() - T(g["wav"])).abs().max() < 1e-4
+    for i in range(22):
+        assert (caches[i][:1].cpu() - T(g[f"e_out{i}"])).abs().max() < 5e-5, f"e_out{i}"
+    for i in range(30):
+        assert (caches[22 + i][:1].cpu() - T(g[f"d_out{i}"])).abs().max() < 5e-5, f"d_out{i}"
+    # (2) batch invariance, bit-exact
+    pick = [0, 1, 511, 1023]
+    z4, idx4, wav4, caches4 = run(x[pick].contiguous())
+    assert torch.equal(z4, z[pick]) and torch.equal(idx4, idx[:, pick]) and torch.equal(wav4, wav[pick])
+    for a, b in zip(caches4, caches):
+        assert torch.equal(a, b[pick])
+    # (3) shard invariance: streams are pinned to a GPU for life, half batches must equal the whole
+    _, idx_a, wav_a, _ = run(x[:512].contiguous())
+    _, idx_b, wav_b, _ = run(x[512:].contiguous())
+    assert torch.equal(torch.cat([idx_a, idx_b], 1), idx) and torch.equal(torch.cat([wav_a, wav_b]), wav)
+    # (4) graph replay == eager at full size, caches included
+    _, idx_g, wav_g, caches_g = run(x, graphed=True)
+    assert torch.equal(idx_g, idx) and torch.equal(wav_g, wav)
+    for a, b in zip(caches_g, caches):
+        assert torch.equal(a, b)
