@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--model", default="hil_speech", choices=["hil_speech", "hil_music"])
+    ap.add_argument("--model", default=None, choices=["hil_speech", "hil_music"],
+                    help="default: hil_speech (BASELINE configs[1]); with --gpus 8: hil_music (configs[4], 2048 clips over 8 GPUs)")
     ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
     ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
@@ -53,6 +54,8 @@ def parse():
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--cpu-clips", type=int, default=16)
     a = ap.parse_args()
+    if a.model is None:
+        a.model = "hil_music" if (a.gpus == 8 and a.mode == "offline") else "hil_speech"
     if a.mode == "offline":
         a.steps = 5 if a.steps is None else a.steps
         a.warmup = 2 if a.warmup is None else a.warmup
@@ -65,22 +68,35 @@ def parse():
 
 
 def cpu_baseline(name, mk, sd, clips: int, samples: int):
+    """The CPU oracle (= the reference's arithmetic) timed on this box's host cores over a bounded sample of the same
+    workload: all cores (the headline CPU figure) and one thread (SURVEY §8d asks for both).  The oracle's outputs for
+    the sample are returned too: they double as the checker of the parity census below."""
     from hilcodec_amd import synth
-    from oracle import hilcodec_oracle as O           # the checker doubles as the timed CPU baseline
-    threads = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(threads)
+    from tests import census                            # test infrastructure: the checker doubles as the timed CPU baseline
     x = synth.synth_clips(clips, samples, seed=1234)
-    chunk = 8
-    with torch.no_grad():
-        O.codec_forward(sd, x[:1], mk)                # warm-up
-        t0 = time.perf_counter()
-        for i in range(0, clips, chunk):
-            O.codec_forward(sd, x[i:i + chunk], mk)
-        dt = time.perf_counter() - t0
+    z_o, idx_o, wav_o, dt, threads = census.oracle_clips(name, sd, mk, x, chunk=8)
     audio_s = clips * samples / 24000.0
-    return {"value": audio_s / dt, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
-            "sample": f"{clips} clips x {samples / 24000.0:g} s in chunks of {chunk}, {name}, fp32, torch CPU ops, "
-                      f"{threads} threads, {dt:.2f} s wall"}
+    _, _, _, dt1, _ = census.oracle_clips(name, sd, mk, x[:1], chunk=1, threads=1)
+    torch.set_num_threads(threads)
+    base = {"value": audio_s / dt, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+            "sample": f"{clips} clips x {samples / 24000.0:g} s in chunks of 8, {name}, fp32, torch CPU ops, "
+                      f"{threads} threads, {dt:.2f} s wall",
+            "single_thread": {"value": (samples / 24000.0) / dt1, "cores": 1,
+                              "sample": f"1 clip x {samples / 24000.0:g} s, 1 thread, {dt1:.2f} s wall"}}
+    return base, (z_o, idx_o, wav_o)
+
+
+def parity_census(model, sd, nq, z, idx, wav, oracle_out):
+    """Every RVQ index of the CPU-baseline sample (the first clips of the bench batch) against the oracle; the 64-clip
+    census is tests/test_gpu_census.py, this is the same comparison riding on the cpu_baseline leg's outputs."""
+    from tests import census
+    z_o, idx_o, wav_o = oracle_out
+    n = z_o.shape[0]
+    pad = torch.zeros(idx.shape[0] - n, *idx_o.shape[1:], dtype=torch.int64)
+    wav_ri = census.gpu_decode_indices(model, torch.cat([idx_o, pad]).to(idx.device))[:n]
+    out = census.compare(sd, nq, z[:n].cpu(), idx[:n].cpu(), wav[:n].cpu(), wav_ri.cpu(), z_o, idx_o, wav_o)
+    out.pop("flips", None)
+    return out
 
 
 def main():
@@ -112,10 +128,13 @@ def main():
         x = synth.synth_clips(hi - lo, T, seed=1234, first=lo).to(dev)
         audio_per_step = (hi - lo) * T / 24000.0
 
+        last = {}
+
         def step(i):
             z = model.encoder(x)
             q, _, _, idx = model.quantizer(z, None, return_indices=True)
             wav = model.decoder(q)
+            last["z"] = z
             return idx, wav
     else:
         from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
@@ -126,15 +145,16 @@ def main():
         hop = 320
         nbuf = 8                                           # distinct input hops, cycled
         xs = [synth.synth_clips(hi - lo, hop, seed=4321 + 7 * j, first=lo).to(dev) for j in range(nbuf)]
-        state = {"ce": None, "cd": None}
-        state["ce"], state["cd"] = model.initialize_cache(xs[0])
+        from hilcodec_amd.graph_step import StateBlock
+        blocks = (StateBlock(model, hi - lo, dev), StateBlock(model, hi - lo, dev))   # persistent ping-pong state in HBM
         audio_per_step = (hi - lo) * hop / 24000.0
 
         def step(i):
-            z, state["ce"] = model.encoder(xs[i % nbuf], *state["ce"])
+            src, dst = blocks[i & 1], blocks[(i & 1) ^ 1]
+            z, _ = model.encoder(xs[i % nbuf], *src.enc, cache_out=dst.enc)
             idx = model.quantizer(z, nq)
             q = model.dequantizer(idx, nq)
-            wav, state["cd"] = model.decoder(q, *state["cd"])
+            wav, _ = model.decoder(q, *src.dec, cache_out=dst.dec)
             return idx, wav
 
         if args.graph:
@@ -164,12 +184,14 @@ def main():
         ops.TIMER = None
 
     per_rank = D.gather_counters({"clips": float((hi - lo) * args.steps), "audio_s": audio_per_step * args.steps,
-                                  "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)
+                                  "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)   # the ONLY collective
     if rank == 0:
         agg = D.aggregate(per_rank)
         value = agg["xrt"]
         cfg_ix = {("offline", "hil_speech"): 1, ("offline", "hil_music"): 2, ("streaming", "hil_speech"): 3}.get(
             (args.mode, name), None)
+        if args.mode == "offline" and name == "hil_music" and world == 8 and B == 256:
+            cfg_ix = 4                                   # hil_music, 2048 clips sharded over 8 GPUs
         if args.mode == "offline":
             workload = (f"{name}, batch={B}x{T / 24000.0:g} s 24 kHz per GPU, Nq={nq}, offline encode+RVQ+decode "
                         f"(BASELINE configs[{cfg_ix}])")
@@ -185,6 +207,10 @@ def main():
                        "parallelism": f"clip-sharded x{world}, replicated weights, counters all_gather only"},
             "frames_per_sec": value * 75.0,
             "index_checksum": int(agg["index_checksum"]),
+            "ranks": {"backend": "rccl (torch.distributed nccl)" if world > 1 else "none (single process)",
+                      "rccl_ranks": world, "collectives_in_timed_region": 0,
+                      "wall_s_per_rank": [r["wall_s"] for r in per_rank],
+                      "wall_skew_s": max(r["wall_s"] for r in per_rank) - min(r["wall_s"] for r in per_rank)},
         }
         whole_tflops = value * FLOP_PER_AUDIO_SECOND[name] / 1e12 / world
         roof = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
@@ -221,7 +247,9 @@ def main():
             pass
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(name, mk, sd, args.cpu_clips, T)
+            out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)
+            if args.mode == "offline" and lo == 0 and hi - lo >= args.cpu_clips:
+                out["parity_census"] = parity_census(model, sd, nq, last["z"], idx, wav, oracle_out)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -501,7 +501,9 @@ def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride:
 
 
 def resblock_supported(C: int, T: int) -> bool:
-    return bool(lib.hilc_resblock_supported(C, T))
+    """mirror of hilc_resblock_supported (plain Python so that a tracing compiler can evaluate it; the C entry point
+    is checked against this in tests/test_api_cpu.py)"""
+    return C in (64, 96, 128, 192) and T % 4 == 0
 
 
 def resblock_pack(wt: Tensor) -> Tensor:
@@ -514,7 +516,10 @@ def resblock(x: Tensor, w1p: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2p: Tensor, 
              hist_out: Optional[Sequence[Tensor]] = None):
     """Fully fused residual block (hilc_resblock): x `[B,C,T]` -> new tensor `[B,C,T]`; w1p / w2p = PACKED
     pointwise weights (`resblock_pack`).  Streaming: hist = (cache of depthwise 1, cache of depthwise 2), each
-    `[B,C,4]` -> (y, [new caches])."""
+    `[B,C,4]` -> (y, [new caches]).  k-major `[C,C]` matrices are accepted too and packed on the fly (tests, tools);
+    the plans hold the packed form."""
+    if w1p.dim() == 2:
+        w1p, w2p = resblock_pack(w1p), resblock_pack(w2p)
     if hist is None:
         return _OPS.resblock(x, w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, None, None, None, None, float(pre_scale),
                              float(out_scale))

@@ -88,3 +88,21 @@ def test_streaming_hop_on_meta_tensors_with_state_block():
         _, ne2 = engine.run_encoder(es, x, ce, channel_last_out=True, caches_out=oe)
         _, nd2 = engine.run_decoder(ds, z.transpose(1, 2), cd, caches_out=od)
         assert all(a is b for a, b in zip(ne2, oe)) and all(a is b for a, b in zip(nd2, od))
+
+
+def test_dynamo_fullgraph_traces_the_module_classes():
+    """torch.compile(fullgraph=True) of the reference-API modules on META tensors: dynamo must get through the plan walk
+    without a graph break (no data_ptr / ctypes / host fold in the traced region) and the fake kernels must propagate
+    shapes; the same compile on real tensors with bit-exact comparison is tests/test_gpu_compile.py."""
+    model, mk, es, ds = _meta_model("hil_speech")
+    model.encoder._plan_cache, model.decoder._plan_cache = es, ds
+    enc = torch.compile(model.encoder, fullgraph=True, backend="aot_eager")
+    dec = torch.compile(model.decoder, fullgraph=True, backend="aot_eager")
+    with torch.no_grad():
+        z = enc(torch.empty(2, 1, 4800, device="meta"))
+        w = dec(z)
+    assert z.shape == (2, 128, 15) and w.shape == (2, 1, 4800)
+    # without a prepared plan the traced region refuses instead of folding weights inside the graph
+    fresh = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+    with pytest.raises(Exception, match="prepare"):
+        torch.compile(fresh.encoder, fullgraph=True, backend="aot_eager")(torch.empty(1, 1, 640, device="meta"))

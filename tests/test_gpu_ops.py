@@ -136,10 +136,11 @@ def test_pw_conv_vs_oracle(env, B, K, M, Tn):
     y = ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev), b.to(dev), res=r.to(dev), in_scale=0.77,
                     in_elu=True, out_scale=0.61)
     close(y, ref, 1e-5, "pw_conv")
-    # in-place residual (SpecBlock usage), no bias, no prologue
+    # residual add (SpecBlock usage), no bias, no prologue; the op is functional: the residual operand is untouched
     r2 = r.clone().to(dev)
-    ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev), None, res=r2, out=r2, out_scale=0.5)
-    close(r2, F.conv1d(x, w) * 0.5 + r, 1e-5, "pw_conv in-place")
+    y2 = ops.pw_conv(x.to(dev), fold.pointwise_layout(w).to(dev), None, res=r2, out_scale=0.5)
+    close(y2, F.conv1d(x, w) * 0.5 + r, 1e-5, "pw_conv residual")
+    assert torch.equal(r2.cpu(), r) and y2.data_ptr() != r2.data_ptr()
 
 
 def test_pw_conv_transpose_detect(env):
@@ -256,9 +257,10 @@ def test_dws_conv_k5_vs_oracle(env, B, K, M, Tn):
     close(y1, ref1, 2e-5, "dws first half")
     ref2 = O.sconv1d(F.conv1d(x, w), dw, db, groups=M) * 0.37 + r
     r2 = r.clone().to(dev)
-    ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev), res=r2,
-                 out_scale=0.37, out=r2)
-    close(r2, ref2, 2e-5, "dws second half (in-place residual)")
+    y2 = ops.dws_conv(x.to(dev), fold.pointwise_layout(w).to(dev), dw[:, 0].contiguous().to(dev), db.to(dev), res=r2,
+                      out_scale=0.37)
+    close(y2, ref2, 2e-5, "dws second half (residual)")
+    assert torch.equal(r2.cpu(), r)
 
 
 @pytest.mark.parametrize("K,M,Tn,r", [(64, 128, 1000, 2), (128, 256, 1203, 4), (256, 512, 600, 5), (512, 1024, 77, 8),

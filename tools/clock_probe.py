@@ -20,7 +20,7 @@ else:
     x = torch.randn(B, K, T, device=dev); wt = torch.randn(K, M, device=dev) / K ** 0.5
     y = torch.empty(B, M, T, device=dev)
     dw = torch.randn(M, 5, device=dev); db = torch.randn(M, device=dev)
-    fn = (lambda: ops.pw_conv(x, wt, out=y)) if kind == "gemm" else (lambda: ops.dws_conv(x, wt, dw, db, out=y, in_scale=0.9, in_elu=True))
+    fn = (lambda: ops.pw_conv(x, wt)) if kind == "gemm" else (lambda: ops.dws_conv(x, wt, dw, db, in_scale=0.9, in_elu=True))
     flops = 2.0 * B * T * K * M
 samples = []
 stop = False

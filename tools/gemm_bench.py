@@ -46,9 +46,9 @@ for K, M, T in shapes:
     y = torch.empty(B, M, T, device=dev)
     fl = 2.0 * B * T * K * M
     r = []
-    r.append(fl / timeit(lambda: ops.pw_conv(x, wt, out=y)) / 1e12)
-    r.append(fl / timeit(lambda: ops.pw_conv(x, wt, out=y, in_scale=0.9, in_elu=True)) / 1e12)
-    r.append(fl / timeit(lambda: ops.dws_conv(x, wt, dw, db, out=y)) / 1e12)
-    r.append(fl / timeit(lambda: ops.dws_conv(x, wt, dw, db, out=y, in_scale=0.9, in_elu=True, out_elu=True)) / 1e12)
+    r.append(fl / timeit(lambda: ops.pw_conv(x, wt)) / 1e12)
+    r.append(fl / timeit(lambda: ops.pw_conv(x, wt, in_scale=0.9, in_elu=True)) / 1e12)
+    r.append(fl / timeit(lambda: ops.dws_conv(x, wt, dw, db)) / 1e12)
+    r.append(fl / timeit(lambda: ops.dws_conv(x, wt, dw, db, in_scale=0.9, in_elu=True, out_elu=True)) / 1e12)
     print(f"{K:5d} {M:5d} {T:6d} | " + " ".join(f"{v:8.1f}" for v in r))
     del x, y

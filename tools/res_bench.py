@@ -24,7 +24,7 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
         return ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
     def two():
         g = ops.dws_conv(x, w1, d1, b1, in_scale=0.9, in_elu=True, out_elu=True)
-        return ops.dws_conv(g, w2, d2, b2, res=x, out_scale=0.5, out=g)
+        return ops.dws_conv(g, w2, d2, b2, res=x, out_scale=0.5)
     res = []
     for fn in (fused, two):
         fn(); torch.cuda.synchronize()
