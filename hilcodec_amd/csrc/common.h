@@ -24,16 +24,20 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
     }                                                         \
   } while (0)
 
-// Hot-path ELU: x > 0 ? x : 2^(x*log2 e) - 1 with the hardware v_exp_f32 (1 ulp).  5 VALU instead of
-// ~32 + a divergent branch for expm1f.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1,
-// i.e. one fp32 ulp of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on
-// a dense grid) — relative accuracy near 0- is given up, which a following dot product cannot see.
+// Hot-path ELU: max(x, 2^(min(x,0)*log2 e) - 1) with the hardware v_exp_f32 (1 ulp): 4 VALU + the transcendental
+// instead of ~32 + a divergent branch for expm1f.  For x > 0 the exponential term is exactly 0 and the max returns x
+// itself; for x <= 0, e^x - 1 >= x.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1, i.e. one fp32 ulp
+// of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on a dense grid) — relative accuracy
+// near 0- is given up, which a following dot product cannot see.  Justified by data, not taste: the full-size parity
+// census (profiles/r02_parity_census.json) finds 0 index flips in 67 200 argmins with this form AND with expm1f.
+// (max instead of compare + select: in the VALU-bound phases every instruction is ~2.8 cycles of the pipe the fp32
+// MFMAs need, profiles/r02_mfma_shadow_microbench.txt.)
 __device__ __forceinline__ float elu_fast(float x) {
 #ifdef HILC_ELU_EXPM1
   return x > 0.0f ? x : expm1f(x);   // A/B build for the parity census (tools/census_run.sh): torch's own ELU form
 #endif
   const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f);
-  return x > 0.0f ? x : e - 1.0f;
+  return fmaxf(x, e - 1.0f);
 }
 
 // optional "scale then ELU" prologue applied to a conv input sample

@@ -2,21 +2,32 @@
 //
 //   y = x + out_scale * dw2( pw2( ELU( dw1( pw1( ELU(pre_scale * x) ) ) + b1 ) ) ) + b2 )      (seanet.py:129-148)
 //
-// For C in {64, 96} the un-fused block is HBM-bound (1x1 conv intensity = C/4 flop/B): this kernel
-// reads x once and writes y once; everything between lives in one LDS tile.
+// For C in {64, 96} the un-fused block is HBM-bound (1x1 conv intensity = C/4 flop/B): this kernel reads x ONCE and
+// writes y once; everything between lives in registers and one LDS tile.
 //
-// Workgroup = 256 threads = 4 waves, one clip, 120 output samples: the tile spans 128 columns,
-// column c <-> time t0 + c with t0 = 120*tile - 8 (8 = left halo of two causal k=5 convs).
-//   P0  x tile -> a1 = ELU(pre*x)                     -> LDS  X[k][c]     (zero outside [0,T))
-//   P1  GEMM1  H1 = W1 * a1   (fp32 MFMA 32x32x2; wave w owns columns [32w,32w+32), all row blocks)
+// Workgroup = NW waves, one clip, NCOL-8 output samples: the tile spans NCOL columns (see Cfg),
+// column c <-> time t0 + c with t0 = (NCOL-8)*tile - 8 (8 = left halo of two causal k=5 convs).
+//   P0  a1 = ELU(pre*x) from the x REGISTERS (loaded during the previous tile's P6)  -> LDS  X[k][c]
+//   P1  GEMM1  H1 = W1 * a1   (fp32 MFMA 32x32x2; a wave owns one 32-column block and CBW row blocks)
 //   P2  accumulators -> LDS  X[m][c]
-//   P3  a2 = ELU(dw1(H1)+b1) in place (a row is handled by one wave, so read-before-write holds
+//   P3  a2 = ELU(dw1(H1)+b1) in place (a row is handled by one wave instruction, so read-before-write holds
 //       without a barrier); columns with t < 0 are forced to 0 (the second conv's zero padding)
 //   P4  GEMM2  H2 = W2 * a2
 //   P5  accumulators -> LDS
-//   P6  y = (dw2(H2)+b2)*out_scale + x  -> HBM, 512-B contiguous per wave
-// A operands (weights, k-major [K][C]) are read straight from global memory (L1/L2 resident, a few
-// tens of KB) into VGPRs one 16-deep K slice ahead — no LDS staging, no barrier in the K loop.
+//   P6  y = (dw2(H2)+b2)*out_scale + x (the shortcut comes from the x registers: no re-read) -> HBM; as soon as a
+//       row batch is stored its x registers are re-loaded with the NEXT tile's rows, so the loads travel under the
+//       rest of P6 / the barrier and P0 never waits for HBM (the next tile's lines were touched into this XCD's L2
+//       during GEMM2).
+// Cost model behind this shape (profiles/r02_mfma_shadow_microbench.txt): next to fp32 MFMAs (64 cycles each) LDS
+// traffic and sparse global loads are free, a VALU instruction costs ~2.8 cycles of the same pipe (4.9 when a SIMD
+// hosts a single wave: one wave cannot issue VALU back to back), v_exp_f32 8.4.  Hence: (i) the element-wise phases
+// process rows in BATCHES — all LDS reads of a batch, then the arithmetic, then the writes; the in-place row
+// update used to serialise on one exposed LDS round trip per row (P3 / P6 ran at a third of their VALU rate);
+// (ii) every LDS address is base + compile-time constant (a select in an address hides the no-alias fact from the
+// scheduler); (iii) C = 192, whose 96 KB tile allows one workgroup per CU, runs 8 waves (two per SIMD, each owning
+// half of the row blocks) so that the VALU phases issue at full rate.
+// A operands (weights) are read straight from global memory (L1/L2 resident, a few tens of KB) into VGPRs one
+// 16-deep K slice ahead — no LDS staging, no barrier in the K loop.
 // Summation order: k ascending (an fmaf chain), taps j = 0..4 — the same as the un-fused kernels.
 //
 // STREAM instantiation (hilc_resblock_stream; streaming.py:195-276 with causal_layers.py:147-167 caches): the
@@ -34,13 +45,50 @@ using namespace hilc;
 
 namespace {
 
-constexpr int XS = 128;   // LDS row stride (floats): every access is row-contiguous across lanes, no padding needed
-constexpr int DWS = 12;   // per-row depthwise table in LDS: w1[5], b1, w2[5], b2
-constexpr int TO = 120;   // output samples per tile
+constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1, w2_0, w2_1 | w2_2..4, b2]
+
+// Shape of a workgroup.  Offline: ONE 8-wave workgroup per CU (two waves per SIMD) that moves through the phases in
+// lockstep — co-resident workgroups in different phases do not help each other here: beside another wave's MFMA
+// stream a VALU phase gets a fraction of its stand-alone issue rate while the matrix wave gains nothing (fp32 MFMA and
+// VALU share the pipe), and 4-wave workgroups leave SIMDs idle at every barrier.  Tile width 256 columns where the
+// tile fits LDS (C <= 128: 248 of 256 columns useful instead of 120 of 128; a wave owns one 32-column block and all
+// row blocks), 128 columns for C = 192 (a wave owns a column block and HALF of the row blocks).
+// STREAM: 128-column tiles over the flat clip-major column space (hops are short), 4 waves (8 for C = 192).
+#ifndef HILC_RES_WIDE_MASK
+#define HILC_RES_WIDE_MASK 0   // bit 0: C = 64, bit 1: C = 96, bit 2: C = 128 use the wide lockstep shape (tuning: tools/res_bench.py)
+#endif
+template <int C>
+constexpr bool wide_shape() {
+  return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
+}
+
+template <int C, bool STREAM>
+struct Cfg {
+  static constexpr int CH = C;
+  static constexpr int CB = C / 32;
+  static constexpr bool WIDE = !STREAM && wide_shape<C>();
+  static constexpr int NCOL = WIDE ? 256 : 128;      // tile width = LDS row stride (floats)
+  static constexpr int XS = NCOL;
+  static constexpr int TO = NCOL - 8;                // output samples per tile (8 = left halo of two causal k=5 convs)
+  static constexpr int NW = (WIDE || C >= 192) ? 8 : 4;           // waves per workgroup
+  static constexpr int NT = 64 * NW;
+  static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
+  static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
+  static constexpr int RPI = 256 / NCOL;             // rows covered by one wave instruction of the element-wise phases
+  static constexpr int RSTEP = RPI * NW;
+  static constexpr int RW = C / RSTEP;               // rows per lane there
+  static constexpr int RB = 4;                       // rows per batch there
+  // weight stream: DEPTH register sets of KP k-pairs each; the loads run DEPTH-1 sets (= (DEPTH-1)*KP*CBW MFMAs per
+  // wave, twice that in wall time with two waves per SIMD) ahead of their use
+  static constexpr int KP = C >= 128 ? 4 : 8;
+  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? 3 : 2);
+  static constexpr int MINW = NW == 8 ? 2 : 2;       // waves per SIMD the register budget must allow
+  static_assert(NW % (NCOL / 32) == 0 && CB % RH == 0 && RW % RB == 0 && C % RSTEP == 0, "tile split");
+};
 
 struct ResArgs {
   const float* x;
-  const float* w1t;   // [C][C] k-major
+  const float* w1t;   // packed, see WeightPipe
   const float* dw1_w; // [C][5]
   const float* dw1_b; // [C]
   const float* w2t;
@@ -56,124 +104,180 @@ struct ResArgs {
   const float* hist2;
   float* hist1_out;
   float* hist2_out;
-  // optional dynamic tile scheduler: two ints, zero at launch and zero again at exit.  The two workgroups that
-  // share a CU do not share it fairly (the older one wins issue arbitration: lifetimes 4.7 M vs 7.0 M cycles for
-  // the same 100 tiles at C = 96), so with static tile lists a third of the kernel runs at half occupancy; with
-  // tickets the faster workgroup simply takes more tiles.
+  // optional dynamic tile scheduler: two ints, zero at launch and zero again at exit.  Co-resident workgroups do
+  // not share a CU fairly (the older one wins issue arbitration), so with static tile lists part of the kernel runs
+  // at reduced occupancy; with tickets the faster workgroup simply takes more tiles.
   int* sched;
-  unsigned long long* dbg;   // optional [blocks][8] s_memtime stamps (tools/res_phase_times.py)
+  unsigned long long* dbg;   // optional [tiles][8] s_memtime stamps (HILC_DEBUG_STAMPS builds, tools/res_phase_times.py)
 };
 
 #ifdef HILC_DEBUG_STAMPS
 unsigned long long* g_dbg = nullptr;   // tools/res_phase_times.py builds its own copy of the library with this
 #endif
 
-// Weight operands of one GEMM phase.  DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the
-// shadow of the MFMAs of slice kt; the first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise
-// phase that precedes the GEMM (P0 / P3), so that their L2 round trip (~2.5 k cycles, otherwise exposed at the
-// head of every GEMM phase) overlaps that phase.  C = 192 runs one workgroup per CU and gets two slices of lead.
 // The weight pointers go through an empty asm (LICM fence, see resblock_kernel) and come back without their
 // address space: loads through them would be FLAT instructions (LDS-or-global check, both wait counters).  This
 // type puts them back into the global address space -> global_load.
 typedef const __attribute__((address_space(1))) float* gptr_t;
+// the same for the laundered LDS row pointers: keep them 32-bit LDS pointers (ds_read / ds_write, not flat_load)
+typedef __attribute__((address_space(3))) float* lptr_t;
+typedef __attribute__((address_space(3))) f32x4* lvec_t;
+typedef __attribute__((address_space(3))) f32x2* lvec2_t;
 
-// Packed ("MFMA lane order") weights, produced by hilc_resblock_pack_weights from the k-major [K][C] matrix:
-//   packed[((kt * 2*CB + q) * 64 + lane) * 4 + e] = W[kt*16 + 2j + (lane >> 5)][32i + (lane & 31)],  q*4 + e = j*CB + i
-// i.e. the 8*CB operands a lane feeds to the MFMAs of K slice kt sit in 2*CB consecutive 16-B words per lane and a
-// wave's 64 lanes read 1 KiB contiguous per load: 2*CB vector loads per slice instead of 8*CB dword loads (every
-// VMEM instruction in these loops costs ~16 cycles of MFMA issue; +4-6 % at C <= 128).
-template <int C>
+// Packed ("MFMA lane order") weights, produced by hilc_resblock_pack_weights from the k-major [K][C] matrix.  For
+// the wave class h (row half, RH of them) and K slice kt the 8*CBW operands a lane feeds to the MFMAs sit in
+// NQ = 2*CBW consecutive 16-B words per lane and a wave's 64 lanes read 1 KiB contiguous per load:
+//   packed[(((h * C/16 + kt) * NQ + q) * 64 + lane) * 4 + e] = W[kt*16 + 2j + (lane >> 5)][32*(h*CBW + i) + (lane & 31)]
+//   with q*4 + e = j*CBW + i   (j = k-pair of the slice, i = row block of the wave).
+// DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the shadow of the MFMAs of slice kt; the
+// first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise phase that precedes the GEMM.
+template <class K>
 struct WeightPipe {
-  static constexpr int CB = C / 32;
-  static constexpr int DEPTH = C >= 192 ? 3 : 2;
-  static constexpr int NQ = 2 * CB;            // 16-B words per lane and slice
-  float a[DEPTH][8][CB];
-  __device__ __forceinline__ void load_word(gptr_t wp, int slot, int kt, int q, int lane) {
+  static constexpr int CBW = K::CBW;
+  static constexpr int DEPTH = K::DEPTH;
+  static constexpr int KP = K::KP;              // k-pairs per register set (8 = one 16-deep slice, 4 = half of one)
+  static constexpr int WPS = KP * CBW / 4;      // 16-B words per lane and set (consecutive in the packed array)
+  static_assert(KP * CBW % 4 == 0 && 8 % KP == 0, "register set = whole 16-B words");
+  float a[DEPTH][KP][CBW];
+  // wset: UNIFORM pointer to the set's first word (scalar base + lane offset + immediate: no per-lane 64-bit adds)
+  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
     typedef const __attribute__((address_space(1))) f32x4* gvec_t;
-    const f32x4 v = *(gvec_t)(wp + ((long)(kt * NQ + q) * 64 + lane) * 4);
+    const f32x4 v = *(gvec_t)(wset + q * 256 + lane * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CB][(q * 4 + e) % CB] = v[e];
+    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CBW][(q * 4 + e) % CBW] = v[e];
   }
   __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) load_word((gptr_t)wt, d, d, q, lane);
+      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
   }
 };
 
-template <int C>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[C / 32],
-                                           WeightPipe<C>& wp, int wave, int lane) {
-  constexpr int CB = C / 32;
-  constexpr int DEPTH = WeightPipe<C>::DEPTH;
+// wt: this wave class's part of the packed matrix;  X: LDS tile;  colblk: the wave's 32-column block
+template <class K>
+__device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
+                                           WeightPipe<K>& wp, int colblk, int lane) {
+  constexpr int C = K::CH, XS = K::XS;
+  constexpr int CBW = K::CBW;
+  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
+  constexpr int NSETS = C / 2 / KP;
   const int kh = lane >> 5, l31 = lane & 31;
+  // this lane's B column: X[(2p+kh)][32*colblk + l31], p = k-pair.  `xn` walks ahead of the MFMAs one register set at a
+  // time and is laundered after every step: a DS instruction reaches 64 KB past its base register, the tile is up to
+  // 136 KB, and left alone hipcc materialises one base register per far row and keeps them all alive (spilling them).
+  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
+  float b[DEPTH][KP];
 #pragma unroll
-  for (int i = 0; i < CB; ++i)
+  for (int d = 0; d < DEPTH - 1; ++d) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  const float* xl = X + kh * XS + wave * 32 + l31;  // this lane's B column: X[(2j+kh)][32w + l31]
-  float b[DEPTH][8];
+    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
+    xn += KP * 2 * XS;
+    asm volatile("" : "+v"(xn));
+  }
+  // Issue order, pinned: the weight words of set s+DEPTH-1 are spread over the MFMAs of set s (one every fourth),
+  // its LDS operand reads one per k-pair.
+  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
+  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
 #pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d)
+  for (int s = 0; s < NSETS; ++s) {
+    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
+    const int sn = s + DEPTH - 1;
+    const bool more = sn < NSETS;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[d][j] = xl[(d * 16 + 2 * j) * XS];
-  // Issue order, pinned: the 2*CB weight words of slice kt+DEPTH-1 are spread over the 8*CB MFMAs of slice kt (one
-  // every fourth MFMA), its LDS operand reads one per k-pair.  Left to itself hipcc sinks the loads next to their
-  // uses; sched_group_barrier lets the scheduler pick WHICH load fills a slot and it picks the consumer's own.
+    for (int j = 0; j < KP; ++j) {
+      if (more) b[nxt][j] = xn[j * 2 * XS];
 #pragma unroll
-  for (int kt = 0; kt < C / 16; ++kt) {
-    const int cur = kt % DEPTH, nxt = (kt + DEPTH - 1) % DEPTH;
-    const int kn = kt + DEPTH - 1;
-    const bool more = kn < C / 16;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (more) b[nxt][j] = xl[(kn * 16 + 2 * j) * XS];
-#pragma unroll
-      for (int i = 0; i < CB; ++i) {
-        const int n = j * CB + i;                    // MFMA index inside the slice
-        if (more && n % 4 == 0) wp.load_word((gptr_t)wt, nxt, kn, n / 4, lane);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < CBW; ++i) {
+        const int n = j * CBW + i;                   // MFMA index inside the set
+        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
+        // inline asm, not the builtin: the pure intrinsic is free to move at IR level and hipcc sinks a whole GEMM
+        // phase's MFMAs below all of its operand loads (every operand then spills); a volatile asm keeps its place
+        // among the loads.  D == C (same registers): back-to-back accumulation needs no software wait states.
+        if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
+        else
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
       }
     }
+    if (more) {
+      xn += KP * 2 * XS;
+      wn += WPS * 256;
+      asm volatile("" : "+v"(xn), "+s"(wn));
+    }
   }
+  // the accumulators are read next by non-MFMA instructions (ds_write after a barrier): the compiler cannot see
+  // into the asm, so the 16-pass MFMA -> VALU/DS read hazard (18 wait states) is covered by hand
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 }
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C, int RH) {
   const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed`
   if (idx >= C * C) return;
-  const int CB = C / 32, NQ = 2 * CB;
+  const int CB = C / 32, CBW = CB / RH, NQ = 2 * CBW, KT = C / 16;
   const int e = idx & 3, lane = (idx >> 2) & 63, w = idx >> 8;
-  const int q = w % NQ, kt = w / NQ;
-  const int v = q * 4 + e, j = v / CB, i = v % CB;
-  const int k = kt * 16 + 2 * j + (lane >> 5), m = 32 * i + (lane & 31);
+  const int q = w % NQ, kt = (w / NQ) % KT, h = w / (NQ * KT);
+  const int v = q * 4 + e, j = v / CBW, i = v % CBW;
+  const int k = kt * 16 + 2 * j + (lane >> 5), m = 32 * (h * CBW + i) + (lane & 31);
   packed[idx] = wt[(long)k * C + m];
 }
 
-template <int C>
-__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[C / 32], float* X, int wave, int lane) {
+template <class K>
+__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[K::CBW], float* X, int rowblk0, int colblk, int lane) {
+  constexpr int XS = K::XS;
+  lptr_t xb = (lptr_t)(X + (rowblk0 * 32 + 4 * (lane >> 5)) * XS + colblk * 32 + (lane & 31));
 #pragma unroll
-  for (int i = 0; i < C / 32; ++i)
+  for (int i = 0; i < K::CBW; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) X[(i * 32 + acc_row(r, lane)) * XS + wave * 32 + (lane & 31)] = acc[i][r];
+    for (int r = 0; r < 16; ++r) xb[((r & 3) + 8 * (r >> 2)) * XS] = acc[i][r];     // acc_row(r, lane) without its lane term
+    xb += 32 * XS;
+    asm volatile("" : "+v"(xb));      // one base register per row block (see gemm_phase)
+  }
 }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() drains vmcnt as well (it is a memory fence for global
+// memory too), i.e. every barrier would wait for the weight words and the next tile's x rows that are deliberately
+// kept in flight across it — measured as a 3-7 k cycle hole at the end of every tile.  All data exchanged between
+// the waves here lives in LDS, and a wave's LDS operations complete in order: lgkmcnt(0) + s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// this lane's 4 columns of a tile: clip, time (a multiple of 4; T % 4 == 0: the group is entirely inside or outside)
+struct Cols {
+  long b;              // offline: clip
+  int t;
+  bool t_in;
+  unsigned boff;       // STREAM: byte offset of (clip, row 0, t) against the tensor base (B*C*T*4 < 2^32, launcher-checked)
+  unsigned hoff;       // STREAM: element offset of this clip's [C][4] cache block
+  bool head, tail;     // STREAM: t == 0 (previous 4 samples live in the cache) / t == T-4 on an output column
+};
+
 template <int C, bool STREAM>
-__global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResArgs a) {
-  constexpr int CB = C / 32;
-  __shared__ __attribute__((aligned(16))) float X[C * XS];
-  __shared__ float DW[C * DWS];
+__global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM>;
+  constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
+  // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
+  // plain base + constant address instead of a select
+  __shared__ __attribute__((aligned(16))) float Xbuf[4 + C * XS];
+  __shared__ __attribute__((aligned(16))) float DW[C * DWS];
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
   // do not pay one exposed global-load latency per row for the single lane that needs them
   __shared__ __attribute__((aligned(16))) float HS[STREAM ? 2 * C * 4 : 4];
+  float* const X = Xbuf + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
+  constexpr int NCB = K::NCOL / 32;                      // column blocks of the tile
+  const int colblk = wave % NCB;
+  const int wclass = wave / NCB;                         // row class (0 unless RH == 2)
+  const int rowblk0 = wclass * CBW;
+#ifdef HILC_DEBUG_STAMPS
 #define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   long stamp_tile = blockIdx.x;
+#else
+#define STAMP(i) do { } while (0)
+#endif
   const int T = a.T;
   // depthwise taps / biases -> LDS once per workgroup (read back as half-wave broadcasts in P3 / P6)
-  for (int e = threadIdx.x; e < C * DWS; e += 256) {
+  for (int e = tid; e < C * DWS; e += NT) {
     const int m = e / DWS, j = e - m * DWS;
     float v;
     if (j < 5) v = a.dw1_w[m * 5 + j];
@@ -182,259 +286,285 @@ __global__ __launch_bounds__(256, (C == 128 ? 2 : 1)) void resblock_kernel(ResAr
     else v = a.dw2_b[m];
     DW[e] = v;
   }
-  // persistent: this workgroup walks tiles blockIdx.x, +gridDim.x, ... ; while tile i is in its second
-  // GEMM the x rows of tile i+gridDim.x are touched so that its P0 finds them in this XCD's L2.
-  float touch = 0.f;
-  __shared__ long s_next;
-  long tile = blockIdx.x;
-  while (tile < a.total_tiles) {
-  stamp_tile = tile;
-  STAMP(0);
-  if (a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
-  // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 8*i), lane = 4 adjacent
+  if (tid < 4) Xbuf[tid] = 0.f;
+  // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 2*NW*i), lane = 4 adjacent
   // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
   // wave instruction, so the in-place update of P3 needs no barrier.
-  constexpr int RW = C / 8;
-  const int rsub = wave * 2 + (lane >> 5);
-  const int c4 = (lane & 31) * 4;
-  // this lane's 4 columns: clip b, time t (a multiple of 4; T % 4 == 0: the group is entirely inside or outside)
-  long b;
-  int t;
-  bool t_in;
-  // STREAM: clips differ between lanes, so the lane carries one 32-bit BYTE offset against the scalar tensor
-  // base (saddr + voffset form) — B*C*T*4 < 2^32, launcher-checked — plus the cache offset and two flags.
-  // They are RE-DERIVED from a laundered copy of c4 at the start of P3 and P6 instead of staying live across
-  // the GEMMs: the C = 128 kernel sits 12 VGPRs under the 2-waves/SIMD budget and hipcc gives up on that
-  // occupancy for the whole kernel (+150 VGPRs) as soon as one region exceeds it.
-  [[maybe_unused]] unsigned boff = 0;
-  [[maybe_unused]] unsigned hoff = 0;          // element offset of this clip's [C][4] cache block
-  [[maybe_unused]] bool clip_head = false;     // t == 0: the previous 4 samples live in the cache
-  [[maybe_unused]] bool clip_tail = false;     // t == T-4 (an output column): these 4 samples are the new cache
+  const int rsub = wave * K::RPI + (K::RPI == 2 ? (lane >> 5) : 0);
+  const int c4 = (lane & (K::NCOL / 4 - 1)) * 4;
   [[maybe_unused]] const unsigned row_b = (unsigned)T * 4u;
-  auto lane_columns = [&]() {
-    if constexpr (STREAM) {
-      int c = c4;
-      asm volatile("" : "+v"(c));
-      const int flat = (int)tile * TO - 8 + c;
-      t_in = flat >= 0 && flat < a.B * T;
-      const unsigned ub = t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
-      b = ub;
-      t = t_in ? flat - (int)ub * T : 0;
-      boff = (ub * (unsigned)(C * T) + (unsigned)t) * 4u;
-      hoff = ub * (unsigned)(C * 4);
-      clip_head = t_in && t == 0;
-      clip_tail = t_in && c >= 8 && t == T - 4;
-    }
-  };
-  if constexpr (STREAM) {
-    lane_columns();
-  } else {
-    b = tile / a.tiles;
-    const int t0 = (int)(tile - b * a.tiles) * TO - 8;
-    t = t0 + c4;
-    t_in = t >= 0 && t < T;
-  }
-  const float* xb = a.x + (STREAM ? 0 : b) * (long)C * T;
-  float* yb = a.y + (STREAM ? 0 : b) * (long)C * T;
-  auto xrow = [&](int m, bool ok) -> const f32x4* {
-    if constexpr (STREAM)
-      return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (boff + (unsigned)m * row_b));
-    else
-      return reinterpret_cast<const f32x4*>(xb + (long)m * T + (ok ? t : 0));
-  };
-  auto yrow = [&](int m) -> f32x4* {
-    if constexpr (STREAM)
-      return reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (boff + (unsigned)m * row_b));
-    else
-      return reinterpret_cast<f32x4*>(yb + (long)m * T + t);
-  };
-
-  // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
-  // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
-  const float* w1t = a.w1t;
-  const float* w2t = a.w2t;
-  asm volatile("" : "+s"(w1t), "+s"(w2t));
   [[maybe_unused]] const bool one_head = STREAM && T >= XS;
-  if constexpr (STREAM) {
-    if (one_head && __builtin_amdgcn_ballot_w64(clip_head) != 0) {   // wave-uniform
-      if (clip_head) {
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-          const float* hp = which == 0 ? a.hist1 : a.hist2;
-          f32x4 h[RW];
-#pragma unroll
-          for (int i = 0; i < RW; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (hp != nullptr) {
-#pragma unroll
-            for (int i = 0; i < RW; ++i) h[i] = *reinterpret_cast<const f32x4*>(hp + hoff + (rsub + 8 * i) * 4);
-          }
-#pragma unroll
-          for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(&HS[(which * C + rsub + 8 * i) * 4]) = h[i];
-        }
-      }
-    }
-  }
-  WeightPipe<C> wp;
-  wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
-  // ---- P0: every row's 16-B load in flight at once, then the prologue
-  {
-    f32x4 v[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
-      v[i] = *xrow(rsub + 8 * i, t_in);
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
-      *reinterpret_cast<f32x4*>(&X[(rsub + 8 * i) * XS + c4]) = prologue4v(zero_unless(t_in, v[i]), a.pre_scale, 1);
-  }
-  __syncthreads();
-  STAMP(1);
-  const long next = a.sched != nullptr ? s_next : tile + gridDim.x;
 
-  f32x16 acc[CB];
-  // ---- P1, P2
-  gemm_phase<C>(w1t, X, acc, wp, wave, lane);
-  __syncthreads();
-  STAMP(2);
-  acc_to_x<C>(acc, X, wave, lane);
-  __syncthreads();
-  STAMP(3);
-
-  // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place
-  wp.prefetch(w2t, lane);                  // GEMM2's first weight slices travel while P3 runs
-  lane_columns();
-#pragma unroll 2
-  for (int i = 0; i < RW; ++i) {
-    const int m = rsub + 8 * i;
-    float* row = &X[m * XS];
-    const f32x4 cur = *reinterpret_cast<const f32x4*>(row + c4);
-    f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));   // c4 == 0: discarded columns
+  auto columns_of = [&](long tile) -> Cols {
+    Cols s;
+    s.boff = 0; s.hoff = 0; s.head = false; s.tail = false;
     if constexpr (STREAM) {
-      if (clip_head) {
-        if (one_head) {
-          prev = *reinterpret_cast<const f32x4*>(&HS[m * 4]);   // written by this same lane before P0
-        } else {
-          prev = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (a.hist1 != nullptr) prev = *reinterpret_cast<const f32x4*>(a.hist1 + hoff + m * 4);
-        }
-      }
-      if (clip_tail && a.hist1_out != nullptr) *reinterpret_cast<f32x4*>(a.hist1_out + hoff + m * 4) = cur;
-    }
-    const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
-    float w[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) w[j] = DW[m * DWS + j];
-    const float bias = DW[m * DWS + 5];
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
-      s = elu_fast(__fadd_rn(s, bias));
-      o[e] = (STREAM || t >= 0) ? s : 0.f;   // STREAM: a clip's first samples never read their LDS neighbours
-    }
-    *reinterpret_cast<f32x4*>(row + c4) = o;
-  }
-  __syncthreads();
-  STAMP(4);
-
-  // ---- P4
-  gemm_phase<C>(w2t, X, acc, wp, wave, lane);
-  lane_columns();
-  // shortcut samples for P6, PF rows at a time: the first chunk is issued here and lands under the
-  // next two barriers, chunk n+1 is issued before chunk n is consumed
-  constexpr int PF = RW < 4 ? RW : 4;
-  const bool out_ok = STREAM ? (c4 >= 8 && t_in) : (c4 >= 8 && t < T);
-  f32x4 xs[2][PF];
-  auto load_xs = [&](int slot, int i0) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i)
-      xs[slot][i] = *xrow(rsub + 8 * (i0 + i), out_ok);
-  };
-  load_xs(0, 0);
-  // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM
-  // (nothing stays live across it), consumed by a never-true test at the end of P6
-  constexpr int NTOUCH = (C * 4 + 255) / 256;
-  float tv[NTOUCH];
-  {
-    const long nt = next < a.total_tiles ? next : tile;
-    // (these loads also keep hipcc from hoisting P6's shortcut loads above the GEMM: without them, or with
-    // per-lane clip indices here, the kernel needs ~130 more VGPRs)
-    const bool have = next < a.total_tiles;
-    long nb;
-    int nt0;
-    if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
-      const int nf0 = (int)nt * TO - 8;
-      const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
-      nb = q;
-      nt0 = nf0 - (int)q * T;
+      const int flat = (int)tile * TO - 8 + c4;
+      s.t_in = flat >= 0 && flat < a.B * T;
+      const unsigned ub = s.t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
+      s.b = ub;
+      s.t = s.t_in ? flat - (int)ub * T : 0;
+      s.boff = (ub * (unsigned)(C * T) + (unsigned)s.t) * 4u;
+      s.hoff = ub * (unsigned)(C * 4);
+      s.head = s.t_in && s.t == 0;
+      s.tail = s.t_in && c4 >= 8 && s.t == T - 4;
     } else {
-      nb = have ? nt / a.tiles : b;
-      nt0 = (int)(nt - nb * a.tiles) * TO - 8;
+      s.b = tile / a.tiles;
+      s.t = (int)(tile - s.b * a.tiles) * TO - 8 + c4;
+      s.t_in = s.t >= 0 && s.t < T;
     }
-    const float* nx = a.x + nb * (long)C * T;
-#pragma unroll
-    for (int i = 0; i < NTOUCH; ++i) {
-      int e = tid + 256 * i;
-      e = e < C * 4 ? e : C * 4 - 1;
-      int tt = nt0 + (e & 3) * 32;
-      tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-      tv[i] = nx[(long)(e >> 2) * T + tt];
-    }
-  }
-  // ---- P5
-  __syncthreads();
-  STAMP(5);
-  acc_to_x<C>(acc, X, wave, lane);
-  __syncthreads();
-  STAMP(6);
+    return s;
+  };
+  auto xrow = [&](const Cols& s, int m) -> const f32x4* {     // rows outside [0, T) read a mapped dummy (zeroed in P0)
+    if constexpr (STREAM)
+      return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (s.boff + (unsigned)m * row_b));
+    else
+      return reinterpret_cast<const f32x4*>(a.x + s.b * (long)C * T + (long)m * T + (s.t_in ? s.t : 0));
+  };
+  auto yrow = [&](const Cols& s, int m) -> f32x4* {
+    if constexpr (STREAM)
+      return reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (s.boff + (unsigned)m * row_b));
+    else
+      return reinterpret_cast<f32x4*>(a.y + s.b * (long)C * T + (long)m * T + s.t);
+  };
 
-  // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for columns >= 8, t < T
+  // persistent: this workgroup walks tiles (static stride or tickets).  x registers: the tile's rows of this
+  // lane, loaded one tile ahead; they are the GEMM input (through P0) AND the shortcut of P6.
+  float touch = 0.f;
+  constexpr int LPR = K::NCOL / 32;                 // 128-B lines per tile row
+  constexpr int NTOUCH = (C * LPR + NT - 1) / NT;
+  float tv[NTOUCH];                                 // L2 touch loads in flight across the tile boundary
 #pragma unroll
-  for (int i0 = 0; i0 < RW; i0 += PF) {
-    const int slot = (i0 / PF) & 1;
-    if (i0 + PF < RW) load_xs(slot ^ 1, i0 + PF);
+  for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
+  __shared__ long s_next;
+  long tile = blockIdx.x;
+  Cols cs = columns_of(tile < a.total_tiles ? tile : 0);
+  f32x4 xr[RW];
+  if (tile < a.total_tiles) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int m = rsub + 8 * (i0 + i);
-      const float* row = &X[m * XS];
-      const f32x4 cur = *reinterpret_cast<const f32x4*>(row + c4);
-      f32x4 prev = *reinterpret_cast<const f32x4*>(row + (c4 >= 4 ? c4 - 4 : 0));
-      if constexpr (STREAM) {
-        if (clip_head) {
-          if (one_head) {
-            prev = *reinterpret_cast<const f32x4*>(&HS[(C + m) * 4]);
-          } else {
-            prev = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.hist2 != nullptr) prev = *reinterpret_cast<const f32x4*>(a.hist2 + hoff + m * 4);
+    for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, rsub + RSTEP * i);
+  }
+  lds_barrier();   // DW / pad visible
+  while (tile < a.total_tiles) {
+#ifdef HILC_DEBUG_STAMPS
+    stamp_tile = tile;
+#endif
+    STAMP(0);
+    // tickets only where several workgroups share a CU (one per CU progresses evenly: static stride, no atomic round
+    // trip on the critical path)
+    constexpr bool TICKETS = K::NW == 4;
+    if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
+    // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
+    // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
+    const float* w1t = a.w1t + (long)wclass * (C * C / K::RH);
+    const float* w2t = a.w2t + (long)wclass * (C * C / K::RH);
+    asm volatile("" : "+s"(w1t), "+s"(w2t));
+    if constexpr (STREAM) {
+      if (one_head && __builtin_amdgcn_ballot_w64(cs.head) != 0) {   // wave-uniform
+        if (cs.head) {
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            const float* hp = which == 0 ? a.hist1 : a.hist2;
+            f32x4 h[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (hp != nullptr) {
+#pragma unroll
+              for (int i = 0; i < RW; ++i) h[i] = *reinterpret_cast<const f32x4*>(hp + cs.hoff + (rsub + RSTEP * i) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(&HS[(which * C + rsub + RSTEP * i) * 4]) = h[i];
           }
         }
-        if (clip_tail && a.hist2_out != nullptr) *reinterpret_cast<f32x4*>(a.hist2_out + hoff + m * 4) = cur;
       }
-      const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
-      float w[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) w[j] = DW[m * DWS + 6 + j];
-      const float bias = DW[m * DWS + 11];
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
-        s = __fmul_rn(__fadd_rn(s, bias), a.out_scale);
-        o[e] = __fadd_rn(s, xs[slot][i][e]);
-      }
-      if (out_ok) *yrow(m) = o;
     }
-  }
+    WeightPipe<K> wp;
+    wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
+    // ---- P0: the prologue on the x registers (they stay live: shortcut of P6)
+    {
+      lptr_t xp = (lptr_t)(X + rsub * XS + c4);   // walks down the tile RB rows at a time (laundered: see gemm_phase)
 #pragma unroll
-  for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
-  STAMP(7);
-  __syncthreads();   // the next tile's P0 overwrites X
-  tile = next;
+      for (int i0 = 0; i0 < RW; i0 += RB) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+          *(lvec_t)(xp + i * RSTEP * XS) = prologue4v(zero_unless(cs.t_in, xr[i0 + i]), a.pre_scale, 1);
+        xp += RB * RSTEP * XS;
+        asm volatile("" : "+v"(xp));
+      }
+    }
+    // last tile's touch loads are older than the x loads P0 just waited for: consuming them here costs no wait (at
+    // the end of P6 it drained the queue, i.e. waited for the freshly issued x loads of the next tile)
+#pragma unroll
+    for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
+    lds_barrier();
+    STAMP(1);
+    const long next = (TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x;
+
+    f32x16 acc[CBW];
+    // ---- P1, P2
+    gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
+    lds_barrier();
+    STAMP(2);
+    acc_to_x<K>(acc, X, rowblk0, colblk, lane);
+    lds_barrier();
+    STAMP(3);
+
+    // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place, RB rows at a time
+    wp.prefetch(w2t, lane);                  // GEMM2's first weight slices travel while P3 runs
+    lptr_t xp3 = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+    for (int i0 = 0; i0 < RW; i0 += RB) {
+      f32x4 cur[RB], prev[RB], wa[RB];
+      f32x2 wb[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int m = rsub + RSTEP * (i0 + i);
+        const lptr_t row = xp3 + i * RSTEP * XS;
+        cur[i] = *(lvec_t)(row);
+        prev[i] = *(lvec_t)(row - 4);          // c4 == 0: discarded columns (pad / previous row)
+        wa[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS]);
+        wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 4]);
+        if constexpr (STREAM) {
+          if (cs.head) {
+            if (one_head) {
+              prev[i] = *reinterpret_cast<const f32x4*>(&HS[m * 4]);   // written by this same lane before P0
+            } else {
+              prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (a.hist1 != nullptr) prev[i] = *reinterpret_cast<const f32x4*>(a.hist1 + cs.hoff + m * 4);
+            }
+          }
+          if (cs.tail && a.hist1_out != nullptr) *reinterpret_cast<f32x4*>(a.hist1_out + cs.hoff + m * 4) = cur[i];
+        }
+      }
+      f32x4 o[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+        const float w[5] = {wa[i].x, wa[i].y, wa[i].z, wa[i].w, wb[i].x};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
+          o[i][e] = elu_fast(__fadd_rn(s, wb[i].y));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        *(lvec_t)(xp3 + i * RSTEP * XS) = o[i];
+      xp3 += RB * RSTEP * XS;
+      asm volatile("" : "+v"(xp3));
+      __builtin_amdgcn_sched_barrier(0);   // batches stay batches: hoisting every row's reads costs RW * 14 registers
+    }
+    if constexpr (!STREAM) {
+      // columns with t < 0 are the second conv's zero padding: only a clip's first tile has them (t0 = -8: column
+      // groups 0 and 1), so instead of a select per element in every tile those two lanes of a row overwrite their
+      // own outputs — same lane, program order, no hazard.  (STREAM: a clip's first samples take the cache instead.)
+      if (__builtin_amdgcn_readfirstlane(cs.t - c4) < 0) {       // uniform
+        if (c4 < 8) {
+          lptr_t xz = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+          for (int i = 0; i < RW; ++i) *(lvec_t)(xz + i * RSTEP * XS) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    lds_barrier();
+    STAMP(4);
+
+    // ---- P4
+    gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
+    // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
+    // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
+    const bool have_next = next < a.total_tiles;
+    const Cols cn = columns_of(have_next ? next : tile);
+    {
+      long nb;
+      int nt0;
+      if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
+        const int nf0 = (int)(have_next ? next : tile) * TO - 8;
+        const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
+        nb = q;
+        nt0 = nf0 - (int)q * T;
+      } else {
+        const long nt = have_next ? next : tile;
+        nb = nt / a.tiles;
+        nt0 = (int)(nt - nb * a.tiles) * TO - 8;
+      }
+      const float* nx = a.x + nb * (long)C * T;
+#pragma unroll
+      for (int i = 0; i < NTOUCH; ++i) {
+        int e = tid + NT * i;
+        e = e < C * LPR ? e : C * LPR - 1;
+        int tt = nt0 + (e % LPR) * 32;
+        tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
+        tv[i] = nx[(long)(e / LPR) * T + tt];
+      }
+    }
+    // ---- P5
+    lds_barrier();
+    STAMP(5);
+    acc_to_x<K>(acc, X, rowblk0, colblk, lane);
+    lds_barrier();
+    STAMP(6);
+
+    // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for columns >= 8, t < T; then this batch's x registers take the
+    //      next tile's rows
+    const bool out_ok = STREAM ? (c4 >= 8 && cs.t_in) : (c4 >= 8 && cs.t < T);
+    lptr_t xp6 = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+    for (int i0 = 0; i0 < RW; i0 += RB) {
+      f32x4 cur[RB], prev[RB], wc[RB];
+      f32x2 wb[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int m = rsub + RSTEP * (i0 + i);
+        const lptr_t row = xp6 + i * RSTEP * XS;
+        cur[i] = *(lvec_t)(row);
+        prev[i] = *(lvec_t)(row - 4);
+        wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 6]);   // w2_0, w2_1
+        wc[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS + 8]);   // w2_2, w2_3, w2_4, b2
+        if constexpr (STREAM) {
+          if (cs.head) {
+            if (one_head) {
+              prev[i] = *reinterpret_cast<const f32x4*>(&HS[(C + m) * 4]);
+            } else {
+              prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (a.hist2 != nullptr) prev[i] = *reinterpret_cast<const f32x4*>(a.hist2 + cs.hoff + m * 4);
+            }
+          }
+          if (cs.tail && a.hist2_out != nullptr) *reinterpret_cast<f32x4*>(a.hist2_out + cs.hoff + m * 4) = cur[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int m = rsub + RSTEP * (i0 + i);
+        const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+        const float w[5] = {wb[i].x, wb[i].y, wc[i].x, wc[i].y, wc[i].z};
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
+          s = __fmul_rn(__fadd_rn(s, wc[i].w), a.out_scale);
+          o[e] = __fadd_rn(s, xr[i0 + i][e]);
+        }
+        if (out_ok) *yrow(cs, m) = o;
+      }
+      if (have_next) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) xr[i0 + i] = *xrow(cn, rsub + RSTEP * (i0 + i));
+      }
+      xp6 += RB * RSTEP * XS;
+      asm volatile("" : "+v"(xp6));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP(7);
+    lds_barrier();   // the next tile's P0 overwrites X
+    tile = next;
+    cs = cn;
   }
-  if (a.sched != nullptr && tid == 0) {          // last workgroup out re-arms the scheduler for the next launch
+  if (K::NW == 4 && a.sched != nullptr && tid == 0) {          // last workgroup out re-arms the scheduler for the next launch
     if (atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) {
       a.sched[0] = 0;
       a.sched[1] = 0;
@@ -455,10 +585,12 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
     a.div_shift = (unsigned)(l - 1);
   }
+  using K = Cfg<C, STREAM>;
+  constexpr int TO = K::TO;
+  a.tiles = (a.T + TO - 1) / TO;
   a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
-  // persistent grid = exactly what can be resident (a surplus workgroup would only start after a
-  // resident one has walked its whole tile list)
-  // immutable per-device facts, looked up once per device (a process may drive several GPUs)
+  // persistent grid = exactly what can be resident (a surplus workgroup would only start after a resident one has
+  // walked its whole tile list).  Immutable per-device facts, looked up once per device (a process may drive several GPUs).
   constexpr int MAXDEV = 64;
   static std::atomic<int> resident_cache[MAXDEV];
   int dev = 0;
@@ -468,7 +600,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     int n_cu = 0, occ = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
       return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM>, 256, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM>, K::NT, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
     cached = n_cu * occ;
     if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
@@ -476,7 +608,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
   const long resident = cached;
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
@@ -495,7 +627,7 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
     return HILC_ERR_UNSUPPORTED;             // callers fall back to two hilc_dws_conv launches
   ResArgs a;
   a.x = x; a.w1t = w1t; a.dw1_w = dw1_w; a.dw1_b = dw1_b; a.w2t = w2t; a.dw2_w = dw2_w; a.dw2_b = dw2_b;
-  a.y = y; a.T = T; a.tiles = (T + TO - 1) / TO; a.pre_scale = pre_scale; a.out_scale = out_scale;
+  a.y = y; a.T = T; a.tiles = 0; a.pre_scale = pre_scale; a.out_scale = out_scale;
   a.hist1 = hist1; a.hist2 = hist2; a.hist1_out = hist1_out; a.hist2_out = hist2_out;
   a.sched = sched;
 #ifdef HILC_DEBUG_STAMPS
@@ -528,8 +660,11 @@ extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C,
   if (!wt || !packed) return HILC_ERR_NULL;
   if (!(C == 64 || C == 96 || C == 128 || C == 192)) return HILC_ERR_UNSUPPORTED;
   if (wt == packed) return HILC_ERR_UNSUPPORTED;
+  const int RH = C == 192 ? 2 : 1;
+  static_assert(Cfg<64, false>::RH == 1 && Cfg<96, false>::RH == 1 && Cfg<128, false>::RH == 1 && Cfg<192, false>::RH == 2 &&
+                Cfg<64, true>::RH == 1 && Cfg<96, true>::RH == 1 && Cfg<128, true>::RH == 1 && Cfg<192, true>::RH == 2, "packed layout");
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, packed, C);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, packed, C, RH);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

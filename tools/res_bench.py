@@ -20,8 +20,10 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
     w2 = torch.randn(C, C, device=dev) / C ** 0.5
     d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
     d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
+    p1, p2 = ops.resblock_pack(w1), ops.resblock_pack(w2)
+
     def fused():
-        return ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
+        return ops.resblock(x, p1, d1, b1, p2, d2, b2, 0.9, 0.5)
     def two():
         g = ops.dws_conv(x, w1, d1, b1, in_scale=0.9, in_elu=True, out_elu=True)
         return ops.dws_conv(g, w2, d2, b2, res=x, out_scale=0.5)
