@@ -39,6 +39,10 @@ SIGNATURES = {
     "hilc_conv_post": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_stft_logmag": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     "hilc_tail": [_p, _p, _p, C.c_long, _i, _i, _i, _p],
+    "hilc_spec_block_supported": [_i, _i, _i, _i],
+    "hilc_spec_block_packed_floats": [_i, _i],
+    "hilc_spec_block_pack": [_p, _p, _i, _i, _i, _p],
+    "hilc_spec_block": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _f, _p],
     "hilc_l2norm": [_p, _p, _i, _i, _i, _f, _f, _i, _p],
     "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_mse_finalize": [_p, _p, _i, _d, _p],
@@ -49,7 +53,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HilcodecLibraryError(RuntimeError):

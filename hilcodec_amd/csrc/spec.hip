@@ -1,0 +1,314 @@
+// One-launch SpecBlock for the long encoder stages (n_fft = 64 / 128 / 256, where one workgroup can hold every bin of
+// a 128-frame tile), gfx950:
+//
+//   y = x + out_scale * ( W * norm(log(max(|STFT(wav)|, 1e-5))) + bias )        (seanet.py:220-246, conv.py:329-358)
+//
+// Un-fused this is two launches (hilc_stft_logmag + hilc_pw_conv) with a [n_fft/2+1 x T] tensor through HBM between
+// them, a DFT GEMM whose n_fft+2 rows pad to the next multiple of 32 (66 -> 96, 130 -> 160/192 rows: a third of the
+// MFMAs of the two longest stages multiply zeros), and a 1x1 conv that is HBM-bound at K = 33 / 65.  Here, per tile:
+//   S0  the 127*hop + n_fft waveform samples of the tile -> LDS once (implicit im2col: a B element of the DFT GEMM is an
+//       LDS read at a per-lane offset + constant; one pad word per 16 samples keeps strided frames off one bank)
+//   A   DFT GEMM with exactly n_fft rows: (cos_k, sin_k) pairs k = 1..n_fft/2-1 in adjacent accumulator registers of
+//       a lane, and the two purely real bins (cos_0, cos_{n_fft/2}) share the pair slot of k = 0.  sin_0 is exactly
+//       zero and dropped; sin_{n_fft/2} (|.| <= 1.4e-4: the fp32 rounding of sin(-pi n), kept for fidelity) is ONE row:
+//       a scalar fmaf chain on the VALU for the lanes that own the Nyquist bin (n_fft FMAs per tile instead of a
+//       padded 32-row MFMA block)
+//   B   magnitude -> log -> normalise on the accumulators -> LDS tile S[bin][frame]
+//   C   1x1 conv as a second GEMM, B operand = S
+//   D   (acc + bias) * out_scale + x -> y through an LDS transpose (16-B coalesced loads / stores)
+// Both A operands (DFT basis, conv weight) stream from L2 in packed "MFMA lane order" (hilc_spec_block_pack), as in
+// the fused residual block: no LDS staging, no barrier inside either K loop.
+// Arithmetic is the un-fused kernels' (same fmaf chains in k order, same separate roundings in the magnitude and the
+// epilogue); only the summation grouping of nothing changes, so outputs are bit-identical to stft_logmag + pw_conv.
+#include "gemm_core.h"
+
+using namespace hilc;
+
+namespace {
+
+typedef const __attribute__((address_space(1))) float* gptr_t;
+typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+typedef __attribute__((address_space(3))) float* lptr_t;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int TF = 128;          // frames per tile
+constexpr int ES = 132;          // row stride of the epilogue transpose tile
+
+template <int N>
+struct SpecCfg {
+  static constexpr int CB = N / 32;                       // row blocks of both GEMMs (C == N)
+  static constexpr int NB = N / 2 + 1;                    // bins
+  static constexpr int KP = N <= 128 ? 4 : 2;             // k-pairs per weight register set
+  static constexpr int DEPTH = 3;                         // register sets: the loads run two sets ahead
+  static constexpr int SETS_A = N / 2 / KP;
+  static constexpr int KPAIRS_C = ((NB + 1) / 2 + KP - 1) / KP * KP;   // conv K = NB rows, zero-padded to whole sets
+  static constexpr int SETS_C = KPAIRS_C / KP;
+  static constexpr int SROWS = 2 * KPAIRS_C;              // rows of the LDS spectrogram tile
+  static constexpr int WPS = KP * CB / 4;                 // 16-B words per lane and set
+};
+
+struct SpecArgs {
+  const float* wav;      // [B][T]
+  const float* dft;      // packed [N x N] DFT basis (rows: see above)
+  const float* nyq;      // [N] sin_{N/2} row of the basis
+  const float* pw;       // packed [SROWS x N] conv weight (rows >= NB zero)
+  const float* bias;     // [N] or null
+  const float* x;        // [B][N][Tf] residual input
+  float* y;              // [B][N][Tf]
+  int T, Tf, hop, tiles;
+  float mean, stdv, out_scale;
+  int normalize;
+};
+
+// packed[((s * WPS + q) * 64 + lane) * 4 + e] = W[2 * (s*KP + j) + (lane >> 5)][32 * i + (lane & 31)],  q*4 + e = j*CB + i;
+// rows >= K read as zero
+__global__ __launch_bounds__(256) void spec_pack_kernel(const float* w, float* packed, int K, int M, int KP, int nsets) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int CB = M / 32, WPS = KP * CB / 4;
+  if (idx >= nsets * WPS * 256) return;
+  const int e = idx & 3, lane = (idx >> 2) & 63, word = idx >> 8;
+  const int q = word % WPS, s = word / WPS;
+  const int v = q * 4 + e, j = v / CB, i = v % CB;
+  const int k = 2 * (s * KP + j) + (lane >> 5), m = 32 * i + (lane & 31);
+  packed[idx] = k < K ? w[(long)k * M + m] : 0.f;
+}
+
+// One GEMM phase: acc[CB] (+)= A(packed, streamed from L2) * B, B element of k-pair P for this lane = bop(P).
+template <int CB, int KP, int DEPTH, int NSETS, class BOp>
+__device__ __forceinline__ void stream_gemm(const float* __restrict__ wt, f32x16 (&acc)[CB], int lane, BOp bop) {
+  constexpr int WPS = KP * CB / 4;
+  float a[DEPTH][KP][CB];
+  float b[DEPTH][KP];
+  auto load_word = [&](gptr_t wset, int slot, int q) {
+    const f32x4 v = *(gvec_t)(wset + q * 256 + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CB][(q * 4 + e) % CB] = v[e];
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) {
+    if (d < NSETS) {
+#pragma unroll
+      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q);
+#pragma unroll
+      for (int j = 0; j < KP; ++j) b[d][j] = bop(d * KP + j);
+    }
+  }
+  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
+  constexpr int LD_EVERY = KP * CB / WPS;            // = 4
+#pragma unroll
+  for (int s = 0; s < NSETS; ++s) {
+    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
+    const int sn = s + DEPTH - 1;
+    const bool more = sn < NSETS;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      if (more) b[nxt][j] = bop(sn * KP + j);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        const int n = j * CB + i;
+        if (more && n % LD_EVERY == 0) load_word((gptr_t)wn, nxt, n / LD_EVERY);
+        // asm, not the builtin: see resblock.hip (hipcc sinks builtin MFMAs below all operand loads of the phase)
+        if (s == 0 && j == 0)
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
+        else
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
+      }
+    }
+    if (more) {
+      wn += WPS * 256;
+      asm volatile("" : "+s"(wn));
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read hazard (the compiler cannot see into the asm)
+}
+
+__device__ __forceinline__ int padded(int u) { return u + (u >> 4); }
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
+  using K = SpecCfg<N>;
+  constexpr int CB = K::CB, NB = K::NB;
+  constexpr int SEG_MAX = (((TF - 1) * (N == 64 ? 1 : (N == 128 ? 2 : 8)) + N) * 17) / 16 + 2;   // hop is fixed per stage
+  constexpr int SE_FLOATS = K::SROWS * TF > 64 * ES ? K::SROWS * TF : 64 * ES;                      // S, later the epilogue tile
+  __shared__ __attribute__((aligned(16))) float seg[SEG_MAX];
+  __shared__ __attribute__((aligned(16))) float SE[SE_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int hop = a.hop;
+  const long b = blockIdx.x / a.tiles;
+  const int f0 = (int)(blockIdx.x - b * a.tiles) * TF;
+
+  // ---- S0: waveform segment (zero outside [0, T)); padding rows of the spectrogram tile
+  {
+    const int s0 = f0 * hop - (N - 1);
+    const int len = (TF - 1) * hop + N;
+    const float* wb = a.wav + b * (long)a.T;
+    for (int i = tid; i < len; i += 256) {
+      const int t = s0 + i;
+      seg[padded(i)] = (t >= 0 && t < a.T) ? wb[t] : 0.f;
+    }
+    for (int i = tid; i < (K::SROWS - NB) * TF; i += 256) SE[NB * TF + i] = 0.f;
+  }
+  lds_barrier();
+
+  const int col = wave * 32 + l31;                       // this lane's frame of the tile
+  f32x16 acc[CB];
+  // ---- A: DFT.  B element of k-pair P (k = 2P + kh) = seg[padded(col*hop + k)]: 8 per-lane offsets per 16-sample
+  //      slice, slices advance by the constant 17 words
+  {
+    int off[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) off[p] = padded(col * hop + 2 * p + kh);
+    // (col*hop + 2p + kh) + 16*kt: padded() adds exactly 17*kt because the slice step is a multiple of 16
+    auto bop = [&](int P) -> float { return seg[off[P & 7] + 17 * (P >> 3)]; };
+    stream_gemm<CB, K::KP, K::DEPTH, K::SETS_A>(a.dft, acc, lane, bop);
+  }
+  // ---- Nyquist bin's imaginary part: scalar chain in k order (lanes 0..31 own rows 0/1 = cos_0 / cos_{N/2})
+  float nyq_im = 0.f;
+  {
+    const int u0 = col * hop;
+#pragma unroll 8
+    for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded(u0 + k)], nyq_im);
+  }
+  // ---- B: magnitude -> log -> normalise -> S[bin][frame]
+  auto finish = [&](float re, float im) -> float {
+    const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // conv.py:357, no FMA contraction
+    float v = sqrtf(fmaxf(p, 1e-12f));
+    if (a.normalize != 2) v = logf(fmaxf(v, 1e-5f));                  // seanet.py:228
+    if (a.normalize == 1) v = __fdiv_rn(__fsub_rn(v, a.mean), a.stdv); // seanet.py:236
+    return v;
+  };
+  float* S = SE;
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int row = i * 32 + acc_row(r, lane);          // even
+      if (i == 0 && r == 0) {
+        if (kh == 0) {                                    // rows 0, 1: the two real bins
+          S[0 * TF + col] = finish(acc[0][0], 0.f);
+          S[(N / 2) * TF + col] = finish(acc[0][1], nyq_im);
+        } else {                                          // rows 4, 5: bin 2
+          S[(row >> 1) * TF + col] = finish(acc[0][0], acc[0][1]);
+        }
+      } else {
+        S[(row >> 1) * TF + col] = finish(acc[i][r], acc[i][r + 1]);
+      }
+    }
+  }
+  lds_barrier();
+
+  // ---- C: 1x1 conv, K = bins (zero-padded to whole register sets), B = S
+  {
+    const float* sl = S + kh * TF + col;
+    auto bop = [&](int P) -> float { return sl[2 * P * TF]; };
+    stream_gemm<CB, K::KP, K::DEPTH, K::SETS_C>(a.pw, acc, lane, bop);
+  }
+  lds_barrier();                                          // every wave is done reading S: it becomes the transpose tile
+
+  // ---- D: epilogue, 64 rows at a time: thread = (row, 16-column segment), 2 per thread
+  float* E = SE;
+  const long ybase = b * (long)N * a.Tf;
+#pragma unroll
+  for (int ch = 0; ch < (CB + 1) / 2; ++ch) {
+    if (ch > 0) lds_barrier();
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      if (i >= 2 * ch && i < 2 * ch + 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) E[((i - 2 * ch) * 32 + acc_row(r, lane)) * ES + col] = acc[i][r];
+      }
+    }
+    lds_barrier();
+    const int rows = (CB - 2 * ch) >= 2 ? 64 : 32;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int sg = tid + 256 * s;
+      const int row = sg >> 3, c0 = (sg & 7) * 16;
+      if (row >= rows) continue;
+      const int m = ch * 64 + row;
+      const float bv = a.bias != nullptr ? a.bias[m] : 0.f;
+      const float* er = E + row * ES + c0;
+      const long off0 = ybase + (long)m * a.Tf + f0 + c0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (f0 + c0 + 4 * g < a.Tf) {                    // Tf % 4 == 0: whole groups
+          f32x4 v = *reinterpret_cast<const f32x4*>(er + 4 * g);
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = v[e];
+            if (a.bias != nullptr) t = __fadd_rn(t, bv);
+            t = __fmul_rn(t, a.out_scale);
+            v[e] = __fadd_rn(t, rr[e]);                  // separate roundings: y.mul_(scale); x.add_(y)
+          }
+          *reinterpret_cast<f32x4*>(a.y + off0 + 4 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int N>
+int launch_spec(const SpecArgs& a, int B, hipStream_t s) {
+  const long blocks = (long)B * a.tiles;
+  if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL((spec_block_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+int stage_hop(int n_fft) { return n_fft == 64 ? 1 : (n_fft == 128 ? 2 : (n_fft == 256 ? 8 : 0)); }
+
+}  // namespace
+
+extern "C" int hilc_spec_block_supported(int n_fft, int hop, int C, int T) {
+  if (!(n_fft == 64 || n_fft == 128 || n_fft == 256)) return 0;
+  if (hop != stage_hop(n_fft) || C != n_fft || T <= 0) return 0;
+  const int Tf = (T - 1) / hop + 1;
+  return Tf % 4 == 0;
+}
+
+extern "C" int hilc_spec_block_packed_floats(int n_fft, int which) {
+  switch (n_fft) {
+    case 64: return which == 0 ? 64 * 64 : SpecCfg<64>::SROWS * 64;
+    case 128: return which == 0 ? 128 * 128 : SpecCfg<128>::SROWS * 128;
+    case 256: return which == 0 ? 256 * 256 : SpecCfg<256>::SROWS * 256;
+    default: return 0;
+  }
+}
+
+extern "C" int hilc_spec_block_pack(const float* w, float* packed, int K, int n_fft, int which, void* stream) {
+  if (!w || !packed) return HILC_ERR_NULL;
+  if (!(n_fft == 64 || n_fft == 128 || n_fft == 256) || w == packed) return HILC_ERR_UNSUPPORTED;
+  const int KP = n_fft == 64 ? SpecCfg<64>::KP : (n_fft == 128 ? SpecCfg<128>::KP : SpecCfg<256>::KP);
+  const int floats = hilc_spec_block_packed_floats(n_fft, which);
+  const int nsets = floats / n_fft / 2 / KP;
+  if (which == 0 ? K != n_fft : K != n_fft / 2 + 1) return HILC_ERR_SHAPE;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(spec_pack_kernel, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, packed,
+                     K, n_fft, KP, nsets);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_spec_block(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
+                               const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop, float mean,
+                               float stdv, int normalize, float out_scale, void* stream) {
+  if (!wav || !dft_packed || !nyq_sin || !pw_packed || !x || !y) return HILC_ERR_NULL;
+  if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_spec_block_supported(n_fft, hop, n_fft, T)) return HILC_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
+  SpecArgs a;
+  a.wav = wav; a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = x; a.y = y;
+  a.T = T; a.Tf = (T - 1) / hop + 1; a.hop = hop; a.tiles = (a.Tf + TF - 1) / TF;
+  a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
+  switch (n_fft) {
+    case 64: return launch_spec<64>(a, B, (hipStream_t)stream);
+    case 128: return launch_spec<128>(a, B, (hipStream_t)stream);
+    default: return launch_spec<256>(a, B, (hipStream_t)stream);
+  }
+}

@@ -27,6 +27,7 @@ FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside
 FUSE_RESBLOCK = True
 FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
+FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
 
 
 @dataclass
@@ -54,6 +55,7 @@ class SpecBlockSpec:
     wt: Tensor              # [n_fft/2+1, C]
     bias: Optional[Tensor]
     out_scale: float        # res_scale * scale_param; 1.0 when merged
+    fused: Optional[tuple] = None   # (dft_packed, nyq_sin, pw_packed) of the one-launch kernel (finalize_spec)
 
 
 @dataclass
@@ -131,6 +133,10 @@ def finalize_spec(spec):
     pointwise weights of the fused residual blocks, expanded up-sampling taps.  (They used to be hidden caches keyed
     by data_ptr inside the op wrappers; as part of the spec they are plain graph inputs for torch.compile.)"""
     for st in spec.stages:
+        sb = getattr(st, "spec", None)
+        if (isinstance(sb, SpecBlockSpec) and sb.fused is None and sb.basis_t.device.type in ("cuda", "meta")
+                and sb.n_fft in (64, 128, 256) and sb.wt.shape[1] == sb.n_fft):
+            sb.fused = ops.spec_block_tables(sb.basis_t, sb.wt, sb.n_fft)
         for rb in st.blocks:
             finalize_block(rb)
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
@@ -143,8 +149,8 @@ def spec_to(spec, device):
     import dataclasses
     if isinstance(spec, Tensor):
         return spec.to(device)
-    if isinstance(spec, list):
-        return [spec_to(v, device) for v in spec]
+    if isinstance(spec, (list, tuple)):
+        return type(spec)(spec_to(v, device) for v in spec)
     if dataclasses.is_dataclass(spec):
         return type(spec)(**{f.name: spec_to(getattr(spec, f.name), device) for f in dataclasses.fields(spec)})
     return spec
@@ -206,6 +212,10 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
 
 
 def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
+    if (FUSE_SPECBLOCK and sb.fused is not None and wav_hist is None
+            and ops.spec_block_supported(sb.n_fft, sb.hop, x.shape[1], wav.shape[2])):
+        return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, x, sb.n_fft, sb.hop, sb.mean, sb.std,
+                              sb.normalize, sb.out_scale)
     s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
     return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
 

@@ -316,6 +316,34 @@ _register("stft_logmag", "(Tensor wav, Tensor? hist, Tensor basis_t, int n_fft, 
           wav.new_empty(wav.shape[0], n_fft // 2 + 1, (wav.shape[2] - 1) // hop + 1))
 
 
+def _spec_block_pack(w, n_fft, which):
+    out = _new(w, lib.hilc_spec_block_packed_floats(n_fft, which))
+    check(lib.hilc_spec_block_pack(_ptr(w), _ptr(out), w.shape[0], n_fft, which, _stream()), "hilc_spec_block_pack")
+    return out
+
+
+_register("spec_block_pack", "(Tensor w, int n_fft, int which) -> Tensor", _spec_block_pack,
+          lambda w, n_fft, which: w.new_empty(lib.hilc_spec_block_packed_floats(n_fft, which)))
+
+
+def _spec_block(wav, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale):
+    B, one, T = wav.shape
+    Tf = (T - 1) // hop + 1
+    if tuple(x.shape) != (B, n_fft, Tf):
+        raise RuntimeError(f"spec_block: x must be [{B},{n_fft},{Tf}], got {tuple(x.shape)}")
+    y = torch.empty_like(x)
+    with _timed("spec_block", 2.0 * B * Tf * n_fft * (n_fft + 1 + n_fft // 2 + 1), f"N{n_fft} hop{hop}"):
+        check(lib.hilc_spec_block(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(x), _ptr(y),
+                                  B, T, n_fft, hop, mean, std, normalize, out_scale, _stream()), "hilc_spec_block")
+    return y
+
+
+_register("spec_block", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor x, int n_fft, "
+          "int hop, float mean, float std, int normalize, float out_scale) -> Tensor", _spec_block,
+          lambda wav, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale:
+          torch.empty_like(x))
+
+
 def _tail(x, hist, out):
     B, Cc, T = x.shape
     pad = out.shape[-1]
@@ -570,6 +598,30 @@ def stft_logmag(wav: Tensor, basis_t: Tensor, n_fft: int, hop: int, mean: float 
     """wav `[B,1,T]` -> `[B, n_fft/2+1, (T-1)//hop+1]`; normalize: False/0 log-mag, True/1 (log-mag - mean)/std,
     2 plain magnitude."""
     return _OPS.stft_logmag(wav, hist, basis_t, int(n_fft), int(hop), float(mean), float(std), int(normalize))
+
+
+def spec_block_supported(n_fft: int, hop: int, C: int, T: int) -> bool:
+    """mirror of hilc_spec_block_supported (plain Python: traceable)"""
+    if n_fft not in (64, 128, 256) or hop != {64: 1, 128: 2, 256: 8}[n_fft] or C != n_fft or T <= 0:
+        return False
+    return ((T - 1) // hop + 1) % 4 == 0
+
+
+def spec_block_tables(basis_t: Tensor, wt: Tensor, n_fft: int):
+    """The fused SpecBlock's operands from the un-fused ones: basis_t `[n_fft][m_pad]` (interleaved cos_k, sin_k columns,
+    k = 0..n_fft/2: hilc_stft_logmag's layout) -> packed DFT matrix with exactly n_fft rows + the sin_{n_fft/2} row;
+    wt `[n_fft/2+1][C]` -> packed conv weight.  Pure column selection: no arithmetic touches the basis."""
+    cols = [0, n_fft] + list(range(2, n_fft))              # cos_0, cos_{N/2}, then (cos_k, sin_k), k = 1..N/2-1
+    dft = basis_t[:, cols].contiguous()
+    nyq = basis_t[:, n_fft + 1].contiguous()
+    return (_OPS.spec_block_pack(dft, int(n_fft), 0), nyq, _OPS.spec_block_pack(wt.contiguous(), int(n_fft), 1))
+
+
+def spec_block(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor], x: Tensor,
+               n_fft: int, hop: int, mean: float = 0.0, std: float = 1.0, normalize=True, out_scale: float = 1.0) -> Tensor:
+    """One-launch SpecBlock (hilc_spec_block): wav `[B,1,T]`, x `[B,n_fft,T/hop]` -> x + out_scale * (W spec + bias)."""
+    return _OPS.spec_block(wav, dft_packed, nyq_sin, pw_packed, bias, x, int(n_fft), int(hop), float(mean), float(std),
+                           int(normalize), float(out_scale))
 
 
 def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = None) -> Tensor:

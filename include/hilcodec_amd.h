@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 2   /* 2: the fused residual block takes packed weights (hilc_resblock_pack_weights) */
+#define HILC_ABI_VERSION 3   /* 2: the fused residual block takes packed weights; 3: hilc_spec_block */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -177,6 +177,24 @@ int hilc_conv_post(const float* x, const float* hist, const float* w, const floa
  * Replaces: CausalSTFT (`conv.py:285-358`, `causal_layers.py:72-144`) + `seanet.py:224-236`. */
 int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const float* basis_t, float* spec,
                      int B, int T, int n_fft, int hop, float mean, float std, int normalize, void* stream);
+
+/* ---- one-launch SpecBlock (long encoder stages: n_fft 64 / 128 / 256 with the codec's hops 1 / 2 / 8, C == n_fft) ---
+ * y[b,m,f] = x[b,m,f] + out_scale * (sum_k pw[k][m] * spec[b,k,f] + bias[m]),  spec as in hilc_stft_logmag (zero history)
+ * i.e. SpecBlock.forward (`models/hilcodec/modules/seanet.py:220-246`: CausalSTFT `conv.py:329-358`, log / normalise,
+ * 1x1 conv, `x.add_(y.mul_(scale))`) without the [n_fft/2+1 x T_f] tensor ever reaching HBM.  Bit-identical to
+ * hilc_stft_logmag + hilc_pw_conv(res = x).  T_f = (T-1)/hop + 1 must be a multiple of 4; x, y 16-B aligned, y != x.
+ * dft_packed / pw_packed: hilc_spec_block_pack of
+ *   which = 0: the k-major `[n_fft][n_fft]` DFT matrix whose columns are (cos_0, cos_{N/2}, cos_1, sin_1, cos_2, sin_2, ...,
+ *              cos_{N/2-1}, sin_{N/2-1}) * hann — the reference basis without the all-zero sin_0 row and without sin_{N/2};
+ *   which = 1: the k-major `[n_fft/2+1][C]` conv weight (hilc_pw_conv's layout);
+ * nyq_sin `[n_fft]`: the sin_{N/2} row of the reference basis (|.| <= 1.4e-4, evaluated as a scalar chain).
+ * hilc_spec_block_packed_floats(n_fft, which) = size of a packed operand. */
+int hilc_spec_block_supported(int n_fft, int hop, int C, int T);
+int hilc_spec_block_packed_floats(int n_fft, int which);
+int hilc_spec_block_pack(const float* w, float* packed, int K, int n_fft, int which, void* stream);
+int hilc_spec_block(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
+                    const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop, float mean,
+                    float std, int normalize, float out_scale, void* stream);
 
 /* ---- streaming cache update: out[row][i] = last `pad` samples of [hist[row][0..hist_len) | x[row][0..T)] ----
  * Replaces: `cache = x[:, :, -causal_padding:]` after `torch.cat((cache, x), dim=2)`

@@ -8,7 +8,7 @@ import torch
 import hilcodec_amd
 from hilcodec_amd import engine, ops, synth
 
-OPS = ["pw_conv", "dws_conv", "dws_conv_stream", "up_conv_expand_taps", "up_conv", "resblock_pack", "resblock", "dw_conv",
+OPS = ["spec_block", "spec_block_pack", "pw_conv", "dws_conv", "dws_conv_stream", "up_conv_expand_taps", "up_conv", "resblock_pack", "resblock", "dw_conv",
        "dw_convtr", "conv_pre", "conv_post", "stft_logmag", "tail", "l2norm", "rvq_encode", "rvq_decode",
        "rvq_ema_stats", "rvq_ema_update"]
 
@@ -43,6 +43,8 @@ def test_offline_plan_on_meta_tensors(name):
     nq = mk["vq_kwargs"]["num_quantizers"]
     assert es.stages[0].blocks[0].pw1_packed is not None and es.stages[3].blocks[0].pw1_packed is None   # C=64 / C=512
     assert ds.stages[1].taps is not None and ds.stages[0].taps is None                                    # stride 5 / 8
+    assert es.stages[0].spec.fused is not None and es.stages[2].spec.fused is not None and es.stages[3].spec.fused is None
+    assert es.stages[0].spec.fused[0].shape == (64 * 64,) and es.stages[1].spec.fused[2].numel() % (128 * 8) == 0
     x = torch.empty(3, 1, 24000, device="meta")
     z = engine.run_encoder(es, x)
     assert z.shape == (3, 128, 75) and z.device.type == "meta"

@@ -418,3 +418,40 @@ def test_up_conv_stream_vs_unfused_and_offline(env, K, M, Tin, r, B):
     if (Tin * hops * r) % 4 == 0:
         full = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True)
         assert torch.equal(torch.cat(outs, dim=2), full)
+
+
+@pytest.mark.parametrize("n_fft,hop,B,T", [(64, 1, 2, 1000), (128, 2, 2, 2400), (256, 8, 3, 4000), (64, 1, 1, 128),
+                                           (128, 2, 1, 24), (256, 8, 1, 24000)])
+def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
+    """hilc_spec_block (STFT -> log-magnitude -> normalise -> 1x1 conv -> += in one launch, exactly n_fft DFT rows)
+    against hilc_stft_logmag + hilc_pw_conv bit for bit, and against the oracle's spec_block()."""
+    ops, fold, O, dev = env
+    C = n_fft
+    nb = n_fft // 2 + 1
+    basis = synth.stft_basis(n_fft)
+    bt = fold.stft_basis_layout(basis).to(dev)
+    w = rnd(n_fft + 1, C, nb, 1) / nb ** 0.5
+    wt = fold.pointwise_layout(w).to(dev)
+    bias = (rnd(n_fft + 2, C) * 0.1).to(dev)
+    wav = synth.synth_clips(B, T, seed=n_fft + T)
+    Tf = (T - 1) // hop + 1
+    x = rnd(n_fft + 3, B, C, Tf)
+    assert ops.spec_block_supported(n_fft, hop, C, T)
+    dft_p, nyq, pw_p = ops.spec_block_tables(bt, wt, n_fft)
+    for b_ in (bias, None):
+        y = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, b_, x.to(dev), n_fft, hop, -4.0, 2.8, True, 0.37)
+        s = ops.stft_logmag(wav.to(dev), bt, n_fft, hop, -4.0, 2.8, True)
+        y2 = ops.pw_conv(s, wt, b_, res=x.to(dev), out_scale=0.37)
+        assert torch.equal(y, y2), f"fused != unfused: {(y - y2).abs().max().item():.3e}"
+    # un-normalised log-magnitude (streaming model's merged form) and plain magnitude
+    for mode in (0, 2):
+        y = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, None, x.to(dev), n_fft, hop, 0.0, 1.0, mode, 1.0)
+        y2 = ops.pw_conv(ops.stft_logmag(wav.to(dev), bt, n_fft, hop, 0.0, 1.0, mode), wt, None, res=x.to(dev))
+        assert torch.equal(y, y2)
+    # oracle: log(max(|STFT|, 1e-5)), (. - mean) / std, 1x1 conv, x + scale * y
+    mag = O.causal_stft_mag(wav, basis, hop, pad=True, clamp=True)
+    spec = (torch.log(mag.clamp_min(1e-5)) - (-4.0)) / 2.8
+    ref = x + (F.conv1d(spec, w) + bias.cpu().view(1, -1, 1)) * 0.37
+    y = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, True, 0.37)
+    close(y, ref, 2e-4, "fused SpecBlock vs oracle")
+    assert not ops.spec_block_supported(512, 40, 512, T) and not ops.spec_block_supported(n_fft, hop, C, 4 * hop + 1)
