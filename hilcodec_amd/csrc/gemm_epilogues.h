@@ -1,0 +1,492 @@
+// Epilogues of the fp32-MFMA GEMM cores (gemm_core.h / gemm_lin.h / gemm_stream.h): they consume the accumulator tile
+// of a workgroup (MB 32-row blocks x 128 columns, wave w owns columns [32w, 32w+32)) and may route it through LDS to
+// apply a depthwise convolution along time before anything touches HBM.
+#pragma once
+#include "gemm_core.h"
+
+namespace hilc {
+
+// the linear-addressing cores use 32-bit byte offsets into x
+static inline bool lin_ok(int B, int K, int T) { return (long)B * K * T * 4 < (1L << 32); }
+
+// n / d for n < 2^31 as __umulhi(n, magic) >> shift (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l)/d); d >= 2
+static inline void div_magic(int d, unsigned& m, unsigned& sh) {
+  int l = 0;
+  while ((1L << l) < d) ++l;
+  if (l < 1) l = 1;
+  m = (unsigned)(((1ULL << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+  sh = (unsigned)(l - 1);
+}
+
+// ================================================================================================
+// Epilogues
+// ================================================================================================
+struct PwEpilogue {
+  float* y;
+  const float* bias;
+  const float* res;
+  int M, T;
+  long ncols;
+  float out_scale;
+  template <int MB> static constexpr int lds_floats() { return 0; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    long n = ntile * BN + wave * 32 + (lane & 31);
+    if (n >= ncols) return;
+    long b = n / T;
+    long colbase = b * (long)M * T + (n - b * T);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + i * 32 + acc_row(r, lane);
+        if (row < M) {
+          long off = colbase + (long)row * T;
+          float v = acc[i][r];
+          // separate roundings, like the reference's `y.mul_(scale)` then `x.add_(y)` (no FMA contraction)
+          if (bias != nullptr) v = __fadd_rn(v, bias[row]);
+          v = __fmul_rn(v, out_scale);
+          if (res != nullptr) v = __fadd_rn(v, res[off]);
+          y[off] = v;
+        }
+      }
+    }
+  }
+};
+
+// rows come in (re, im) pairs: row 2k = cos_k, row 2k+1 = sin_k; regs (2j, 2j+1) of a lane hold a pair.
+struct StftEpilogue {
+  float* spec;
+  int nbins, Tf;  // nbins = n_fft/2+1
+  long ncols;
+  float mean, stdv;
+  int normalize;
+  template <int MB> static constexpr int lds_floats() { return 0; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    long n = ntile * BN + wave * 32 + (lane & 31);
+    if (n >= ncols) return;
+    long b = n / Tf;
+    long colbase = b * (long)nbins * Tf + (n - b * Tf);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        int row = m0 + i * 32 + acc_row(r, lane);
+        int bin = row >> 1;
+        if (bin < nbins) {
+          float re = acc[i][r], im = acc[i][r + 1];
+          // x.square().sum(dim=1).clamp_min(1e-12).sqrt()  (conv.py:357) — no FMA contraction
+          float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+          float v = sqrtf(fmaxf(p, 1e-12f));
+          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
+          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
+          spec[colbase + (long)bin * Tf] = v;
+        }
+      }
+    }
+  }
+};
+
+// the same for per-clip column tiles (tile = frames [128*tix, +128) of clip b), used with StftSegB
+struct StftClipEpilogue {
+  float* spec;
+  int nbins, Tf, tiles;
+  float mean, stdv;
+  int normalize;
+  template <int MB> static constexpr int lds_floats() { return 0; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    const long b = ntile / tiles;
+    const int f = (int)(ntile - b * tiles) * BN + wave * 32 + (lane & 31);
+    if (f >= Tf) return;
+    const long colbase = b * (long)nbins * Tf + f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = m0 + i * 32 + acc_row(r, lane);
+        const int bin = row >> 1;
+        if (bin < nbins) {
+          const float re = acc[i][r], im = acc[i][r + 1];
+          const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // conv.py:357, no FMA contraction
+          float v = sqrtf(fmaxf(p, 1e-12f));
+          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
+          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
+          spec[colbase + (long)bin * Tf] = v;
+        }
+      }
+    }
+  }
+};
+
+constexpr int HS = 132;  // LDS row stride of the post-GEMM tile: 128 columns + 4, keeps float4 alignment
+
+constexpr int CH = 2;    // the post-GEMM tile goes through LDS in chunks of CH 32-row blocks (33 KB)
+
+// chunk c of the accumulators -> LDS rows [0, 32*nblk)
+template <int MB>
+__device__ __forceinline__ int acc_chunk_to_lds(const f32x16 (&acc)[MB], float* smem, int c, int wave, int lane) {
+  __syncthreads();  // previous readers of the tile (staged K slices / previous chunk) are done
+  const int nblk = (MB - c * CH) < CH ? (MB - c * CH) : CH;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    if (i >= c * CH && i < c * CH + CH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        smem[((i - c * CH) * 32 + acc_row(r, lane)) * HS + wave * 32 + (lane & 31)] = acc[i][r];
+    }
+  }
+  __syncthreads();
+  return nblk;
+}
+
+// Pointwise epilogue through LDS (T % 4 == 0, 16-B aligned y / res): the accumulator layout gives every lane 16
+// scattered rows of one column (64 dword stores + 64 dword residual loads per lane and tile); transposed through
+// LDS a thread owns 16 consecutive columns of one row: 4 x 16-B stores / loads.  Same arithmetic as PwEpilogue.
+struct PwLdsEpilogue {
+  float* y;
+  const float* bias;
+  const float* res;
+  int M, T;
+  long ncols;
+  unsigned t_magic, t_shift;   // n / T for n < 2^31
+  float out_scale;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int seg = tid + NT * s;
+        const int row = seg >> 3, c0 = (seg & 7) * 16;
+        const int m = m0 + ch * CH * 32 + row;
+        if (row >= nblk * 32 || m >= M) continue;
+        const float bv = bias != nullptr ? bias[m] : 0.f;
+        const long n0 = ntile * BN + c0;
+        unsigned b = __umulhi((unsigned)(n0 < ncols ? n0 : 0), t_magic) >> t_shift;
+        int t = (int)((n0 < ncols ? n0 : 0) - (long)b * T);
+        const float* hrow = smem + row * HS + c0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (n0 + 4 * g < ncols) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(hrow + 4 * g);
+            const long off = ((long)b * M + m) * (long)T + t;
+            // separate roundings, like the reference's `y.mul_(scale)` then `x.add_(y)` (no FMA contraction)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = v[e];
+              if (bias != nullptr) a = __fadd_rn(a, bv);
+              v[e] = __fmul_rn(a, out_scale);
+            }
+            if (res != nullptr) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], rr[e]);
+            }
+            *reinterpret_cast<f32x4*>(y + off) = v;
+          }
+          t += 4;
+          if (t >= T) { t = 0; ++b; }
+        }
+      }
+    }
+  }
+};
+
+// depthwise causal conv, k = 5, stride 1, on the GEMM tile: column c <-> time t0 + c, t0 = tix*124 - 4;
+// output column c >= 4 reads columns c-4..c.  Thread = (row, 16-column segment).
+struct Dw5Epilogue {
+  float* y;
+  const float* dw_w;   // [M][5]
+  const float* dw_b;   // [M] or null
+  const float* res;    // [B][M][T] or null (may alias y)
+  int M, T, tiles;
+  float out_scale;
+  int out_elu;
+  int vec;  // T % 4 == 0 and y/res 16-B aligned
+  static constexpr int STEP = BN - 4;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    long b = ntile / tiles;
+    int tix = (int)(ntile - b * tiles);
+    int t0 = tix * STEP - 4;
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+    const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      int seg = tid + NT * s;
+      int row = seg >> 3, c0 = (seg & 7) * 16;
+      int m = m0 + ch * CH * 32 + row;
+      if (row >= nblk * 32 || m >= M) continue;
+      float v[20];
+      const float* hrow = smem + row * HS;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        int c = c0 - 4 + 4 * g;
+        float4 q = c >= 0 ? *reinterpret_cast<const float4*>(hrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+      }
+      float w[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
+      float bias = dw_b ? dw_b[m] : 0.f;
+      long rowoff = (b * M + m) * (long)T;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int c = c0 + 4 * g;
+        int t = t0 + c;
+        if (c < 4 || t >= T) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) a = fmaf(w[j], v[4 * g + e + j], a);   // taps in order j = 0..4
+          a = __fadd_rn(a, bias);
+          a = __fmul_rn(a, out_scale);
+          o[e] = a;
+        }
+        if (vec) {
+          if (res != nullptr) {
+            float4 rr = *reinterpret_cast<const float4*>(res + rowoff + t);
+            o[0] = __fadd_rn(o[0], rr.x); o[1] = __fadd_rn(o[1], rr.y);
+            o[2] = __fadd_rn(o[2], rr.z); o[3] = __fadd_rn(o[3], rr.w);
+          }
+          if (out_elu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
+          }
+          *reinterpret_cast<float4*>(y + rowoff + t) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (t + e < T) {
+              float a = o[e];
+              if (res != nullptr) a = __fadd_rn(a, res[rowoff + t + e]);
+              if (out_elu) a = elu_fast(a);
+              y[rowoff + t + e] = a;
+            }
+          }
+        }
+      }
+    }
+    }
+  }
+};
+
+// depthwise causal conv k = 2r, stride r (down-sampling): tile covers times [o0*r - H, +128) with
+// H = round_up(r, 4); output o0 + i reads columns H - r + i*r + j, j < 2r.
+struct DwStrideEpilogue {
+  float* y;
+  const float* dw_w;   // [M][2r]
+  const float* dw_b;
+  int M, To, tiles, r, H, n_out;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  // One wave = one row at a time (row = wave + 4*s is wave-uniform, so the 2r taps and the bias come through
+  // scalar loads), lane = output i of the tile (n_out <= 64): no index division, coalesced stores, taps unrolled
+  // for the strides the codec uses.
+  template <int MB, int KR>
+  __device__ void rows(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane) const {
+    const long b = ntile / tiles;
+    const int o0 = (int)(ntile - b * tiles) * n_out;
+    const int k = KR > 0 ? KR : 2 * r;
+    const int o = o0 + lane;
+    const bool live = lane < n_out && o < To;
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+      for (int s = 0; s < 8 * nblk; ++s) {
+        const int row = __builtin_amdgcn_readfirstlane(wave + 4 * s);
+        const int m = m0 + ch * CH * 32 + row;
+        if (m >= M) break;                      // uniform
+        const float* w = dw_w + (long)m * k;
+        const float* h = smem + row * HS + (H - r) + (live ? lane : 0) * r;
+        float a = 0.f;
+        if (KR > 0) {
+#pragma unroll
+          for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(w[j], h[j], a);
+        } else {
+          for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+        }
+        if (dw_b) a = __fadd_rn(a, dw_b[m]);
+        if (live) y[(b * M + m) * (long)To + o] = a;
+      }
+    }
+  }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int) const {
+    switch (r) {                                 // uniform
+      case 2: rows<MB, 4>(acc, smem, m0, ntile, wave, lane); break;
+      case 4: rows<MB, 8>(acc, smem, m0, ntile, wave, lane); break;
+      case 5: rows<MB, 10>(acc, smem, m0, ntile, wave, lane); break;
+      case 8: rows<MB, 16>(acc, smem, m0, ntile, wave, lane); break;
+      default: rows<MB, 0>(acc, smem, m0, ntile, wave, lane); break;
+    }
+  }
+};
+
+// Streaming hop, wide layers (T <= 128 samples per stream and call): a tile holds `cpt` WHOLE clips
+// (columns q*T + t), so there is no halo — the samples before t = 0 come from the cache
+// hist[b][m][pad] (pad = ksize - stride: the last `pad` pointwise outputs of the previous hop,
+// causal_layers.py:147-165) and the new cache is written from the tile.  Generic k / stride (k5 s1 and
+// k = 2r stride r); work item = (clip, row, output), output fastest: y / hist_out writes of a clip's
+// rows are contiguous.
+struct DwSegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][k]
+  const float* dw_b;
+  const float* res;    // [B][M][To] or null (may alias y)
+  const float* hist;   // [B][M][pad] or null (zeros)
+  float* hist_out;     // [B][M][pad] or null
+  int B, M, T, To, k, stride, pad, cpt;
+  unsigned to_magic, to_shift, pad_magic, pad_shift;   // n / To, n / pad as __umulhi(n, magic) >> shift
+  float out_scale;
+  int out_elu;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+      const int rows = 32 * nblk;                       // 32 or 64
+      const int rsh = nblk == 1 ? 5 : 6;
+      for (int idx = tid; idx < cpt * rows * To; idx += NT) {
+        const int qr = To == 1 ? idx : (int)(__umulhi((unsigned)idx, to_magic) >> to_shift);   // idx / To
+        const int o = idx - qr * To;
+        const int q = qr >> rsh, row = qr & (rows - 1);
+        const long b = ntile * cpt + q;
+        const int m = m0 + ch * CH * 32 + row;
+        if (m >= M || b >= B) continue;
+        const float* h = smem + row * HS + q * T;
+        const float* hp = hist != nullptr ? hist + (b * M + m) * (long)pad + pad : nullptr;   // hp[tt], tt < 0
+        const float* w = dw_w + (long)m * k;
+        float a = 0.f;
+        for (int j = 0; j < k; ++j) {
+          const int tt = o * stride - pad + j;
+          const float v = tt >= 0 ? h[tt] : (hp != nullptr ? hp[tt] : 0.f);
+          a = fmaf(w[j], v, a);
+        }
+        if (dw_b != nullptr) a = __fadd_rn(a, dw_b[m]);
+        a = __fmul_rn(a, out_scale);
+        const long off = (b * M + m) * (long)To + o;
+        if (res != nullptr) a = __fadd_rn(a, res[off]);
+        if (out_elu) a = elu_fast(a);
+        y[off] = a;
+      }
+      if (hist_out != nullptr) {
+        for (int idx = tid; idx < cpt * rows * pad; idx += NT) {
+          const int qr = pad == 1 ? idx : (int)(__umulhi((unsigned)idx, pad_magic) >> pad_shift);   // idx / pad
+          const int i = idx - qr * pad;
+          const int q = qr >> rsh, row = qr & (rows - 1);
+          const long b = ntile * cpt + q;
+          const int m = m0 + ch * CH * 32 + row;
+          if (m >= M || b >= B) continue;
+          const int src = T - pad + i;          // last `pad` samples of [cache | this hop]
+          const long ho = (b * M + m) * (long)pad;
+          hist_out[ho + i] = src >= 0 ? smem[row * HS + q * T + src] : (hist != nullptr ? hist[ho + pad + src] : 0.f);
+        }
+      }
+    }
+  }
+};
+
+// k = 5, stride 1, T % 4 == 0 (so T >= 4 and a 4-column group never straddles clips): vector form of the above.
+// Thread = (row, 16-column segment) like Dw5Epilogue; the 4 samples before a clip's t = 0 come from the cache.
+struct Dw5SegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][5]
+  const float* dw_b;
+  const float* res;
+  const float* hist;   // [B][M][4] or null
+  float* hist_out;     // [B][M][4] or null
+  int B, M, T, cpt;
+  unsigned t_magic, t_shift;   // n / T
+  float out_scale;
+  int out_elu;
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int seg = tid + NT * s;
+        const int row = seg >> 3, c0 = (seg & 7) * 16;
+        const int m = m0 + ch * CH * 32 + row;
+        if (row >= nblk * 32 || m >= M) continue;
+        float v[20];
+        const float* hrow = smem + row * HS;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+          const int c = c0 - 4 + 4 * g;
+          const f32x4 qv = c >= 0 ? *reinterpret_cast<const f32x4*>(hrow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          v[4 * g] = qv.x; v[4 * g + 1] = qv.y; v[4 * g + 2] = qv.z; v[4 * g + 3] = qv.w;
+        }
+        float w[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
+        const float bias = dw_b ? dw_b[m] : 0.f;
+        int q = (int)(__umulhi((unsigned)c0, t_magic) >> t_shift);   // clip of the first column
+        int t = c0 - q * T;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const long b = ntile * cpt + q;
+          const bool live = (c0 + 4 * g) < cpt * T && b < B;
+          if (live) {
+            const long bm = b * M + m;
+            float win[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) win[e] = v[4 * g + e];
+            if (t == 0) {                     // clip start: the previous 4 pointwise outputs are the cache
+              f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (hist != nullptr) hv = *reinterpret_cast<const f32x4*>(hist + bm * 4);
+              win[0] = hv.x; win[1] = hv.y; win[2] = hv.z; win[3] = hv.w;
+            }
+            if (hist_out != nullptr && t == T - 4)
+              *reinterpret_cast<f32x4*>(hist_out + bm * 4) = f32x4{win[4], win[5], win[6], win[7]};
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = 0.f;
+#pragma unroll
+              for (int j = 0; j < 5; ++j) a = fmaf(w[j], win[e + j], a);
+              a = __fadd_rn(a, bias);
+              o[e] = __fmul_rn(a, out_scale);
+            }
+            const long off = bm * (long)T + t;
+            if (res != nullptr) {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], rr[e]);
+            }
+            if (out_elu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
+            }
+            *reinterpret_cast<f32x4*>(y + off) = o;
+          }
+          t += 4;
+          if (t >= T) { t = 0; ++q; }
+        }
+      }
+    }
+  }
+};
+
+
+}  // namespace hilc
