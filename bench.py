@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense; no xf32/TF32 on gfx950
 FLOP_PER_AUDIO_SECOND = {"hil_speech": 34.219e9, "hil_music": 34.298e9}
-MFMA_KINDS = ("pw_conv", "dws_conv", "resblock", "up_conv")
+MFMA_KINDS = ("pw_conv", "dws_conv", "resblock", "up_conv", "spec_block")
 
 
 def parse():
@@ -223,7 +223,7 @@ def main():
             flops = sum(tot[k][1] for k in kinds)
             secs = sum(tot[k][2] for k in kinds)
             roof.update({
-                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM> ("
+                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM> + spec_block_kernel<N> ("
                           + "+".join(kinds) + "; fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": flops / secs / 1e12, "frac": flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "launches_per_step": launches // args.steps, "avg_launch_us": secs / launches * 1e6,

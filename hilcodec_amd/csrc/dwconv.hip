@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
   a.y[b * (long)a.T + t] = acc;
 }
 
-// Offline fast path (k = 5, T % 4 == 0, no history): 64 threads x 4 samples = 256 samples per block;
+// Fast path (k = 5, T % 4 == 0; offline, or a streaming hop with its [B][C][4] cache): 64 threads x 4 samples = 256 samples per block;
 // the block's 4 waves split the channels (c = wave, wave+4, ...) so 4x more loads are in flight, each
 // lane moves 16 B, each sample's prologue (ELU) is evaluated once; partial sums meet in LDS.  The
 // channel order of the reduction is c ascending within a wave, then wave 0..3 — fixed.
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
       const f32x4 cur = prologue4v(*reinterpret_cast<const f32x4*>(xrow + t), a.in_scale, a.in_elu);
       f32x4 prev = {0.f, 0.f, 0.f, 0.f};
       if (t >= 4) prev = prologue4v(*reinterpret_cast<const f32x4*>(xrow + t - 4), a.in_scale, a.in_elu);
+      else if (a.hist != nullptr) prev = *reinterpret_cast<const f32x4*>(a.hist + (b * a.C + c) * 4);   // cache: activated samples
       const float v[8] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w};
       float w[5];
 #pragma unroll
@@ -323,7 +324,8 @@ extern "C" int hilc_conv_post(const float* x, const float* hist, const float* w,
   a.tblocks = (unsigned)ceil_div(T, 256);
   if ((long)B * a.tblocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   dim3 grid((unsigned)((long)B * a.tblocks));
-  const bool fast = ksize == 5 && T % 4 == 0 && hist == nullptr && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const bool fast = ksize == 5 && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (hist == nullptr || (reinterpret_cast<uintptr_t>(hist) & 15) == 0);
   HILC_CLEAR_ERROR();
   if (fast) hipLaunchKernelGGL(conv_post_k5_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -16,6 +16,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace hilc {
@@ -142,23 +144,50 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const float* __restrict__ wt, 
   ep.template run<MB>(acc, smem, m0, ntile, wave, lane, tid);
 }
 
+// CUs of the current device (immutable per device, looked up once per device)
+inline int device_cus() {
+  constexpr int MAXDEV = 64;
+  static std::atomic<int> cache[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int n = dev >= 0 && dev < MAXDEV ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    if (dev >= 0 && dev < MAXDEV) cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+// Row-tile height (in 32-row MFMA blocks) of a launch with `ntiles` column tiles and m32 row blocks.  Big launches
+// (offline: thousands of workgroups) want the tallest tile: every staged activation feeds MB MFMAs.  Small launches
+// (a streaming hop: a few hundred workgroups on 256 CUs) are decided by load balance instead: the busiest CU
+// serialises ceil(workgroups / CUs) tiles on its matrix pipe, so 384 tall tiles (2 on half of the CUs, 1 on the rest)
+// lose a quarter of the chip against 768 tiles of half the height.  Cost = tiles on the busiest CU x (MB + fixed
+// per-tile overhead); per-output arithmetic (k order) does not depend on MB, results are bit-identical.
+inline int pick_mb(int m32, long ntiles) {
+  const long cus = device_cus();
+  const long groups = (ntiles + 7) / 8;
+  int best = 1;
+  double best_cost = 1e300;
+  for (int mb = 1; mb <= 4; ++mb) {
+    const long mtiles = (m32 + mb - 1) / mb;
+    const long wgs = groups * 8 * mtiles;
+    const double cost = (double)((wgs + cus - 1) / cus) * (mb + 0.5);
+    if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && mb > best)) {   // ties: the taller tile
+      best_cost = cost < best_cost ? cost : best_cost;
+      best = mb;
+    }
+  }
+  return best;
+}
+
 template <class Loader, class Epilogue>
 int launch_gemm(const float* wt, int M, int K, int ldw, long ntiles, bool lds_epilogue, const Loader& ld,
                 const Epilogue& ep, hipStream_t s) {
-  int m32 = (M + 31) / 32;
   (void)lds_epilogue;
-  int MB;  // row-tile height in 32-row MFMA blocks: fewest padded rows, then tallest
-  if (m32 % 4 == 0) MB = 4;
-  else if (m32 % 3 == 0) MB = 3;
-  else if (m32 < 4) MB = m32;
-  else {
-    int pad4 = (4 - m32 % 4) % 4, pad3 = (3 - m32 % 3) % 3;
-    MB = pad3 < pad4 ? 3 : 4;
-  }
-  // few columns (a streaming hop's T = 1 layers: 8 column tiles): shorter row tiles so that more CUs get a
-  // workgroup — per-output arithmetic (k order) is unchanged
-  long groups = (ntiles + 7) / 8;
-  while (MB > 1 && groups * 8 * ((m32 + MB - 1) / MB) < 128) --MB;
+  const int m32 = (M + 31) / 32;
+  const int MB = pick_mb(m32, ntiles);
+  const long groups = (ntiles + 7) / 8;
   int mtiles = (m32 + MB - 1) / MB;
   long blocks = groups * 8 * mtiles;
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;

@@ -366,17 +366,9 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
 
 template <class BOp, class Epilogue>
 int launch_lin(const float* wt, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep, hipStream_t s) {
-  int m32 = (M + 31) / 32;
-  int MB;
-  if (m32 % 4 == 0) MB = 4;
-  else if (m32 % 3 == 0) MB = 3;
-  else if (m32 < 4) MB = m32;
-  else {
-    int pad4 = (4 - m32 % 4) % 4, pad3 = (3 - m32 % 3) % 3;
-    MB = pad3 < pad4 ? 3 : 4;
-  }
-  long groups = (ntiles + 7) / 8;
-  while (MB > 1 && groups * 8 * ((m32 + MB - 1) / MB) < 128) --MB;
+  const int m32 = (M + 31) / 32;
+  const int MB = pick_mb(m32, ntiles);
+  const long groups = (ntiles + 7) / 8;
   int mtiles = (m32 + MB - 1) / MB;
   long blocks = groups * 8 * mtiles;
   if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;

@@ -73,6 +73,6 @@ print(f"{'#':>3} {'kind':10} {'shape':22} {'ms':>8} {'%':>6} {'rate':>10}")
 for key in order:
     i, kind, tag = key
     work, sec = agg[key]
-    rate = f"{work / sec / 1e12:7.1f} TF" if kind in ("pw_conv", "stft", "rvq_encode", "dws_conv", "resblock", "up_conv") else f"{work / sec / 1e9:7.0f} GB/s"
+    rate = f"{work / sec / 1e12:7.1f} TF" if kind in ("pw_conv", "stft", "rvq_encode", "dws_conv", "resblock", "up_conv", "spec_block") else f"{work / sec / 1e9:7.0f} GB/s"
     print(f"{i:3d} {kind:10} {tag:22} {sec * 1e3:8.3f} {100 * sec / tot:6.2f} {rate:>10}")
 print(f"total {tot * 1e3:.2f} ms/step")

@@ -38,7 +38,7 @@ with open(out_prefix + "_kernel_stats.csv", "w") as f:
         fe, wr, n = traffic.get(k, [0, 0, 0])
         f.write(f"{k},{s['calls']},{s['total_ms']:.3f},{s['avg_us']:.1f},{s['pct']:.2f},"
                 f"{fe * 1024 * 2 / 1e9 / steps_total:.3f},{wr * 1024 / 1e9 / steps_total:.3f}\n")
-mf = [k for k in stats if (k.startswith(("gemm_kernel", "gemm_lin_kernel")) and "Stft" not in k) or k.startswith("resblock")]
+mf = [k for k in stats if (k.startswith(("gemm_kernel", "gemm_lin_kernel")) and "Stft" not in k) or k.startswith(("resblock", "spec_block"))]
 tot_ms = sum(stats[k]["total_ms"] for k in mf)
 calls = sum(stats[k]["calls"] for k in mf)
 rd = sum(traffic[k][0] for k in mf) * 1024 * 2
