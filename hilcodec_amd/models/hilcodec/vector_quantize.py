@@ -160,8 +160,11 @@ class ResidualVQ(nn.Module):
             else:
                 high = len(self.layers)
             idx, q, num_replaces = self._train_update(x, high)
-            loss = torch.nn.functional.mse_loss(x, q)          # commitment loss: gradient w.r.t. x (`:233`)
-            q = q + x - x.detach()                              # straight-through estimator (`:234-235`)
+            # Values of the reference's training outputs (`:233-235`).  This branch UPDATES CODEBOOKS ONLY: x reaches it
+            # from raw kernels without an autograd graph (and HILCodec.forward runs under no_grad), so neither the
+            # commitment loss nor the straight-through term carries a gradient here — encoder training is out of scope.
+            loss = torch.nn.functional.mse_loss(x, q)
+            q = q + x - x.detach()
             if return_indices:
                 return q, num_replaces, loss, idx
             return q, num_replaces, loss

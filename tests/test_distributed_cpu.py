@@ -139,3 +139,116 @@ def test_two_rank_gloo_rvq_ema_all_reduce():
     assert np.array_equal(np.concatenate([idx0, idx1]), idx.numpy())
     for k in st:
         assert np.allclose(st0[k], st[k].numpy(), rtol=1e-6, atol=1e-7), k
+
+
+def _cpu_rvq_kernels():
+    """CPU stand-ins with the kernels' contracts (hilc_rvq_encode / _ema_stats / _ema_update), built on the oracle:
+    they let the PRODUCT's multi-rank code (`ResidualVQ._train_update` -> `distributed.all_reduce_sum_` ->
+    `replace_` -> `broadcast_`) run under gloo without a GPU; the kernels themselves are checked by -m gpu tests."""
+    import torch.nn.functional as F
+    from oracle import hilcodec_oracle as O
+
+    def rvq_encode(z, cb, cbt, norms, n, channel_last=False, stage_major=False, want_q=True, want_loss=False):
+        sd = {f"quantizer.layers.{i}.embed": cb[i] for i in range(cb.shape[0])}
+        zz = z.transpose(1, 2) if channel_last else z
+        q, _, loss, idx = O.rvq_forward(sd, zz, int(n), cb.shape[0])
+        if stage_major:
+            idx = idx.transpose(0, 1).contiguous()
+        return idx, (q.transpose(1, 2) if channel_last else q), (loss if want_loss else None)
+
+    def rvq_ema_stats(z, cb, idx, n, channel_last=False, stage_major=False):
+        res = (z if channel_last else z.transpose(1, 2)).reshape(-1, z.shape[-1 if channel_last else 1]).clone()
+        K = cb.shape[1]
+        rows = []
+        for s in range(n):
+            ind = (idx[s] if stage_major else idx[:, s]).reshape(-1)
+            onehot = F.one_hot(ind, K).float()
+            rows.append(torch.cat([onehot.sum(0), (onehot.t() @ res).reshape(-1)]))
+            res = res - F.embedding(ind, cb[s])
+        return torch.stack(rows)
+
+    def rvq_ema_update(embed, ema_num, ema_embed, bucket, decay):
+        n, K, C = embed.shape
+        ema_num.mul_(decay).add_(bucket[:, :K], alpha=1 - decay)
+        ema_embed.mul_(decay).add_(bucket[:, K:].view(n, K, C), alpha=1 - decay)
+        embed.copy_(ema_embed / ema_num.unsqueeze(2))
+
+    return rvq_encode, rvq_ema_stats, rvq_ema_update
+
+
+def _make_product_rvq(threshold):
+    import numpy as np
+    from hilcodec_amd import synth
+    from hilcodec_amd.models.hilcodec.vector_quantize import ResidualVQ
+    nq, K, Dm = 2, 1024, 128
+    rvq = ResidualVQ(num_quantizers=nq, dropout=False, channel_last=False, dim=Dm, codebook_size=K, kmeans_init=False,
+                     decay=0.9, ema_num_threshold=threshold, ema_num_initial=0.5).train()
+    for i, l in enumerate(rvq.layers):
+        e = torch.from_numpy(synth.normalish(300 + i, K * Dm) * np.float32(0.3)).view(K, Dm)
+        l.embed.copy_(e)
+        l.ema_embed.copy_(e * 0.5)
+    return rvq
+
+
+def _product_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    import torch.distributed as dist
+    from hilcodec_amd import distributed as D, ops, synth
+    torch.set_num_threads(2)
+    D.init("gloo")
+    ops.rvq_encode, ops.rvq_ema_stats, ops.rvq_ema_update = _cpu_rvq_kernels()
+    total, Tn = 6, 30
+    z = torch.from_numpy(synth.normalish(55, total * 128 * Tn)).view(total, 128, Tn)
+    lo, hi = D.shard_range(total, rank, world)
+    out = {}
+    for name, thr in (("plain", 0.0), ("expiry", 0.46)):
+        rvq = _make_product_rvq(thr)
+        torch.manual_seed(100 + rank)                  # ranks draw DIFFERENT replacement candidates: rank 0's must win
+        qz, num_replaces, loss = rvq(z[lo:hi])
+        out[name] = ({k: v.numpy().copy() for k, v in rvq.state_dict().items() if not k.endswith("_extra_state")},
+                     num_replaces.copy(), float(loss))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_product_rvq_training_path():
+    """The PRODUCT's data-parallel RVQ training step (not the oracle's): one bucketed all-reduce for all stages, then
+    EMA update; with an expiry threshold, dead codes are replaced by rank 0's broadcast choice.  Both ranks must end
+    with identical codebooks; without expiry they must equal a single process that saw the whole batch."""
+    import numpy as np
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_product_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name in ("plain", "expiry"):
+        st0, nr0, _ = res[0][name]
+        st1, nr1, _ = res[1][name]
+        assert (nr0 == nr1).all()
+        for k in st0:
+            assert np.array_equal(st0[k], st1[k]), (name, k)
+    assert res[0]["expiry"][1].sum() > 0 and not res[0]["plain"][1].any()
+    # single process, whole batch, same stand-in kernels
+    sys.path.insert(0, ROOT)
+    from hilcodec_amd import ops, synth
+    saved = (ops.rvq_encode, ops.rvq_ema_stats, ops.rvq_ema_update)
+    try:
+        ops.rvq_encode, ops.rvq_ema_stats, ops.rvq_ema_update = _cpu_rvq_kernels()
+        rvq = _make_product_rvq(0.0)
+        z = torch.from_numpy(synth.normalish(55, 6 * 128 * 30)).view(6, 128, 30)
+        rvq(z)
+        single = {k: v.numpy() for k, v in rvq.state_dict().items() if not k.endswith("_extra_state")}
+    finally:
+        ops.rvq_encode, ops.rvq_ema_stats, ops.rvq_ema_update = saved
+    for k, v in single.items():
+        assert np.allclose(res[0]["plain"][0][k], v, rtol=1e-6, atol=1e-7), k
