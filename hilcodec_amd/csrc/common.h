@@ -67,4 +67,33 @@ __device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
   return ok ? v : z;
 }
 
+// SpecBlock front half on one (re, im) pair: |.| -> log -> normalise (conv.py:357, seanet.py:228,236).
+//   reference:  m = sqrt(max(re^2 + im^2, 1e-12));  v = (log(max(m, 1e-5)) - mean) / std
+// evaluated as  v = c1 * log2(max(re^2 + im^2, 1e-10)) + c0,  c1 = ln2 / (2 std), c0 = -mean / std   (the two clamps
+// collapse: max(sqrt(max(p, 1e-12)), 1e-5) == sqrt(max(p, 1e-10))), i.e. 5 VALU + one v_log_f32 instead of a correctly
+// rounded sqrt, a full logf and an IEEE division (~50 VALU + 3 transcendentals, which cost as much matrix-pipe time as
+// a third of the DFT of the n_fft = 64 stage).  The clamp keeps the argument in the normal range, so the raw
+// v_log_f32 (1 ulp on log2) needs no denormal scaling; the result differs from the step-by-step form by a few 1e-7
+// absolute on values in [-12, 3] — inside the reference's own rounding and far inside the 2e-4 spectrogram bar
+// (tests/test_gpu_ops.py::test_stft_vs_oracle, golden SpecBlock KATs).  The squares stay separately rounded.
+// mode 0: plain log-magnitude (c1 = ln2 / 2, c0 = 0: the streaming model's merged normalisation), 1: normalised,
+// 2: magnitude only (CausalSTFT as a layer): sqrt(max(p, 1e-12)) on v_sqrt_f32.
+struct SpecFinish {
+  float c1, c0;
+  int mode;
+  __host__ __device__ static SpecFinish make(float mean, float stdv, int normalize) {
+    SpecFinish f;
+    f.mode = normalize;
+    const float half_ln2 = 0.34657359027997264f;
+    f.c1 = normalize == 1 ? half_ln2 / stdv : half_ln2;
+    f.c0 = normalize == 1 ? -mean / stdv : 0.f;
+    return f;
+  }
+  __device__ __forceinline__ float operator()(float re, float im) const {
+    const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    if (mode == 2) return __builtin_amdgcn_sqrtf(fmaxf(p, 1e-12f));
+    return fmaf(c1, __builtin_amdgcn_logf(fmaxf(p, 1e-10f)), c0);
+  }
+};
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

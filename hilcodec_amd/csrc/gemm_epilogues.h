@@ -66,6 +66,7 @@ struct StftEpilogue {
 
   template <int MB>
   __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    const SpecFinish fin = SpecFinish::make(mean, stdv, normalize);
     long n = ntile * BN + wave * 32 + (lane & 31);
     if (n >= ncols) return;
     long b = n / Tf;
@@ -79,10 +80,7 @@ struct StftEpilogue {
         if (bin < nbins) {
           float re = acc[i][r], im = acc[i][r + 1];
           // x.square().sum(dim=1).clamp_min(1e-12).sqrt()  (conv.py:357) — no FMA contraction
-          float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-          float v = sqrtf(fmaxf(p, 1e-12f));
-          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
-          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
+          const float v = fin(re, im);
           spec[colbase + (long)bin * Tf] = v;
         }
       }
@@ -100,6 +98,7 @@ struct StftClipEpilogue {
 
   template <int MB>
   __device__ void run(const f32x16 (&acc)[MB], float*, int m0, long ntile, int wave, int lane, int) const {
+    const SpecFinish fin = SpecFinish::make(mean, stdv, normalize);
     const long b = ntile / tiles;
     const int f = (int)(ntile - b * tiles) * BN + wave * 32 + (lane & 31);
     if (f >= Tf) return;
@@ -112,10 +111,7 @@ struct StftClipEpilogue {
         const int bin = row >> 1;
         if (bin < nbins) {
           const float re = acc[i][r], im = acc[i][r + 1];
-          const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // conv.py:357, no FMA contraction
-          float v = sqrtf(fmaxf(p, 1e-12f));
-          if (normalize != 2) v = logf(fmaxf(v, 1e-5f));                 // seanet.py:228
-          if (normalize == 1) v = __fdiv_rn(__fsub_rn(v, mean), stdv);   // seanet.py:236
+          const float v = fin(re, im);
           spec[colbase + (long)bin * Tf] = v;
         }
       }

@@ -77,12 +77,23 @@ struct Cfg {
   static constexpr int RPI = 256 / NCOL;             // rows covered by one wave instruction of the element-wise phases
   static constexpr int RSTEP = RPI * NW;
   static constexpr int RW = C / RSTEP;               // rows per lane there
-  static constexpr int RB = 4;                       // rows per batch there
+#ifndef HILC_RES_RB
+#define HILC_RES_RB 4
+#endif
+  static constexpr int RB = HILC_RES_RB;             // rows per batch there
   // weight stream: DEPTH register sets of KP k-pairs each; the loads run DEPTH-1 sets (= (DEPTH-1)*KP*CBW MFMAs per
   // wave, twice that in wall time with two waves per SIMD) ahead of their use
+#ifdef HILC_RES_KP
+  static constexpr int KP = HILC_RES_KP;
+  static constexpr int DEPTH = HILC_RES_DEPTH;
+#else
   static constexpr int KP = C >= 128 ? 4 : 8;
   static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? 3 : 2);
-  static constexpr int MINW = NW == 8 ? 2 : 2;       // waves per SIMD the register budget must allow
+#endif
+#ifndef HILC_RES_MINW
+#define HILC_RES_MINW 2
+#endif
+  static constexpr int MINW = NW == 8 ? 2 : HILC_RES_MINW;   // waves per SIMD the register budget must allow
   static_assert(NW % (NCOL / 32) == 0 && CB % RH == 0 && RW % RB == 0 && C % RSTEP == 0, "tile split");
 };
 

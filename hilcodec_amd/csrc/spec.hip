@@ -173,13 +173,7 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
     for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded(u0 + k)], nyq_im);
   }
   // ---- B: magnitude -> log -> normalise -> S[bin][frame]
-  auto finish = [&](float re, float im) -> float {
-    const float p = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // conv.py:357, no FMA contraction
-    float v = sqrtf(fmaxf(p, 1e-12f));
-    if (a.normalize != 2) v = logf(fmaxf(v, 1e-5f));                  // seanet.py:228
-    if (a.normalize == 1) v = __fdiv_rn(__fsub_rn(v, a.mean), a.stdv); // seanet.py:236
-    return v;
-  };
+  const SpecFinish finish = SpecFinish::make(a.mean, a.stdv, a.normalize);
   float* S = SE;
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
