@@ -54,7 +54,10 @@ struct SpecArgs {
   const float* nyq;      // [N] sin_{N/2} row of the basis
   const float* pw;       // packed [SROWS x N] conv weight (rows >= NB zero)
   const float* bias;     // [N] or null
-  const float* x;        // [B][N][Tf] residual input
+  const float* x;        // [B][N][Tf] residual input (PRE: unused)
+  const float* pre_w;    // PRE: first encoder conv `[N][5]` and its bias `[N]` — x is computed here, not read
+  const float* pre_b;
+  float pre_in_scale;
   float* y;              // [B][N][Tf]
   int T, Tf, hop, tiles;
   float mean, stdv, out_scale;
@@ -125,7 +128,11 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ wt, f32x16
 
 __device__ __forceinline__ int padded(int u) { return u + (u >> 4); }
 
-template <int N>
+// PRE (n_fft = 64, hop 1 only): the residual input is the first encoder conv of the SAME waveform tile,
+// x[m][t] = sum_j pre_w[m][j] * (pre_in_scale * wav[t-4+j]) + pre_b[m]   (seanet.py:280-286; hilc_conv_pre's arithmetic),
+// evaluated from the LDS segment in the epilogue: the [64 x T] tensor conv_pre would write and this kernel re-read
+// (2 x 1.57 GB at B = 256) never exists.
+template <int N, bool PRE>
 __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   using K = SpecCfg<N>;
   constexpr int CB = K::CB, NB = K::NB;
@@ -230,7 +237,25 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
       for (int g = 0; g < 4; ++g) {
         if (f0 + c0 + 4 * g < a.Tf) {                    // Tf % 4 == 0: whole groups
           f32x4 v = *reinterpret_cast<const f32x4*>(er + 4 * g);
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+          f32x4 rr;
+          if constexpr (PRE) {
+            // column c of the tile is time f0 + c (hop 1) = segment sample c + N - 1
+            float w5[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) w5[j] = a.pre_w[m * 5 + j];
+            float sm[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[j] = seg[padded(c0 + 4 * g + j + N - 5)] * a.pre_in_scale;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float acc5 = 0.f;
+#pragma unroll
+              for (int j = 0; j < 5; ++j) acc5 = fmaf(w5[j], sm[e + j], acc5);
+              rr[e] = a.pre_b != nullptr ? __fadd_rn(acc5, a.pre_b[m]) : acc5;
+            }
+          } else {
+            rr = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float t = v[e];
@@ -245,12 +270,12 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   }
 }
 
-template <int N>
+template <int N, bool PRE = false>
 int launch_spec(const SpecArgs& a, int B, hipStream_t s) {
   const long blocks = (long)B * a.tiles;
   if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((spec_block_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((spec_block_kernel<N, PRE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
@@ -300,9 +325,26 @@ extern "C" int hilc_spec_block(const float* wav, const float* dft_packed, const 
   a.wav = wav; a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = x; a.y = y;
   a.T = T; a.Tf = (T - 1) / hop + 1; a.hop = hop; a.tiles = (a.Tf + TF - 1) / TF;
   a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
+  a.pre_w = nullptr; a.pre_b = nullptr; a.pre_in_scale = 1.f;
   switch (n_fft) {
     case 64: return launch_spec<64>(a, B, (hipStream_t)stream);
     case 128: return launch_spec<128>(a, B, (hipStream_t)stream);
     default: return launch_spec<256>(a, B, (hipStream_t)stream);
   }
+}
+
+extern "C" int hilc_spec_block_conv_pre(const float* wav, const float* dft_packed, const float* nyq_sin,
+                                        const float* pw_packed, const float* bias, const float* pre_w, const float* pre_b,
+                                        float pre_in_scale, float* y, int B, int T, int n_fft, int hop, int pre_ksize,
+                                        float mean, float stdv, int normalize, float out_scale, void* stream) {
+  if (!wav || !dft_packed || !nyq_sin || !pw_packed || !pre_w || !y) return HILC_ERR_NULL;
+  if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (n_fft != 64 || hop != 1 || pre_ksize != 5 || !hilc_spec_block_supported(n_fft, hop, n_fft, T)) return HILC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(y) & 15) return HILC_ERR_UNSUPPORTED;
+  SpecArgs a;
+  a.wav = wav; a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = nullptr; a.y = y;
+  a.pre_w = pre_w; a.pre_b = pre_b; a.pre_in_scale = pre_in_scale;
+  a.T = T; a.Tf = T; a.hop = 1; a.tiles = (a.Tf + TF - 1) / TF;
+  a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
+  return launch_spec<64, true>(a, B, (hipStream_t)stream);
 }

@@ -246,9 +246,18 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         wav_hist = caches[0]
         new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
         ci = 1
-    x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
-    for st in es.stages:
-        x = _spec_block(st.spec, x, wav, wav_hist)
+    sb0 = es.stages[0].spec
+    fuse_pre = (FUSE_SPECBLOCK and not streaming and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
+                and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2]))
+    if fuse_pre:
+        # first conv + first SpecBlock in one launch: the [64 x T] tensor between them never exists
+        x = ops.spec_block_conv_pre(wav, sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b,
+                                    es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale)
+    else:
+        x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
+    for si, st in enumerate(es.stages):
+        if not (fuse_pre and si == 0):
+            x = _spec_block(st.spec, x, wav, wav_hist)
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
                           caches_out[ci:ci + 2] if caches_out is not None else None)

@@ -344,6 +344,26 @@ _register("spec_block", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor 
           torch.empty_like(x))
 
 
+def _spec_block_conv_pre(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std,
+                         normalize, out_scale):
+    B, one, T = wav.shape
+    Cc, k = pre_w.shape
+    y = _new(wav, B, Cc, T)
+    with _timed("spec_block", 2.0 * B * T * n_fft * (n_fft + 1 + n_fft // 2 + 1) + 2.0 * B * T * Cc * k,
+                f"N{n_fft} hop{hop} +conv_pre"):
+        check(lib.hilc_spec_block_conv_pre(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias),
+                                           _ptr(pre_w), _ptr(pre_b), pre_in_scale, _ptr(y), B, T, n_fft, hop, k, mean, std,
+                                           normalize, out_scale, _stream()), "hilc_spec_block_conv_pre")
+    return y
+
+
+_register("spec_block_conv_pre", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor pre_w, "
+          "Tensor? pre_b, float pre_in_scale, int n_fft, int hop, float mean, float std, int normalize, float out_scale) "
+          "-> Tensor", _spec_block_conv_pre,
+          lambda wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std, normalize,
+          out_scale: wav.new_empty(wav.shape[0], pre_w.shape[0], wav.shape[2]))
+
+
 def _tail(x, hist, out):
     B, Cc, T = x.shape
     pad = out.shape[-1]
@@ -622,6 +642,14 @@ def spec_block(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tens
     """One-launch SpecBlock (hilc_spec_block): wav `[B,1,T]`, x `[B,n_fft,T/hop]` -> x + out_scale * (W spec + bias)."""
     return _OPS.spec_block(wav, dft_packed, nyq_sin, pw_packed, bias, x, int(n_fft), int(hop), float(mean), float(std),
                            int(normalize), float(out_scale))
+
+
+def spec_block_conv_pre(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor],
+                        pre_w: Tensor, pre_b: Optional[Tensor], pre_in_scale: float, n_fft: int, hop: int, mean: float = 0.0,
+                        std: float = 1.0, normalize=True, out_scale: float = 1.0) -> Tensor:
+    """First encoder stage in one launch: conv_pre(wav) + SpecBlock branch (hilc_spec_block_conv_pre)."""
+    return _OPS.spec_block_conv_pre(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, float(pre_in_scale), int(n_fft),
+                                    int(hop), float(mean), float(std), int(normalize), float(out_scale))
 
 
 def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = None) -> Tensor:

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 3   /* 2: the fused residual block takes packed weights; 3: hilc_spec_block */
+#define HILC_ABI_VERSION 4   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -195,6 +195,14 @@ int hilc_spec_block_pack(const float* w, float* packed, int K, int n_fft, int wh
 int hilc_spec_block(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
                     const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop, float mean,
                     float std, int normalize, float out_scale, void* stream);
+/* First encoder stage: the same with x = the first conv of the same waveform, computed in the kernel instead of read:
+ * x[b,m,t] = sum_j pre_w[m][j] * (pre_in_scale * wav[b, t-(ksize-1)+j]) + pre_b[m]   (hilc_conv_pre; `seanet.py:280-286`,
+ * `:368-372`).  n_fft = 64, hop = 1, pre_ksize = 5 only (HILC_ERR_UNSUPPORTED otherwise); bit-identical to
+ * hilc_conv_pre + hilc_spec_block. */
+int hilc_spec_block_conv_pre(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
+                             const float* bias, const float* pre_w, const float* pre_b, float pre_in_scale, float* y,
+                             int B, int T, int n_fft, int hop, int pre_ksize, float mean, float std, int normalize,
+                             float out_scale, void* stream);
 
 /* ---- streaming cache update: out[row][i] = last `pad` samples of [hist[row][0..hist_len) | x[row][0..T)] ----
  * Replaces: `cache = x[:, :, -causal_padding:]` after `torch.cat((cache, x), dim=2)`

@@ -455,3 +455,12 @@ def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
     y = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, True, 0.37)
     close(y, ref, 2e-4, "fused SpecBlock vs oracle")
     assert not ops.spec_block_supported(512, 40, 512, T) and not ops.spec_block_supported(n_fft, hop, C, 4 * hop + 1)
+    if n_fft == 64:
+        # first encoder stage: conv_pre computed inside the SpecBlock launch == conv_pre launch + SpecBlock launch
+        pw_, pb_ = (rnd(71, 64, 5) * 0.5).to(dev), (rnd(72, 64) * 0.1).to(dev)
+        for pb in (pb_, None):
+            x0 = ops.conv_pre(wav.to(dev), pw_, pb, in_scale=1 / 0.1122080159)
+            y_two = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x0, n_fft, hop, -4.0, 2.8, True, 0.37)
+            y_one = ops.spec_block_conv_pre(wav.to(dev), dft_p, nyq, pw_p, bias, pw_, pb, 1 / 0.1122080159, n_fft, hop,
+                                            -4.0, 2.8, True, 0.37)
+            assert torch.equal(y_one, y_two), f"{(y_one - y_two).abs().max().item():.3e}"
