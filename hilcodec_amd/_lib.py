@@ -42,8 +42,8 @@ SIGNATURES = {
     "hilc_spec_block_supported": [_i, _i, _i, _i],
     "hilc_spec_block_packed_floats": [_i, _i],
     "hilc_spec_block_pack": [_p, _p, _i, _i, _i, _p],
-    "hilc_spec_block_conv_pre": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p],
-    "hilc_spec_block": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _f, _p],
+    "hilc_spec_block_conv_pre": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p],
+    "hilc_spec_block": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _f, _p],
     "hilc_l2norm": [_p, _p, _i, _i, _i, _f, _f, _i, _p],
     "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_mse_finalize": [_p, _p, _i, _d, _p],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HilcodecLibraryError(RuntimeError):

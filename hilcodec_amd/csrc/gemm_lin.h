@@ -62,19 +62,20 @@ struct RowsB {
   struct State {
     unsigned off[BP], off_last[BP];
     float sc_last[BP];
-    bool ok;
+    float sc;       // in_scale, or 0 for a column group outside [0, T) (halo / ragged tile): 0 * finite == 0 and
+                    // ELU(0) == 0, so the zero padding costs no select in the K loop
   };
   __device__ State init(long ntile, int tid, int krem) const {
     State s;
     const LinCol lc = cols.at(ntile, (tid & 31) * 4);
-    s.ok = lc.ok;
+    s.sc = (lc.ok || !Cols::kZeroInvalid) ? in_scale : 0.f;
 #pragma unroll
     for (int h = 0; h < BP; ++h) {
       const int r = (tid >> 5) + 8 * h;
       const int rl = r < krem ? r : krem - 1;
       s.off[h] = lc.ok ? (lc.off + (unsigned)r * (unsigned)T) * 4u : 0u;
       s.off_last[h] = lc.ok ? (lc.off + (unsigned)rl * (unsigned)T) * 4u : 0u;
-      s.sc_last[h] = r < krem ? in_scale : 0.f;
+      s.sc_last[h] = r < krem ? s.sc : 0.f;
     }
     return s;
   }
@@ -83,8 +84,7 @@ struct RowsB {
     return *reinterpret_cast<const f32x4*>(sb + (last ? s.off_last[h] : s.off[h]));
   }
   __device__ f32x4 xform(const State& s, Raw v, bool last, int h) const {
-    if (Cols::kZeroInvalid) v = zero_unless(s.ok, v);
-    const float sc = last ? s.sc_last[h] : in_scale;
+    const float sc = last ? s.sc_last[h] : s.sc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float t = v[e] * sc;

@@ -50,6 +50,8 @@ struct SpecCfg {
 
 struct SpecArgs {
   const float* wav;      // [B][T]
+  const float* hist;     // streaming: [B][hist_len] waveform history (samples before t = 0), or null (zeros)
+  int hist_len;
   const float* dft;      // packed [N x N] DFT basis (rows: see above)
   const float* nyq;      // [N] sin_{N/2} row of the basis
   const float* pw;       // packed [SROWS x N] conv weight (rows >= NB zero)
@@ -152,9 +154,13 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
     const int s0 = f0 * hop - (N - 1);
     const int len = (TF - 1) * hop + N;
     const float* wb = a.wav + b * (long)a.T;
+    const float* hb = a.hist != nullptr ? a.hist + b * (long)a.hist_len + a.hist_len : nullptr;   // hb[t], t < 0
     for (int i = tid; i < len; i += 256) {
       const int t = s0 + i;
-      seg[padded(i)] = (t >= 0 && t < a.T) ? wb[t] : 0.f;
+      float v = 0.f;
+      if (t >= 0) { if (t < a.T) v = wb[t]; }
+      else if (hb != nullptr && t >= -a.hist_len) v = hb[t];
+      seg[padded(i)] = v;
     }
     for (int i = tid; i < (K::SROWS - NB) * TF; i += 256) SE[NB * TF + i] = 0.f;
   }
@@ -314,15 +320,18 @@ extern "C" int hilc_spec_block_pack(const float* w, float* packed, int K, int n_
   return HILC_OK;
 }
 
-extern "C" int hilc_spec_block(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
-                               const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop, float mean,
-                               float stdv, int normalize, float out_scale, void* stream) {
+extern "C" int hilc_spec_block(const float* wav, const float* hist, int hist_len, const float* dft_packed,
+                               const float* nyq_sin, const float* pw_packed, const float* bias, const float* x, float* y,
+                               int B, int T, int n_fft, int hop, float mean, float stdv, int normalize, float out_scale,
+                               void* stream) {
   if (!wav || !dft_packed || !nyq_sin || !pw_packed || !x || !y) return HILC_ERR_NULL;
   if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (hist != nullptr && hist_len < n_fft - 1) return HILC_ERR_SHAPE;
   if (!hilc_spec_block_supported(n_fft, hop, n_fft, T)) return HILC_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
   SpecArgs a;
-  a.wav = wav; a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = x; a.y = y;
+  a.wav = wav; a.hist = hist; a.hist_len = hist_len;
+  a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = x; a.y = y;
   a.T = T; a.Tf = (T - 1) / hop + 1; a.hop = hop; a.tiles = (a.Tf + TF - 1) / TF;
   a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
   a.pre_w = nullptr; a.pre_b = nullptr; a.pre_in_scale = 1.f;
@@ -333,16 +342,18 @@ extern "C" int hilc_spec_block(const float* wav, const float* dft_packed, const 
   }
 }
 
-extern "C" int hilc_spec_block_conv_pre(const float* wav, const float* dft_packed, const float* nyq_sin,
-                                        const float* pw_packed, const float* bias, const float* pre_w, const float* pre_b,
-                                        float pre_in_scale, float* y, int B, int T, int n_fft, int hop, int pre_ksize,
-                                        float mean, float stdv, int normalize, float out_scale, void* stream) {
+extern "C" int hilc_spec_block_conv_pre(const float* wav, const float* hist, int hist_len, const float* dft_packed,
+                                        const float* nyq_sin, const float* pw_packed, const float* bias, const float* pre_w,
+                                        const float* pre_b, float pre_in_scale, float* y, int B, int T, int n_fft, int hop,
+                                        int pre_ksize, float mean, float stdv, int normalize, float out_scale, void* stream) {
   if (!wav || !dft_packed || !nyq_sin || !pw_packed || !pre_w || !y) return HILC_ERR_NULL;
   if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (hist != nullptr && hist_len < n_fft - 1) return HILC_ERR_SHAPE;
   if (n_fft != 64 || hop != 1 || pre_ksize != 5 || !hilc_spec_block_supported(n_fft, hop, n_fft, T)) return HILC_ERR_UNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(y) & 15) return HILC_ERR_UNSUPPORTED;
   SpecArgs a;
-  a.wav = wav; a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = nullptr; a.y = y;
+  a.wav = wav; a.hist = hist; a.hist_len = hist_len;
+  a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = nullptr; a.y = y;
   a.pre_w = pre_w; a.pre_b = pre_b; a.pre_in_scale = pre_in_scale;
   a.T = T; a.Tf = T; a.hop = 1; a.tiles = (a.Tf + TF - 1) / TF;
   a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;

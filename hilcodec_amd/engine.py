@@ -212,10 +212,10 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
 
 
 def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
-    if (FUSE_SPECBLOCK and sb.fused is not None and wav_hist is None
+    if (FUSE_SPECBLOCK and sb.fused is not None and (wav_hist is None or wav_hist.shape[-1] >= sb.n_fft - 1)
             and ops.spec_block_supported(sb.n_fft, sb.hop, x.shape[1], wav.shape[2])):
         return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, x, sb.n_fft, sb.hop, sb.mean, sb.std,
-                              sb.normalize, sb.out_scale)
+                              sb.normalize, sb.out_scale, hist=wav_hist)
     s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
     return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
 
@@ -247,12 +247,13 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
         ci = 1
     sb0 = es.stages[0].spec
-    fuse_pre = (FUSE_SPECBLOCK and not streaming and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
-                and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2]))
+    fuse_pre = (FUSE_SPECBLOCK and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
+                and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2])
+                and (wav_hist is None or wav_hist.shape[-1] >= 63))
     if fuse_pre:
         # first conv + first SpecBlock in one launch: the [64 x T] tensor between them never exists
         x = ops.spec_block_conv_pre(wav, sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b,
-                                    es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale)
+                                    es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
     for si, st in enumerate(es.stages):

@@ -326,41 +326,43 @@ _register("spec_block_pack", "(Tensor w, int n_fft, int which) -> Tensor", _spec
           lambda w, n_fft, which: w.new_empty(lib.hilc_spec_block_packed_floats(n_fft, which)))
 
 
-def _spec_block(wav, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale):
+def _spec_block(wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale):
     B, one, T = wav.shape
+    hl = hist.shape[-1] if hist is not None else 0
     Tf = (T - 1) // hop + 1
     if tuple(x.shape) != (B, n_fft, Tf):
         raise RuntimeError(f"spec_block: x must be [{B},{n_fft},{Tf}], got {tuple(x.shape)}")
     y = torch.empty_like(x)
     with _timed("spec_block", 2.0 * B * Tf * n_fft * (n_fft + 1 + n_fft // 2 + 1), f"N{n_fft} hop{hop}"):
-        check(lib.hilc_spec_block(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(x), _ptr(y),
+        check(lib.hilc_spec_block(_ptr(wav), _ptr(hist), hl, _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(x), _ptr(y),
                                   B, T, n_fft, hop, mean, std, normalize, out_scale, _stream()), "hilc_spec_block")
     return y
 
 
-_register("spec_block", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor x, int n_fft, "
-          "int hop, float mean, float std, int normalize, float out_scale) -> Tensor", _spec_block,
-          lambda wav, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale:
+_register("spec_block", "(Tensor wav, Tensor? hist, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor x, "
+          "int n_fft, int hop, float mean, float std, int normalize, float out_scale) -> Tensor", _spec_block,
+          lambda wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale:
           torch.empty_like(x))
 
 
-def _spec_block_conv_pre(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std,
+def _spec_block_conv_pre(wav, hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std,
                          normalize, out_scale):
     B, one, T = wav.shape
+    hl = hist.shape[-1] if hist is not None else 0
     Cc, k = pre_w.shape
     y = _new(wav, B, Cc, T)
     with _timed("spec_block", 2.0 * B * T * n_fft * (n_fft + 1 + n_fft // 2 + 1) + 2.0 * B * T * Cc * k,
                 f"N{n_fft} hop{hop} +conv_pre"):
-        check(lib.hilc_spec_block_conv_pre(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias),
+        check(lib.hilc_spec_block_conv_pre(_ptr(wav), _ptr(hist), hl, _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias),
                                            _ptr(pre_w), _ptr(pre_b), pre_in_scale, _ptr(y), B, T, n_fft, hop, k, mean, std,
                                            normalize, out_scale, _stream()), "hilc_spec_block_conv_pre")
     return y
 
 
-_register("spec_block_conv_pre", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor pre_w, "
-          "Tensor? pre_b, float pre_in_scale, int n_fft, int hop, float mean, float std, int normalize, float out_scale) "
-          "-> Tensor", _spec_block_conv_pre,
-          lambda wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std, normalize,
+_register("spec_block_conv_pre", "(Tensor wav, Tensor? hist, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, "
+          "Tensor pre_w, Tensor? pre_b, float pre_in_scale, int n_fft, int hop, float mean, float std, int normalize, "
+          "float out_scale) -> Tensor", _spec_block_conv_pre,
+          lambda wav, hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std, normalize,
           out_scale: wav.new_empty(wav.shape[0], pre_w.shape[0], wav.shape[2]))
 
 
@@ -638,17 +640,19 @@ def spec_block_tables(basis_t: Tensor, wt: Tensor, n_fft: int):
 
 
 def spec_block(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor], x: Tensor,
-               n_fft: int, hop: int, mean: float = 0.0, std: float = 1.0, normalize=True, out_scale: float = 1.0) -> Tensor:
-    """One-launch SpecBlock (hilc_spec_block): wav `[B,1,T]`, x `[B,n_fft,T/hop]` -> x + out_scale * (W spec + bias)."""
-    return _OPS.spec_block(wav, dft_packed, nyq_sin, pw_packed, bias, x, int(n_fft), int(hop), float(mean), float(std),
+               n_fft: int, hop: int, mean: float = 0.0, std: float = 1.0, normalize=True, out_scale: float = 1.0,
+               hist: Optional[Tensor] = None) -> Tensor:
+    """One-launch SpecBlock (hilc_spec_block): wav `[B,1,T]`, x `[B,n_fft,T/hop]` -> x + out_scale * (W spec + bias);
+    hist `[B,1,L]` (L >= n_fft-1) = the waveform before t = 0 (streaming hop)."""
+    return _OPS.spec_block(wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, int(n_fft), int(hop), float(mean), float(std),
                            int(normalize), float(out_scale))
 
 
 def spec_block_conv_pre(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor],
                         pre_w: Tensor, pre_b: Optional[Tensor], pre_in_scale: float, n_fft: int, hop: int, mean: float = 0.0,
-                        std: float = 1.0, normalize=True, out_scale: float = 1.0) -> Tensor:
+                        std: float = 1.0, normalize=True, out_scale: float = 1.0, hist: Optional[Tensor] = None) -> Tensor:
     """First encoder stage in one launch: conv_pre(wav) + SpecBlock branch (hilc_spec_block_conv_pre)."""
-    return _OPS.spec_block_conv_pre(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, float(pre_in_scale), int(n_fft),
+    return _OPS.spec_block_conv_pre(wav, hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, float(pre_in_scale), int(n_fft),
                                     int(hop), float(mean), float(std), int(normalize), float(out_scale))
 
 

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 4   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre */
+#define HILC_ABI_VERSION 5   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -179,7 +179,8 @@ int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const fl
                      int B, int T, int n_fft, int hop, float mean, float std, int normalize, void* stream);
 
 /* ---- one-launch SpecBlock (long encoder stages: n_fft 64 / 128 / 256 with the codec's hops 1 / 2 / 8, C == n_fft) ---
- * y[b,m,f] = x[b,m,f] + out_scale * (sum_k pw[k][m] * spec[b,k,f] + bias[m]),  spec as in hilc_stft_logmag (zero history)
+ * y[b,m,f] = x[b,m,f] + out_scale * (sum_k pw[k][m] * spec[b,k,f] + bias[m]),  spec as in hilc_stft_logmag: `hist`
+ * `[B][hist_len]` (hist_len >= n_fft-1) = the waveform before t = 0 for a streaming hop (`streaming.py:482-490`), NULL = zeros
  * i.e. SpecBlock.forward (`models/hilcodec/modules/seanet.py:220-246`: CausalSTFT `conv.py:329-358`, log / normalise,
  * 1x1 conv, `x.add_(y.mul_(scale))`) without the [n_fft/2+1 x T_f] tensor ever reaching HBM.  Bit-identical to
  * hilc_stft_logmag + hilc_pw_conv(res = x).  T_f = (T-1)/hop + 1 must be a multiple of 4; x, y 16-B aligned, y != x.
@@ -192,17 +193,17 @@ int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const fl
 int hilc_spec_block_supported(int n_fft, int hop, int C, int T);
 int hilc_spec_block_packed_floats(int n_fft, int which);
 int hilc_spec_block_pack(const float* w, float* packed, int K, int n_fft, int which, void* stream);
-int hilc_spec_block(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
-                    const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop, float mean,
-                    float std, int normalize, float out_scale, void* stream);
+int hilc_spec_block(const float* wav, const float* hist, int hist_len, const float* dft_packed, const float* nyq_sin,
+                    const float* pw_packed, const float* bias, const float* x, float* y, int B, int T, int n_fft, int hop,
+                    float mean, float std, int normalize, float out_scale, void* stream);
 /* First encoder stage: the same with x = the first conv of the same waveform, computed in the kernel instead of read:
  * x[b,m,t] = sum_j pre_w[m][j] * (pre_in_scale * wav[b, t-(ksize-1)+j]) + pre_b[m]   (hilc_conv_pre; `seanet.py:280-286`,
  * `:368-372`).  n_fft = 64, hop = 1, pre_ksize = 5 only (HILC_ERR_UNSUPPORTED otherwise); bit-identical to
  * hilc_conv_pre + hilc_spec_block. */
-int hilc_spec_block_conv_pre(const float* wav, const float* dft_packed, const float* nyq_sin, const float* pw_packed,
-                             const float* bias, const float* pre_w, const float* pre_b, float pre_in_scale, float* y,
-                             int B, int T, int n_fft, int hop, int pre_ksize, float mean, float std, int normalize,
-                             float out_scale, void* stream);
+int hilc_spec_block_conv_pre(const float* wav, const float* hist, int hist_len, const float* dft_packed,
+                             const float* nyq_sin, const float* pw_packed, const float* bias, const float* pre_w,
+                             const float* pre_b, float pre_in_scale, float* y, int B, int T, int n_fft, int hop, int pre_ksize,
+                             float mean, float std, int normalize, float out_scale, void* stream);
 
 /* ---- streaming cache update: out[row][i] = last `pad` samples of [hist[row][0..hist_len) | x[row][0..T)] ----
  * Replaces: `cache = x[:, :, -causal_padding:]` after `torch.cat((cache, x), dim=2)`

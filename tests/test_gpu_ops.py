@@ -455,6 +455,18 @@ def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
     y = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, True, 0.37)
     close(y, ref, 2e-4, "fused SpecBlock vs oracle")
     assert not ops.spec_block_supported(512, 40, 512, T) and not ops.spec_block_supported(n_fft, hop, C, 4 * hop + 1)
+    # streaming hop: the samples before t = 0 come from the waveform cache (1023 samples in the codec)
+    hist = synth.synth_clips(B, 1023, seed=n_fft + 5).to(dev)
+    y_h = ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, 0, 0.37, hist=hist)
+    s_h = ops.stft_logmag(wav.to(dev), bt, n_fft, hop, -4.0, 2.8, 0, hist=hist)
+    assert torch.equal(y_h, ops.pw_conv(s_h, wt, bias, res=x.to(dev), out_scale=0.37))
+    assert not torch.equal(y_h, ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, 0, 0.37))
+    if n_fft == 64:
+        # (in_scale 1: the streaming model merges 1/wav_std into the weights, `streaming.py:472-480`)
+        x0h = ops.conv_pre(wav.to(dev), (rnd(71, 64, 5) * 0.5).to(dev), None, in_scale=1.0, hist=hist)
+        y_1 = ops.spec_block_conv_pre(wav.to(dev), dft_p, nyq, pw_p, bias, (rnd(71, 64, 5) * 0.5).to(dev), None, 1.0, n_fft,
+                                      hop, -4.0, 2.8, 0, 0.37, hist=hist)
+        assert torch.equal(y_1, ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x0h, n_fft, hop, -4.0, 2.8, 0, 0.37, hist=hist))
     if n_fft == 64:
         # first encoder stage: conv_pre computed inside the SpecBlock launch == conv_pre launch + SpecBlock launch
         pw_, pb_ = (rnd(71, 64, 5) * 0.5).to(dev), (rnd(72, 64) * 0.1).to(dev)
