@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="with --graph: two-stage software pipeline over hops "
+                    "(decoder of hop i-1 beside the encoder of hop i on a second HIP stream; +1 hop output latency)")
     ap.add_argument("--graph", action="store_true", help="streaming mode: replay each hop as one HIP graph "
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--cpu-clips", type=int, default=16)
@@ -164,8 +166,8 @@ def main():
             return idx, wav
 
         if args.graph:
-            from hilcodec_amd.graph_step import GraphedHop
-            hopper = GraphedHop(model, hi - lo, hop, nq, dev)
+            from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
+            hopper = (PipelinedHop if args.pipeline else GraphedHop)(model, hi - lo, hop, nq, dev)
             args.no_launch_timing = True
 
             def step(i):                                   # noqa: F811
@@ -203,7 +205,9 @@ def main():
                         f"(BASELINE configs[{cfg_ix}])")
         else:
             workload = (f"{name} streaming, hop=320, {B} concurrent streams per GPU, Nq={nq}, 22+30 caches per stream "
-                        f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else ""))
+                        f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else "")
+                        + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop output latency)"
+                           if args.graph and args.pipeline else ""))
         out = {
             "metric": "audio-seconds/sec (xRT) encode+RVQ+decode, 24 kHz batch=256",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,

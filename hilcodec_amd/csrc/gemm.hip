@@ -6,6 +6,7 @@
 #include "gemm_core.h"
 #include "gemm_lin.h"
 #include "gemm_epilogues.h"
+#include "frame1.h"
 
 using namespace hilc;
 
@@ -252,6 +253,12 @@ extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, 
   if (!x || !wt || !y) return HILC_ERR_NULL;
   if (B <= 0 || K <= 0 || M <= 0 || T <= 0) return HILC_ERR_SHAPE;
   if (M % 4 != 0) return HILC_ERR_UNSUPPORTED;  // weight rows are read as float4
+  if (T == 1 && B <= 65535L * 32) {             // single-frame layers of a streaming hop: latency-bound, own kernel
+    Frame1Args f{};
+    f.x = x; f.wt = wt; f.bias = bias; f.res = res; f.y = y; f.B = B; f.K = K; f.M = M;
+    f.in_scale = in_scale; f.in_elu = in_elu; f.out_scale = out_scale;
+    return launch_frame1(f, (hipStream_t)stream);
+  }
   long ncols = (long)B * T;
   PwFlatLoader ld;
   ld.x = x; ld.K = K; ld.T = T; ld.ncols = ncols; ld.in_scale = in_scale; ld.in_elu = in_elu;
@@ -430,10 +437,34 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
                                     float out_scale, int out_elu, void* stream) {
   if (!x || !wt || !dw_w || !y) return HILC_ERR_NULL;
   if (B <= 0 || K <= 0 || M <= 0 || T <= 0 || ksize <= 0 || stride <= 0) return HILC_ERR_SHAPE;
-  if (M % 4 != 0 || T > BN || T % stride != 0 || ksize < stride || ksize > 32) return HILC_ERR_UNSUPPORTED;
+  if (M % 4 != 0 || T % stride != 0 || ksize < stride || ksize > 32) return HILC_ERR_UNSUPPORTED;
   if (hist != nullptr && hist == hist_out) return HILC_ERR_UNSUPPORTED;
   const int pad = ksize - stride;
   if (pad == 0 && (hist != nullptr || hist_out != nullptr)) return HILC_ERR_SHAPE;
+  if (T == 1 && stride == 1 && B <= 65535L * 32) {
+    Frame1Args f{};
+    f.x = x; f.wt = wt; f.res = res; f.y = y; f.dw_w = dw_w; f.dw_b = dw_b; f.hist = hist; f.hist_out = hist_out;
+    f.B = B; f.K = K; f.M = M; f.ksize = ksize; f.in_scale = in_scale; f.in_elu = in_elu; f.out_scale = out_scale;
+    f.out_elu = out_elu;
+    return launch_frame1(f, (hipStream_t)stream);
+  }
+  if (T > BN) {
+    // a hop longer than one tile (the encoder's first two down-sampling layers: 320 / 160 samples per stream): per-clip
+    // tiles with a recomputed halo, exactly the offline kernel, plus the cache in front of the first tile and the new
+    // cache out of the last one
+    if (ksize != 2 * stride || stride > 16 || res != nullptr || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
+    if (T % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || !lin_ok(B, K, T)) return HILC_ERR_UNSUPPORTED;
+    DwStrideEpilogue ep;
+    ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.M = M; ep.r = stride; ep.hist = hist; ep.hist_out = hist_out; ep.T = T;
+    ep.To = T / stride;
+    ep.H = (stride + 3) / 4 * 4;
+    ep.n_out = (BN - ep.H - stride) / stride + 1;
+    while ((ep.n_out * stride) % 4 != 0) --ep.n_out;
+    ep.tiles = (ep.To + ep.n_out - 1) / ep.n_out;
+    TileCols tc;
+    tc.K = K; tc.T = T; tc.tiles = ep.tiles; tc.step = ep.n_out * stride; tc.halo = ep.H;
+    return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, tc, ep, (hipStream_t)stream);
+  }
   const int cpt = BN / T;
   PwFlatLoader ld;
   ld.x = x; ld.K = K; ld.T = T; ld.ncols = (long)B * T; ld.in_scale = in_scale; ld.in_elu = in_elu;

@@ -286,6 +286,11 @@ struct DwStrideEpilogue {
   float* y;
   const float* dw_w;   // [M][2r]
   const float* dw_b;
+  // streaming hop longer than one tile: cache [B][M][r] = the last r pointwise outputs of the previous hop (they
+  // replace the zero padding in front of a clip's first tile), and its successor, written from the clip's last tile
+  const float* hist = nullptr;
+  float* hist_out = nullptr;
+  int T = 0;           // input samples per clip (needed for hist_out only)
   int M, To, tiles, r, H, n_out;
   template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS; }
 
@@ -309,7 +314,11 @@ struct DwStrideEpilogue {
         const float* w = dw_w + (long)m * k;
         const float* h = smem + row * HS + (H - r) + (live ? lane : 0) * r;
         float a = 0.f;
-        if (KR > 0) {
+        if (hist != nullptr && o0 == 0) {        // uniform: a clip's first tile in a streaming hop — output 0's first
+          const bool from_cache = lane == 0;     // r taps lie before t = 0 and come from the cache, not the zero halo
+          const float* hc = hist + (b * M + m) * (long)r;
+          for (int j = 0; j < k; ++j) a = fmaf(w[j], (from_cache && j < r) ? hc[j] : h[j], a);
+        } else if (KR > 0) {
 #pragma unroll
           for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(w[j], h[j], a);
         } else {
@@ -317,6 +326,10 @@ struct DwStrideEpilogue {
         }
         if (dw_b) a = __fadd_rn(a, dw_b[m]);
         if (live) y[(b * M + m) * (long)To + o] = a;
+        if (hist_out != nullptr && o0 + n_out >= To && lane < r) {      // the clip's last tile: columns of t = T-r .. T-1
+          const int c = (T - r + lane) - (o0 * r - H);
+          hist_out[(b * M + m) * (long)r + lane] = smem[row * HS + c];
+        }
       }
     }
   }

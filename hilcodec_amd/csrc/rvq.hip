@@ -81,21 +81,31 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
 #pragma unroll
       for (int f = 0; f < FR; ++f) acc[j][f] = 0.f;
 
-#pragma unroll 2
-    for (int c = 0; c < C; ++c) {
-      float e[CPT];
+    // Code words come from L2 (the transposed codebook, 512 KB per stage, is shared by every workgroup): UC channels'
+    // worth of loads are issued before the first FMA of the group needs one.  With FR = 4 a CU holds one wave per
+    // SIMD and nothing else hides the L2 round trip, so the group is deep (64 loads in flight per thread); with
+    // FR = 16 the 64 accumulators leave room for 2 channels.
+    constexpr int UC = FR <= 4 ? 16 : 2;
+    static_assert(C % UC == 0, "channel groups");
+    for (int c0 = 0; c0 < C; c0 += UC) {
+      float e[UC][CPT];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) e[j] = cbt[(long)c * a.K + tid + 256 * j];
-      float r[FR];
+      for (int u = 0; u < UC; ++u)
 #pragma unroll
-      for (int f4 = 0; f4 < FR; f4 += 4) {
-        float4 v = *reinterpret_cast<const float4*>(&res[c][f4]);
-        r[f4] = v.x; r[f4 + 1] = v.y; r[f4 + 2] = v.z; r[f4 + 3] = v.w;
+        for (int j = 0; j < CPT; ++j) e[u][j] = cbt[(long)(c0 + u) * a.K + tid + 256 * j];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        float r[FR];
+#pragma unroll
+        for (int f4 = 0; f4 < FR; f4 += 4) {
+          float4 v = *reinterpret_cast<const float4*>(&res[c0 + u][f4]);
+          r[f4] = v.x; r[f4 + 1] = v.y; r[f4 + 2] = v.z; r[f4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+#pragma unroll
+          for (int f = 0; f < FR; ++f) acc[j][f] = fmaf(r[f], e[u][j], acc[j][f]);
       }
-#pragma unroll
-      for (int j = 0; j < CPT; ++j)
-#pragma unroll
-        for (int f = 0; f < FR; ++f) acc[j][f] = fmaf(r[f], e[j], acc[j][f]);
     }
 
     float nk[CPT];

@@ -213,7 +213,7 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
 
 def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
     if (FUSE_SPECBLOCK and sb.fused is not None and (wav_hist is None or wav_hist.shape[-1] >= sb.n_fft - 1)
-            and ops.spec_block_supported(sb.n_fft, sb.hop, x.shape[1], wav.shape[2])):
+            and ops.spec_block_profitable(sb.n_fft, sb.hop, x.shape[1], wav.shape[2])):
         return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, x, sb.n_fft, sb.hop, sb.mean, sb.std,
                               sb.normalize, sb.out_scale, hist=wav_hist)
     s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)

@@ -504,13 +504,18 @@ def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None,
 
 
 def dws_conv_stream_supported(T: int, k: int, stride: int) -> bool:
-    """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride"""
-    return T <= 128 and T % stride == 0 and stride <= k <= 32
+    """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride; longer hops for the
+    down-sampling form (k = 2 * stride): per-clip tiles with a recomputed halo"""
+    if T > 128:
+        return k == 2 * stride and stride <= 16 and T % 4 == 0 and T % stride == 0
+    return T % stride == 0 and stride <= k <= 32
 
 
 def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
     """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
-    --mode streaming): not for single-sample hops, whose depthwise taps are nearly all cache reads."""
+    --mode streaming): not for 2- or 3-sample hops of the tiled core, whose depthwise taps are nearly all cache reads."""
+    if T == 1 and stride == 1:
+        return True     # single-frame layers: the latency-bound 32 x 32-tile kernel (csrc/frame1.hip), taps in its epilogue
     return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
 
 
@@ -522,7 +527,7 @@ def _state_out(given: Optional[Tensor], like: Tensor, *shape) -> Tensor:
 def dws_conv_stream(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
                     res: Optional[Tensor] = None, stride: int = 1, in_scale: float = 1.0, in_elu: bool = False,
                     out_scale: float = 1.0, out_elu: bool = False, hist_out: Optional[Tensor] = None):
-    """Streaming hop of a depthwise-separable block (hilc_dws_conv_stream): x `[B,K,T]`, T <= 128, cache
+    """Streaming hop of a depthwise-separable block (hilc_dws_conv_stream): x `[B,K,T]` (T <= 128, or any T % 4 == 0 for k = 2 * stride), cache
     `[B,M,k-stride]` (last pointwise outputs of the previous hop) -> (y `[B,M,T/stride]`, new cache)."""
     hout = _state_out(hist_out, x, x.shape[0], wt.shape[1], dw_w.shape[1] - stride)
     y = _OPS.dws_conv_stream(x, wt, dw_w, dw_b, hist, hout, res, int(stride), float(in_scale), bool(in_elu),
@@ -627,6 +632,15 @@ def spec_block_supported(n_fft: int, hop: int, C: int, T: int) -> bool:
     if n_fft not in (64, 128, 256) or hop != {64: 1, 128: 2, 256: 8}[n_fft] or C != n_fft or T <= 0:
         return False
     return ((T - 1) // hop + 1) % 4 == 0
+
+
+def spec_block_profitable(n_fft: int, hop: int, C: int, T: int) -> bool:
+    """supported, and the clip fills its 128-frame tiles to >= 60 % (a 320-sample streaming hop has 40 frames at
+    n_fft = 256: a third of a tile — the two-launch path with flat columns is faster there, measured)"""
+    if not spec_block_supported(n_fft, hop, C, T):
+        return False
+    tf = (T - 1) // hop + 1
+    return tf * 10 >= ((tf + 127) // 128) * 128 * 6
 
 
 def spec_block_tables(basis_t: Tensor, wt: Tensor, n_fft: int):

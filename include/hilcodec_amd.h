@@ -90,7 +90,8 @@ int hilc_up_conv_expanded(const float* x, const float* hist, float* hist_out, co
                           int M, int Tin, int stride, float in_scale, int in_elu, void* stream);
 
 /* Streaming hop of hilc_dws_conv for the wide layers (DWSBlock.forward `streaming.py:160-192`, CausalConv1d
- * `causal_layers.py:147-165`): T <= 128 samples per stream and call, T % stride == 0, any ksize >= stride.
+ * `causal_layers.py:147-165`): T <= 128 samples per stream and call, T % stride == 0, any ksize >= stride; longer
+ * hops (T % 4 == 0; per-clip tiles with a recomputed halo) for ksize == 2 * stride.
  * hist `[B][M][ksize-stride]` = the last pointwise outputs of the previous hop (NULL = zeros), hist_out receives
  * the new cache (must not alias hist).  A tile holds whole clips, so nothing is recomputed. */
 int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, const float* dw_b, const float* hist,

@@ -125,7 +125,10 @@ def test_golden_resblock_modules(env, golden):
                                       (2, 128, 1536, 75), (2, 257, 512, 40), (1, 768, 384, 360), (5, 192, 192, 128),
                                       # linear-addressing core (T % 4 == 0): ragged K tails with every row-tile height
                                       (2, 33, 64, 1000), (1, 65, 96, 400), (4, 129, 160, 128), (2, 40, 192, 64),
-                                      (1, 16, 32, 4), (3, 17, 128, 2048), (1, 513, 1024, 76)])
+                                      (1, 16, 32, 4), (3, 17, 128, 2048), (1, 513, 1024, 76),
+                                      # single-frame layers of a streaming hop (csrc/frame1.hip): ragged K / M / B
+                                      (70, 513, 1024, 1), (1024, 1024, 128, 1), (33, 128, 1536, 1), (5, 7, 20, 1),
+                                      (97, 130, 36, 1), (1, 2, 4, 1)])
 def test_pw_conv_vs_oracle(env, B, K, M, Tn):
     ops, fold, O, dev = env
     x = rnd(B * 7 + K, B, K, Tn)
@@ -360,9 +363,12 @@ def test_up_conv_vs_oracle(env, K, M, Tin, r):
 
 @pytest.mark.parametrize("K,M,Tn,k,s,B", [(256, 256, 40, 5, 1, 7), (512, 512, 8, 5, 1, 33), (128, 1536, 1, 5, 1, 130),
                                            (256, 512, 40, 10, 5, 5), (512, 1024, 8, 16, 8, 20), (96, 64, 128, 4, 2, 3),
-                                           (64, 128, 12, 5, 1, 11)])
+                                           (64, 128, 12, 5, 1, 11),
+                                           # hops longer than one tile (the encoder's first two down-sampling layers)
+                                           (64, 128, 320, 4, 2, 5), (128, 256, 160, 8, 4, 6), (96, 192, 132, 4, 2, 3),
+                                           (64, 96, 640, 10, 5, 2)])
 def test_dws_conv_stream_vs_unfused_and_offline(env, K, M, Tn, k, s, B):
-    """hilc_dws_conv_stream (whole-clip tiles, cache-aware epilogue) over 3 hops: against the pointwise GEMM +
+    """hilc_dws_conv_stream (whole-clip tiles, or per-clip halo tiles for T > 128; cache-aware epilogues) over 3 hops: against the pointwise GEMM +
     cached depthwise conv (the already oracle-pinned streaming ops), and — concatenated — against the oracle's
     offline causal conv of the whole signal (causal_layers.py:147-165 cache semantics)."""
     ops, fold, O, dev = env
@@ -392,6 +398,7 @@ def test_dws_conv_stream_vs_unfused_and_offline(env, K, M, Tn, k, s, B):
         full = F.elu(full * 0.5 + res)
     close(torch.cat(outs, dim=2), full, 3e-5, "streamed vs offline oracle")
     assert not ops.dws_conv_stream_supported(160, 5, 1) and not ops.dws_conv_stream_supported(40, 16, 16)
+    assert ops.dws_conv_stream_supported(320, 4, 2) and not ops.dws_conv_stream_supported(322, 4, 2)
 
 
 @pytest.mark.parametrize("K,M,Tin,r,B", [(1536, 768, 1, 8, 9), (768, 384, 8, 5, 4), (384, 192, 40, 4, 3), (192, 96, 160, 2, 2)])

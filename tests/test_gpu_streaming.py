@@ -213,6 +213,43 @@ def test_graphed_hop_equals_eager():
         assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1])
 
 
+def test_pipelined_hop_equals_eager():
+    """PipelinedHop (decoder of hop i-1 beside the encoder of hop i, two HIP streams inside one graph): indices of
+    every hop and — one replay later — its wav bit-identical to the eager loop; flush() delivers the last hop; a
+    second pass after reset() and a continuation after flush() give the same again."""
+    from hilcodec_amd.graph_step import PipelinedHop
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming()
+    B, hops = 5, 5
+    x = synth.synth_clips(B, 320 * hops, seed=78).to(dev)
+    ce, cd = model.initialize_cache(x)
+    eager = []
+    with torch.no_grad():
+        for h in range(hops):
+            z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)].contiguous(), *ce)
+            idx = model.quantizer(z, 8)
+            wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+            eager.append((idx.clone(), wav.clone()))
+    g = PipelinedHop(model, B, 320, 8, dev)
+    for rep in range(2):
+        for h in range(hops):
+            idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])
+            assert torch.equal(idx, eager[h][0]), f"pass {rep} hop {h} indices"
+            if h == 0:
+                assert wav is None
+            else:
+                assert torch.equal(wav, eager[h - 1][1]), f"pass {rep} wav of hop {h - 1}"
+            if h == 2 and rep == 1:            # drain in mid-stream, then carry on: the caches stay consistent
+                assert torch.equal(g.flush(), eager[2][1])
+                idx, wav = g.step(x[:, :, 320 * 3: 320 * 4])
+                assert wav is None and torch.equal(idx, eager[3][0])
+                idx, wav = g.step(x[:, :, 320 * 4: 320 * 5])
+                assert torch.equal(idx, eager[4][0]) and torch.equal(wav, eager[3][1])
+                break
+        assert torch.equal(g.flush(), eager[hops - 1][1]) and g.flush() is None
+        g.reset()
+
+
 @pytest.mark.parametrize("name,n,hop_frames", [("hil_music", 12, 1), ("hil_speech", 8, 3), ("hil_music", 5, 2)])
 def test_streaming_vs_oracle_other_configs(name, n, hop_frames):
     """hil_music (Nq = 12) and multi-frame hops (test_onnx.py `num_frames` > 1: 640 / 960 samples per call) against
