@@ -27,6 +27,7 @@ FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside
 FUSE_RESBLOCK = True
 FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
+SIDE_STREAM = None        # set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
 
 
@@ -211,13 +212,46 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
     return y
 
 
-def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
-    if (FUSE_SPECBLOCK and sb.fused is not None and (wav_hist is None or wav_hist.shape[-1] >= sb.n_fft - 1)
-            and ops.spec_block_profitable(sb.n_fft, sb.hop, x.shape[1], wav.shape[2])):
+def _spec_fused(sb: SpecBlockSpec, wav: Tensor, wav_hist: Optional[Tensor]) -> bool:
+    return bool(FUSE_SPECBLOCK and sb.fused is not None and (wav_hist is None or wav_hist.shape[-1] >= sb.n_fft - 1)
+                and ops.spec_block_profitable(sb.n_fft, sb.hop, sb.wt.shape[1], wav.shape[2]))
+
+
+def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor], early: Optional[dict] = None) -> Tensor:
+    if _spec_fused(sb, wav, wav_hist):
         return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, x, sb.n_fft, sb.hop, sb.mean, sb.std,
                               sb.normalize, sb.out_scale, hist=wav_hist)
-    s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+    if early is not None and id(sb) in early:
+        s, done = early[id(sb)]
+        torch.cuda.current_stream(x.device).wait_event(done)
+    else:
+        s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
     return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
+
+
+def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor]) -> Optional[dict]:
+    """Streaming hop inside a captured graph: the log-magnitude spectra of the un-fused SpecBlocks depend on the
+    waveform only, so they are computed on SIDE_STREAM beside the first encoder stages (their small launches fill
+    idle CUs instead of standing in the chain); `_spec_block` waits for each one's event.  Same launches, same
+    results."""
+    side = SIDE_STREAM
+    if side is None or torch.compiler.is_compiling() or not wav.is_cuda:
+        return None
+    main = torch.cuda.current_stream(wav.device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    early = {}
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for sb in [st.spec for st in es.stages] + [es.spec_post]:
+            if _spec_fused(sb, wav, wav_hist):
+                continue
+            s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+            if not capturing:
+                s.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(side)
+            early[id(sb)] = (s, done)
+    return early
 
 
 def _contig(caches: Optional[Sequence[Tensor]]):
@@ -256,9 +290,10 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
+    early = _early_spectra(es, wav, wav_hist) if streaming else None
     for si, st in enumerate(es.stages):
         if not (fuse_pre and si == 0):
-            x = _spec_block(st.spec, x, wav, wav_hist)
+            x = _spec_block(st.spec, x, wav, wav_hist, early)
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
                           caches_out[ci:ci + 2] if caches_out is not None else None)
@@ -279,7 +314,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
             x = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio)
         ci += 1
-    x = _spec_block(es.spec_post, x, wav, wav_hist)
+    x = _spec_block(es.spec_post, x, wav, wav_hist, early)
     if streaming:
         h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)

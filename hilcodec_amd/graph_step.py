@@ -11,13 +11,29 @@ streaming Encoder / Decoder), so a hop moves no cache bytes beyond what its kern
 copy-back.  Two graphs are captured (A->B and B->A) and replayed alternately.
 
 The captured kernels are the same launches the eager path issues (same custom ops on the capture stream), so a
-replayed hop is bit-identical to an eager hop (tests/test_gpu_streaming.py)."""
+replayed hop is bit-identical to an eager hop (tests/test_gpu_streaming.py).  The graph is not a pure chain: the
+log-magnitude spectra of the un-fused SpecBlocks (n_fft 256 / 512 / 1024 at one hop: small launches that depend on the
+waveform only) sit on a second branch beside the first encoder stages (`engine._early_spectra`)."""
 from __future__ import annotations
 
+import contextlib
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
+
+from . import engine
+
+
+@contextlib.contextmanager
+def _spectra_on(stream: Optional[torch.cuda.Stream]):
+    """while a hop is warmed up / captured: the STFT front halves of the un-fused SpecBlocks go to `stream`
+    (engine._early_spectra), a branch of the graph beside the first encoder stages"""
+    prev, engine.SIDE_STREAM = engine.SIDE_STREAM, stream
+    try:
+        yield
+    finally:
+        engine.SIDE_STREAM = prev
 
 
 class StateBlock:
@@ -68,6 +84,7 @@ class GraphedHop:
         self.x = torch.zeros(batch, 1, hop, device=device)
         self.state = (StateBlock(model, batch, device), StateBlock(model, batch, device))
         self.parity = 0                       # the block holding the CURRENT caches (input of the next hop)
+        self.spec_side = torch.cuda.Stream(device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
@@ -91,7 +108,8 @@ class GraphedHop:
     def _hop(self, p: int) -> Tuple[Tensor, Tensor]:
         m = self.model
         src, dst = self.state[p], self.state[p ^ 1]
-        z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
+        with _spectra_on(self.spec_side):
+            z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
         idx = m.quantizer(z, self.n)
         q = m.dequantizer(idx, self.n)
         wav, _ = m.decoder(q, *src.dec, cache_out=dst.dec)
@@ -140,6 +158,7 @@ class PipelinedHop:
         self.parity = 0                       # encoder parity: the block holding the encoder caches of the next hop
         self.pending = False                  # a hop is encoded but not decoded yet
         self.side = torch.cuda.Stream(device)
+        self.spec_side = torch.cuda.Stream(device)
         warm = torch.cuda.Stream(device)
         warm.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(warm), torch.no_grad():
@@ -164,7 +183,8 @@ class PipelinedHop:
 
     def _encode(self, p: int) -> Tensor:
         m = self.model
-        z, _ = m.encoder(self.x, *self.state[p].enc, cache_out=self.state[p ^ 1].enc)
+        with _spectra_on(self.spec_side):
+            z, _ = m.encoder(self.x, *self.state[p].enc, cache_out=self.state[p ^ 1].enc)
         return m.quantizer(z, self.n)
 
     def _decode(self, p: int) -> Tensor:
