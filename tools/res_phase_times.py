@@ -8,7 +8,7 @@ DBG = os.path.join(ROOT, "gpurun_out", "libhilcodec_amd_stamps.so")
 if not os.path.isfile(DBG):
     os.makedirs(os.path.dirname(DBG), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                    "-DHILC_DEBUG_STAMPS", "-o", DBG] + sorted(glob.glob(os.path.join(ROOT, "hilcodec_amd", "csrc", "*.hip"))),
+                    "-ffp-contract=off", "-DHILC_DEBUG_STAMPS", "-o", DBG] + sorted(glob.glob(os.path.join(ROOT, "hilcodec_amd", "csrc", "*.hip"))),
                    check=True)
 os.environ["HILC_LIB"] = DBG
 import torch
@@ -21,7 +21,7 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
     w1 = torch.randn(C, C, device=dev) / C ** 0.5; w2 = torch.randn(C, C, device=dev) / C ** 0.5
     d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
     d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
-    TO = 120 if C == 192 else 248
+    TO = 120
     nblk = B * ((T + TO - 1) // TO)
     w1, w2 = ops.resblock_pack(w1), ops.resblock_pack(w2)
     ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); torch.cuda.synchronize()
@@ -32,6 +32,15 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
     d = (buf[:, 1:] - buf[:, :-1]).double()
     med = d.median(dim=0).values.tolist()
     tot = (buf[:, 7] - buf[:, 0]).double().median().item()
+    live = buf[:, 0] > 0
+    tt = (buf[live, 7] - buf[live, 0]).double()
+    qs = torch.quantile(tt[:200000], torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95, 0.99], dtype=torch.float64, device=dev)).tolist()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"C={C}: {int(live.sum())} tiles stamped, mean {tt.mean().item():.0f}, quantiles 5/25/50/75/95/99 % = "
+          + "/".join(f"{q:.0f}" for q in qs) + f"; kernel {ms:.3f} ms -> sum(ticks)/ms = {tt.sum().item() / ms / 1e6:.2f} G tile-ticks per second"
+          f" = {tt.sum().item() / ms / 1e6 / 2.4 / 256:.2f} tiles in flight per CU if a tick is a 2.4 GHz cycle")
     names = ["P0 ELU(regs)", "G1", "P2 acc->lds", "P3 dw+ELU", "G2", "P5 acc->lds", "P6 dw+store+prefetch"]
     mf = (C // 2) * (C // 32) * 64
     print(f"C={C}: total {tot:.0f} ticks; ideal MFMA per GEMM {mf} cyc; " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
