@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2.5 s sustained clock / power sample")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="with --graph: two-stage software pipeline over hops "
                     "(decoder of hop i-1 beside the encoder of hop i on a second HIP stream; +1 hop output latency)")
@@ -67,6 +68,54 @@ def parse():
         a.warmup = 5 if a.warmup is None else a.warmup
         a.batch = 1024 if a.batch is None else a.batch
     return a
+
+
+def sustained_clock(step, first_index: int, seconds: float = 2.5):
+    """Shader clock and socket power while the benchmark's own steps run back to back: `rocm-smi` sampled from a
+    thread (≈3 samples per second).  Returns medians, or None where rocm-smi is missing / prints something else."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import torch
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    sclk, power, stop = [], [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                txt = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True,
+                                     timeout=10).stdout
+            except Exception:
+                return
+            m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if m:
+                sclk.append(float(m.group(1)))
+            if w:
+                power.append(float(w.group(1)))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    with torch.no_grad():
+        step(first_index)
+        torch.cuda.synchronize()
+        th.start()
+        t0 = time.perf_counter()
+        i = first_index + 1
+        while time.perf_counter() - t0 < seconds:
+            step(i)
+            i += 1
+            torch.cuda.synchronize()
+    stop[0] = True
+    th.join(timeout=15)
+    sclk, power = sclk[1:] or sclk, power[1:] or power      # the first sample straddles the ramp
+    if not sclk:
+        return None
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"sclk_mhz": med(sclk), "power_w": med(power) if power else None, "samples": len(sclk),
+            "how": "rocm-smi medians over %.1f s of the same steps after the timed region" % seconds}
 
 
 def cpu_baseline(name, mk, sd, clips: int, samples: int):
@@ -255,6 +304,14 @@ def main():
                 roof["algorithmic_bytes_per_step"] = 196800 * B + 38150404 + nq * 524288 + 5602816
         except (OSError, KeyError, ValueError):
             pass
+        if world == 1 and not args.no_clock_probe:
+            # the fp32-MFMA peak assumes 2.4 GHz; this workload runs at the socket power limit and the clock follows
+            # (profiles/r02_experiments.md).  Sampled AFTER the timed region, while the same steps keep running.
+            sus = sustained_clock(step, args.warmup + args.steps)
+            if sus is not None:
+                sus["peak_at_sclk_tflops"] = FP32_MFMA_PEAK_TFLOPS * sus["sclk_mhz"] / 2400.0
+                sus["whole_path_frac_at_sclk"] = whole_tflops / sus["peak_at_sclk_tflops"]
+                roof["sustained"] = sus
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)
