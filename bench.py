@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
     ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
+    ap.add_argument("--decoder-gemm", default="fp32", choices=["fp32", "bf16x3"],
+                    help="EXPERIMENTAL, offline only: run the decoder's wide GEMMs in the bf16 split-operand mode "
+                         "(csrc/gemm_x3.h).  A separately labelled line; the headline is the fp32 default.")
+    ap.add_argument("--x3-blocks-from", type=int, default=0, help="with --decoder-gemm bf16x3: residual blocks of at least "
+                    "this width leave the fused fp32 kernel for two bf16x3 launches (0 = keep the fused kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2.5 s sustained clock / power sample")
     ap.add_argument("--no-launch-timing", action="store_true")
@@ -222,6 +227,24 @@ def main():
             def step(i):                                   # noqa: F811
                 return hopper.step(xs[i % nbuf])
 
+    numerics = None
+    if args.decoder_gemm != "fp32":
+        if args.mode != "offline":
+            raise SystemExit("--decoder-gemm applies to --mode offline")
+        from hilcodec_amd import engine
+        with torch.no_grad():
+            idx_f, wav_f = step(0)                          # the fp32 product path on the same inputs, outside the timed region
+            engine.DECODER_GEMM = args.decoder_gemm
+            if args.x3_blocks_from > 0:
+                engine.X3_FUSED_BLOCK_MIN_C = args.x3_blocks_from
+            idx_x, wav_x = step(0)
+        numerics = {"mode": args.decoder_gemm, "scope": "offline decoder: up-sampling and depthwise-separable GEMMs"
+                    + (f", residual blocks of width >= {args.x3_blocks_from}" if args.x3_blocks_from > 0 else "")
+                    + "; encoder and RVQ exact fp32",
+                    "indices_equal_to_fp32_path": bool(torch.equal(idx_f, idx_x)),
+                    "dwav_max_vs_fp32_path": float((wav_f - wav_x).abs().max()),
+                    "operand_bits": 16}
+        del idx_f, wav_f, idx_x, wav_x
     with torch.no_grad():
         for i in range(args.warmup):
             idx, wav = step(i)
@@ -271,6 +294,10 @@ def main():
                       "wall_s_per_rank": [r["wall_s"] for r in per_rank],
                       "wall_skew_s": max(r["wall_s"] for r in per_rank) - min(r["wall_s"] for r in per_rank)},
         }
+        if numerics is not None:
+            out["metric"] += " — EXPERIMENTAL decoder GEMMs in bf16x3, NOT the fp32 headline"
+            out["dtype"] = "f32 (encoder, RVQ, narrow decoder blocks) + bf16x3 split-operand GEMMs (wide decoder layers)"
+            out["numerics"] = numerics
         whole_tflops = value * FLOP_PER_AUDIO_SECOND[name] / 1e12 / world
         roof = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None, "whole_path_tflops_per_gpu": whole_tflops,

@@ -27,6 +27,22 @@ FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside
 FUSE_RESBLOCK = True
 FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
+# EXPERIMENTAL, opt-in: "bf16x3" runs the GEMMs of the OFFLINE DECODER's wide depthwise-separable and up-sampling layers
+# on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32 accumulation).  The
+# encoder and the RVQ — hence every index — are never touched.  Default "fp32" = the reference's arithmetic.
+DECODER_GEMM = "fp32"
+X3_FUSED_BLOCK_MIN_C = 10 ** 9   # residual blocks of at least this width leave the fused fp32 kernel for two bf16x3 launches
+_X3_SPLIT = {}            # id(weight tensor) -> (weight tensor, its split form); built on first use
+
+
+def _x3(wt: Tensor) -> Tensor:
+    hit = _X3_SPLIT.get(id(wt))
+    if hit is None or hit[0] is not wt:
+        hit = (wt, ops.x3_split(wt))
+        _X3_SPLIT[id(wt)] = hit
+    return hit[1]
+
+
 SIDE_STREAM = None        # set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
 
@@ -171,10 +187,16 @@ def _fusable(rb: ResBlockSpec, x: Tensor) -> bool:
 
 
 def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list],
-              outs: Optional[Sequence[Tensor]] = None) -> Tensor:
+              outs: Optional[Sequence[Tensor]] = None, x3: bool = False) -> Tensor:
     """One residual block; streaming: `caches` = its two depthwise caches, `outs` = where the next hop's caches go
-    (persistent state block) or None (fresh tensors, the reference's protocol)."""
+    (persistent state block) or None (fresh tensors, the reference's protocol).  `x3`: offline decoder block in the
+    experimental bf16x3 mode."""
     o0, o1 = (outs[0], outs[1]) if outs is not None else (None, None)
+    if (x3 and caches is None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
+            and ops.x3_supported(x.shape[1], x.shape[1], x.shape[2])
+            and (not _fusable(rb, x) or x.shape[1] >= X3_FUSED_BLOCK_MIN_C)):
+        g = ops.dws_conv_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
+        return ops.dws_conv_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
     if caches is None and _fusable(rb, x):
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
@@ -340,6 +362,9 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         return caches_out[i] if caches_out is not None else None
 
     q = q.contiguous().float()
+    if DECODER_GEMM not in ("fp32", "bf16x3"):
+        raise RuntimeError(f"engine.DECODER_GEMM must be 'fp32' or 'bf16x3', got {DECODER_GEMM!r}")
+    x3 = DECODER_GEMM == "bf16x3" and not streaming and not torch.compiler.is_compiling()
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
@@ -365,6 +390,8 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
                                  in_scale=st.in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio):
+            x = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps)
         elif fused_up:
             # the up-sampled tensor only exists inside the GEMM's loader
             x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True, taps=st.taps)
@@ -374,7 +401,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         ci += 1
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
-                          caches_out[ci:ci + 2] if caches_out is not None else None)
+                          caches_out[ci:ci + 2] if caches_out is not None else None, x3=x3)
             ci += 2
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,

@@ -185,6 +185,73 @@ _register("up_conv", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor tr_w
           x.new_empty(x.shape[0], wt.shape[1], x.shape[2] * stride))
 
 
+# ---- EXPERIMENTAL bf16x3 numerics mode (csrc/gemm_x3.h): opt-in, decoder side only -------------------------------------
+def _x3_split(wt):
+    K, M = wt.shape
+    out = torch.empty(2, K, M, device=wt.device, dtype=torch.int16)
+    check(lib.hilc_x3_split_weights(_ptr(wt), _ptr(out, torch.int16), K, M, _stream()), "hilc_x3_split_weights")
+    return out
+
+
+_register("x3_split", "(Tensor wt) -> Tensor", _x3_split,
+          lambda wt: torch.empty(2, wt.shape[0], wt.shape[1], device=wt.device, dtype=torch.int16))
+
+
+def _dws_conv_x3(x, wsplit, dw_w, dw_b, res, in_scale, in_elu, out_scale, out_elu):
+    B, K, T = x.shape
+    M = wsplit.shape[2]
+    y = _new(x, B, M, T)
+    with _timed("dws_conv_x3", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k5 s1 bf16x3"):
+        check(lib.hilc_dws_conv_x3(_ptr(x), _ptr(wsplit, torch.int16), _ptr(dw_w), _ptr(dw_b), _ptr(res), _ptr(y), B, K, M,
+                                   T, in_scale, int(in_elu), out_scale, int(out_elu), _stream()), "hilc_dws_conv_x3")
+    return y
+
+
+_register("dws_conv_x3", "(Tensor x, Tensor wsplit, Tensor dw_w, Tensor? dw_b, Tensor? res, float in_scale, bool in_elu, "
+          "float out_scale, bool out_elu) -> Tensor", _dws_conv_x3,
+          lambda x, wsplit, dw_w, dw_b, res, in_scale, in_elu, out_scale, out_elu:
+          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2]))
+
+
+def _up_conv_x3(x, tr_w, taps, wsplit, bias, stride, in_scale):
+    B, K, Tin = x.shape
+    M = wsplit.shape[2]
+    y = _new(x, B, M, Tin * stride)
+    with _timed("up_conv_x3", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride} bf16x3"):
+        check(lib.hilc_up_conv_x3(_ptr(x), _ptr(tr_w), _ptr(taps), _ptr(wsplit, torch.int16), _ptr(bias), _ptr(y), B, K, M,
+                                  Tin, stride, in_scale, _stream()), "hilc_up_conv_x3")
+    return y
+
+
+_register("up_conv_x3", "(Tensor x, Tensor tr_w, Tensor? taps, Tensor wsplit, Tensor? bias, int stride, float in_scale) -> Tensor",
+          _up_conv_x3, lambda x, tr_w, taps, wsplit, bias, stride, in_scale:
+          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2] * stride))
+
+
+def x3_supported(K: int, M: int, T: int) -> bool:
+    """mirror of hilc_x3_supported"""
+    return K % 32 == 0 and M % 8 == 0 and T % 4 == 0
+
+
+def x3_split(wt: Tensor) -> Tensor:
+    """k-major fp32 `[K,M]` -> `[2,K,M]` bf16 bit patterns (int16): head and head of the remainder (hilc_x3_split_weights)"""
+    return _OPS.x3_split(wt)
+
+
+def dws_conv_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], res: Optional[Tensor] = None,
+                in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False) -> Tensor:
+    """`dws_conv` (k5, stride 1) with the pointwise GEMM in the EXPERIMENTAL bf16x3 mode (hilc_dws_conv_x3)"""
+    return _OPS.dws_conv_x3(x, wsplit, dw_w, dw_b, res, float(in_scale), bool(in_elu), float(out_scale), bool(out_elu))
+
+
+def up_conv_x3(x: Tensor, tr_w: Tensor, wsplit: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
+               taps: Optional[Tensor] = None) -> Tensor:
+    """`up_conv` (ELU prologue, no cache) with the pointwise GEMM in the EXPERIMENTAL bf16x3 mode (hilc_up_conv_x3)"""
+    if taps is None and stride not in (2, 4, 8):
+        taps = up_conv_taps(tr_w, stride)
+    return _OPS.up_conv_x3(x, tr_w, taps, wsplit, bias, int(stride), float(in_scale))
+
+
 def _resblock_pack(wt):
     Cc = wt.shape[0]
     out = _new(wt, Cc * Cc)

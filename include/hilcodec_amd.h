@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 5   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both */
+#define HILC_ABI_VERSION 6   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental) */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -109,6 +109,21 @@ int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const fl
                   const float* dw2_w, const float* dw2_b, float* y, int B, int C, int T, float pre_scale,
                   float out_scale, void* stream);
 int hilc_resblock_supported(int C, int T);
+
+/* ---- EXPERIMENTAL numerics mode "bf16x3" (csrc/gemm_x3.h) — opt-in, decoder side only, never the default --------
+ * The layer's GEMM runs on the bf16 matrix pipe with both operands split into two bf16 parts (three products, fp32
+ * accumulation): operands carry 16 significant bits instead of 24.  Nothing in the reference corresponds to it; the
+ * product calls these entry points only when the caller asks for it (hilcodec_amd.engine.DECODER_GEMM = "bf16x3"),
+ * and only for decoder layers, so the encoder, the RVQ and therefore every index stay exact fp32.
+ * hilc_x3_split_weights: k-major fp32 `[K][M]` -> `wsplit` = `[2][K][M]` bf16 (head, head of the remainder).
+ * hilc_dws_conv_x3 / hilc_up_conv_x3: as hilc_dws_conv (ksize 5, stride 1) / hilc_up_conv_expanded (in_elu = 1, no cache)
+ * with `wsplit` in place of `wt`; K % 32 == 0, M % 8 == 0, T % 4 == 0 (hilc_x3_supported), else HILC_ERR_UNSUPPORTED. */
+int hilc_x3_supported(int K, int M, int T);
+int hilc_x3_split_weights(const float* wt, void* wsplit, int K, int M, void* stream);
+int hilc_dws_conv_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* res, float* y,
+                     int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
+int hilc_up_conv_x3(const float* x, const float* tr_w, const float* tr_w_expanded, const void* wsplit, const float* bias,
+                    float* y, int B, int K, int M, int Tin, int stride, float in_scale, void* stream);
 
 /* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv
  * takes) into "MFMA lane order": the operands one lane feeds to the matrix pipe for a 16-deep K slice become

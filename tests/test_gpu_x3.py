@@ -1,0 +1,106 @@
+"""GPU: the EXPERIMENTAL bf16x3 numerics mode (csrc/gemm_x3.h; opt-in, offline decoder only, never the default).
+Layer level: the split-operand GEMM against the exact fp32 kernels it mirrors (same prologues, same epilogues), on the
+decoder's shapes.  Path level: with engine.DECODER_GEMM = "bf16x3" every index is unchanged (the encoder and the RVQ
+are not touched), the decoded waveform stays within 5e-5 of the fp32 product path and within the codec's 1e-4 bar of
+the real reference's golden waveform; the default mode is restored and bit-identical afterwards."""
+import numpy as np
+import pytest
+import torch
+
+from hilcodec_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def rnd(seed, *shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def test_split_is_exact_to_16_bits():
+    from hilcodec_amd import ops
+    w = (rnd(1, 96, 64) * 0.3).to(DEV)
+    s = ops.x3_split(w)
+    assert s.shape == (2, 96, 64) and s.dtype == torch.int16
+    parts = (s.to(torch.int32) << 16).view(torch.float32)            # bf16 bit patterns -> fp32
+    hi, lo = parts[0], parts[1]
+    assert torch.equal(hi, w.to(torch.bfloat16).float())             # round to nearest even, like torch
+    assert torch.equal(lo, (w - hi).to(torch.bfloat16).float())
+    assert ((hi + lo) - w).abs().max() <= w.abs().max() * 2.0 ** -16
+
+
+@pytest.mark.parametrize("K,M,Tn,B", [(768, 768, 600, 3), (384, 384, 1000, 2), (192, 192, 372, 2), (96, 96, 128, 3),
+                                       (64, 72, 40, 1), (1536, 768, 76, 2)])
+def test_dws_conv_x3_vs_fp32(K, M, Tn, B):
+    from hilcodec_amd import ops, fold
+    x = rnd(K + Tn, B, K, Tn).to(DEV)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    wt = fold.pointwise_layout(w).to(DEV)
+    dw = (rnd(3, M, 5) * 0.4).to(DEV)
+    db = (rnd(4, M) * 0.2).to(DEV)
+    res = rnd(5, B, M, Tn).to(DEV)
+    ws = ops.x3_split(wt)
+    for kw in (dict(in_scale=0.9, in_elu=True, out_elu=True), dict(res=res, out_scale=0.5)):
+        ref = ops.dws_conv(x, wt, dw, db, **kw)
+        y = ops.dws_conv_x3(x, ws, dw, db, **kw)
+        err = (y - ref).abs().max().item()
+        assert err <= 4e-5 * max(1.0, ref.abs().max().item()), (kw.keys(), err)
+        assert err > 0.0                                             # it IS a different arithmetic: not silently the fp32 kernel
+    assert ops.x3_supported(768, 768, 600) and not ops.x3_supported(100, 768, 600) and not ops.x3_supported(768, 100, 600)
+    with pytest.raises(RuntimeError):
+        ops.dws_conv_x3(x[:, : K - 16].contiguous(), ops.x3_split(wt[: K - 16].contiguous()), dw, db)   # K % 32 != 0: no silent fallback
+
+
+@pytest.mark.parametrize("K,M,Tin,r,B", [(1536, 768, 75, 8, 2), (768, 384, 60, 5, 2), (384, 192, 300, 4, 2), (192, 96, 1000, 2, 2)])
+def test_up_conv_x3_vs_fp32(K, M, Tin, r, B):
+    from hilcodec_amd import ops, fold
+    x = rnd(K + Tin, B, K, Tin).to(DEV)
+    tw = rnd(K + r, K, 2 * r).to(DEV)
+    w = rnd(K + M, M, K, 1) / K ** 0.5
+    wt = fold.pointwise_layout(w).to(DEV)
+    b = (rnd(M, M) * 0.1).to(DEV)
+    ref = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True)
+    y = ops.up_conv_x3(x, tw, ops.x3_split(wt), b, r, in_scale=0.7071)
+    err = (y - ref).abs().max().item()
+    assert 0.0 < err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("name", ["hil_speech", "hil_music"])
+def test_decoder_in_bf16x3_mode(golden, name):
+    import hilcodec_amd
+    from hilcodec_amd import engine
+    g = golden(f"offline_{name}")
+    mk = synth.model_kwargs(name)
+    model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+    model.load_state_dict(synth.synth_state_dict(name, seed=7), strict=False)
+    for l in model.quantizer.layers:
+        l.initted = True
+    n = g["z"].shape[0]
+    x = synth.synth_clips(max(n, 8), 24000, seed=int(g["clip_seed"])).to(DEV)
+
+    def run():
+        with torch.no_grad():
+            z = model.encoder(x)
+            q, _, _, idx = model.quantizer(z, None, return_indices=True)
+            return idx, model.decoder(q)
+
+    idx0, wav0 = run()
+    assert engine.DECODER_GEMM == "fp32"
+    engine.DECODER_GEMM = "bf16x3"
+    try:
+        idx1, wav1 = run()
+    finally:
+        engine.DECODER_GEMM = "fp32"
+    idx2, wav2 = run()
+    assert torch.equal(idx0, idx1) and torch.equal(idx1[:n].cpu(), torch.from_numpy(np.asarray(g["indices"])).long())
+    d = (wav1 - wav0).abs().max().item()
+    assert 0.0 < d < 5e-5, d
+    assert (wav1[:n].cpu() - torch.from_numpy(np.asarray(g["wav"]))).abs().max() < 1e-4      # the reference's golden waveform
+    assert torch.equal(wav2, wav0) and torch.equal(idx2, idx0)                                # the default is untouched
+    engine.DECODER_GEMM = "tf32"
+    try:
+        with pytest.raises(RuntimeError):
+            run()
+    finally:
+        engine.DECODER_GEMM = "fp32"
