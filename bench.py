@@ -339,6 +339,9 @@ def main():
                 sus["peak_at_sclk_tflops"] = FP32_MFMA_PEAK_TFLOPS * sus["sclk_mhz"] / 2400.0
                 sus["whole_path_frac_at_sclk"] = whole_tflops / sus["peak_at_sclk_tflops"]
                 roof["sustained"] = sus
+        if numerics is not None:
+            roof["note"] = ("EXPERIMENTAL line: part of the work runs on the bf16 matrix pipe; every fraction here is "
+                            "fp32-EQUIVALENT flops against the fp32 peak, not a utilisation")
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)

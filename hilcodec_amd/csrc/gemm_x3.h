@@ -9,7 +9,7 @@
 //
 // Same tiling, B-operand policies (gemm_lin.h) and epilogues (gemm_epilogues.h) as the fp32 core: a workgroup =
 // 32*MB rows x 128 columns, wave w owns column block w.  Differences:
-//   * a K step is 32 deep (two 32x32x16 MFMA steps per barrier); K % 32 == 0
+//   * a staged step is X3_KS 32x32x16 MFMA steps deep; global loads run X3_DEPTH staged steps ahead; K % 32 == 0
 //   * the weights arrive pre-split (hilc_x3_split_weights: [2][K][M] bf16, once per checkpoint) and are copied to LDS;
 //     the activations go through the layer's own prologue (Scale / ELU / transposed-conv taps) in fp32 and are split
 //     while they are staged: 2.5 VALU per element (v_cvt_pk_bf16_f32, two masks, one packed subtract, one more cvt)
@@ -17,6 +17,8 @@
 //     consecutive k of one column, which is what ds_read_b64_tr_b16 delivers from that image (a 4 x 16 transpose per
 //     16 lanes).  Row stride 320 B: the two 16-lane groups served in one LDS cycle never share a bank.
 #pragma once
+#include <utility>
+
 #include "gemm_lin.h"
 
 namespace hilc {
@@ -27,10 +29,30 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-constexpr int X3_BK = 2 * BK;        // 32 rows per staged step
+#ifndef HILC_X3_KS
+#define HILC_X3_KS 1                 // 16-deep MFMA steps per staged step (barrier): 1 = 40 KB of LDS (4 workgroups per CU), 2 = 80 KB
+#endif
+#ifndef HILC_X3_DEPTH
+#define HILC_X3_DEPTH 1              // staged steps between a global load and its use (measured: 2-4 are slower, the unrolled ring doubles the VGPRs)
+#endif
+#ifndef HILC_X3_MIN_WAVES
+#define HILC_X3_MIN_WAVES 1          // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int X3_MIN_WAVES = HILC_X3_MIN_WAVES;
+constexpr int X3_KS = HILC_X3_KS;
+constexpr int X3_DEPTH = HILC_X3_DEPTH;
+constexpr int X3_BK = X3_KS * BK;    // rows per staged step
 constexpr int X3_RS = 160;           // LDS row stride, bf16 elements
 constexpr int X3_PART = X3_BK * X3_RS;   // elements of one operand part of one buffer
 static_assert(BK == 16 && BP == 2, "two B slices of the fp32 core per step");
+
+template <int I, int N, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    x3_static_for<I + 1, N>(f);
+  }
+}
 
 // 4 fp32 -> their bf16 heads and the bf16 heads of the remainders, packed 4 x 16 bit each
 __device__ __forceinline__ void x3_split4(f32x4 v, uint2& hi, uint2& lo) {
@@ -43,7 +65,7 @@ __device__ __forceinline__ void x3_split4(f32x4 v, uint2& hi, uint2& lo) {
 }
 
 template <int MB, class BOp, class Epilogue>
-__global__ __launch_bounds__(NT) void gemm_x3_kernel(const unsigned short* __restrict__ wsplit, int M, int K, int ldw,
+__global__ __launch_bounds__(NT, X3_MIN_WAVES) void gemm_x3_kernel(const unsigned short* __restrict__ wsplit, int M, int K, int ldw,
                                                      long ntiles, int mtiles, BOp bop, Epilogue ep) {
   constexpr int BM = 32 * MB;
   constexpr int AG = X3_BK * BM / 8;            // 16-B chunks of one weight part per step
@@ -92,34 +114,40 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const unsigned short* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  f32x4 ra[2][AP];
-  typename BOp::Raw rb[2][BP];
-  auto fetch = [&](int kt) {
+  // Global loads run DEPTH staged steps ahead of their use, in a ring of register sets (slot = step % DEPTH): at bf16
+  // rates a 16-deep step is 12 MFMAs = 384 cycles per wave, far less than one HBM round trip, so a single step of
+  // lead (the fp32 core's scheme) leaves the kernel latency-bound (measured: K = 384 ran at 23 % MFMA utilisation).
+  constexpr int DEPTH = X3_DEPTH;
+  f32x4 ra[DEPTH][2][AP];
+  typename BOp::Raw rb[DEPTH][X3_KS][BP];
+  auto fetch = [&](int kt, auto slot) {
+    constexpr int S = decltype(slot)::value;
     const char* sa = reinterpret_cast<const char*>(wsplit) + (size_t)kt * a_step;   // uniform
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
       for (int p = 0; p < AP; ++p)
-        ra[part][p] = *reinterpret_cast<const f32x4*>(sa + (size_t)part * part_stride * 2u + aoff[p]);
+        ra[S][part][p] = *reinterpret_cast<const f32x4*>(sa + (size_t)part * part_stride * 2u + aoff[p]);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < X3_KS; ++s)
 #pragma unroll
-      for (int h = 0; h < BP; ++h) rb[s][h] = bop.fetch(bs, 2 * kt + s, false, h);
+      for (int h = 0; h < BP; ++h) rb[S][s][h] = bop.fetch(bs, X3_KS * kt + s, false, h);
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, auto slot) {
+    constexpr int S = decltype(slot)::value;
 #pragma unroll
     for (int part = 0; part < 2; ++part)
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
         const int g = tid + p * NT;
-        if (AG % NT == 0 || g < AG) *reinterpret_cast<f32x4*>(lds + a_at(buf, part) + alds[p]) = ra[part][p];
+        if (AG % NT == 0 || g < AG) *reinterpret_cast<f32x4*>(lds + a_at(buf, part) + alds[p]) = ra[S][part][p];
       }
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < X3_KS; ++s)
 #pragma unroll
       for (int h = 0; h < BP; ++h) {
         uint2 hi, lo;
-        x3_split4(bop.xform(bs, rb[s][h], false, h), hi, lo);
+        x3_split4(bop.xform(bs, rb[S][s][h], false, h), hi, lo);
         const int e = (s * BK + (tid >> 5) + 8 * h) * X3_RS + (tid & 31) * 4;
         *reinterpret_cast<uint2*>(lds + b_at(buf, 0) + e) = hi;
         *reinterpret_cast<uint2*>(lds + b_at(buf, 1) + e) = lo;
@@ -137,16 +165,9 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const unsigned short* __res
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p + 4 * X3_RS));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
-
-  fetch(0);
-  stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < ksteps; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < ksteps;
-    if (more) fetch(kt + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < X3_KS; ++ks) {
       const bf16x8 b1 = operand(b_at(buf, 0), ks, wave * 32);
       const bf16x8 b2 = operand(b_at(buf, 1), ks, wave * 32);
 #pragma unroll
@@ -158,10 +179,25 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const unsigned short* __res
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[i], 0, 0, 0);
       }
     }
-    if (more) {
-      stage(buf ^ 1);
-      __syncthreads();
-    }
+  };
+
+  x3_static_for<0, DEPTH>([&](auto d) {
+    if (decltype(d)::value < ksteps) fetch(decltype(d)::value, d);
+  });
+  stage(0, std::integral_constant<int, 0>{});
+  __syncthreads();
+  for (int kt0 = 0; kt0 < ksteps; kt0 += DEPTH) {
+    x3_static_for<0, DEPTH>([&](auto d) {
+      constexpr int D = decltype(d)::value;
+      const int kt = kt0 + D;
+      if (kt >= ksteps) return;
+      if (kt + DEPTH < ksteps) fetch(kt + DEPTH, d);   // slot D held step kt, which was staged one iteration ago
+      compute(kt & 1);
+      if (kt + 1 < ksteps) {
+        stage((kt + 1) & 1, std::integral_constant<int, (D + 1) % DEPTH>{});
+        __syncthreads();
+      }
+    });
   }
   if (EPI > 0) __syncthreads();     // the epilogue re-uses the staging buffers
   ep.template run<MB>(acc, smem, m0, ntile, wave, lane, tid);
@@ -170,7 +206,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const unsigned short* __res
 template <class BOp, class Epilogue>
 int launch_x3(const unsigned short* wsplit, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep,
               hipStream_t s) {
-  if (K % X3_BK != 0 || ldw % 8 != 0 || (reinterpret_cast<uintptr_t>(wsplit) & 15)) return HILC_ERR_UNSUPPORTED;
+  if (K % 32 != 0 || ldw % 8 != 0 || (reinterpret_cast<uintptr_t>(wsplit) & 15)) return HILC_ERR_UNSUPPORTED;
   const int m32 = (M + 31) / 32;
   const int MB = pick_mb(m32, ntiles);
   const long groups = (ntiles + 7) / 8;

@@ -31,7 +31,7 @@ extern "C" int hilc_x3_split_weights(const float* wt, void* wsplit, int K, int M
   return HILC_OK;
 }
 
-extern "C" int hilc_x3_supported(int K, int M, int T) { return K % X3_BK == 0 && M % 8 == 0 && T % 4 == 0; }
+extern "C" int hilc_x3_supported(int K, int M, int T) { return K % 32 == 0 && M % 8 == 0 && T % 4 == 0; }
 
 extern "C" int hilc_dws_conv_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* res,
                                 float* y, int B, int K, int M, int T, float in_scale, int in_elu, float out_scale,
