@@ -20,12 +20,14 @@ struct DwArgs {
   int in_elu;
   float out_scale;
   int out_elu;
+  int hist_raw;   // the history holds RAW input samples (the waveform cache of the first conv): they take the prologue
+                  // too; 0 = it holds prologue'd samples (the depthwise caches)
 };
 
 // extended input: history for t < 0 (zero if none), prologue'd x for 0 <= t < T, zero beyond.
 __device__ __forceinline__ float xe(const DwArgs& a, const float* xrow, const float* hrow, int t) {
   if (t >= 0) return t < a.T ? prologue(xrow[t], a.in_scale, a.in_elu) : 0.f;
-  if (hrow != nullptr) return hrow[a.hist_len + t];
+  if (hrow != nullptr) return a.hist_raw ? prologue(hrow[a.hist_len + t], a.in_scale, a.in_elu) : hrow[a.hist_len + t];
   return 0.f;
 }
 
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(256) void dw_k5_vec_kernel(DwArgs a, long total) {
     v[0] = prev.x; v[1] = prev.y; v[2] = prev.z; v[3] = prev.w;
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = hrow ? hrow[a.hist_len - 4 + j] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      v[j] = hrow ? hrow[a.hist_len - 4 + j] : 0.f;
+      if (a.hist_raw && hrow) v[j] = prologue(v[j], a.in_scale, a.in_elu);
+    }
   }
   float wk[5];
 #pragma unroll
@@ -276,7 +281,7 @@ extern "C" int hilc_dw_conv(const float* x, const float* hist, const float* w, c
   a.x = x; a.hist = hist; a.w = w; a.bias = bias; a.res = res; a.y = y;
   a.C = C; a.Cin = C; a.T = T; a.To = (T + stride - 1) / stride; a.ksize = ksize; a.stride = stride;
   a.pad = (ksize - 1) - (stride - 1); a.hist_len = a.pad;
-  a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.out_elu = out_elu;
+  a.in_scale = in_scale; a.in_elu = in_elu; a.out_scale = out_scale; a.out_elu = out_elu; a.hist_raw = 0;
   int rc = launch_dw(a, B, (hipStream_t)stream);
   if (rc != HILC_OK) return rc;
   if (hist_out) return launch_hist_out(x, hist, hist_out, (long)B * C, T, a.pad, a.pad, in_scale, in_elu, (hipStream_t)stream);
@@ -293,7 +298,7 @@ extern "C" int hilc_conv_pre(const float* wav, const float* hist, int hist_len, 
   a.x = wav; a.hist = hist; a.w = w; a.bias = bias; a.res = nullptr; a.y = y;
   a.C = C; a.Cin = 1; a.T = T; a.To = T; a.ksize = ksize; a.stride = 1; a.pad = ksize - 1;
   a.hist_len = hist ? hist_len : a.pad;
-  a.in_scale = in_scale; a.in_elu = 0; a.out_scale = 1.f; a.out_elu = 0;
+  a.in_scale = in_scale; a.in_elu = 0; a.out_scale = 1.f; a.out_elu = 0; a.hist_raw = 1;
   return launch_dw(a, B, (hipStream_t)stream);
 }
 

@@ -7,8 +7,9 @@
 // 16x the multiply-adds per cycle; it is only reachable through the *_x3 entry points, which the product calls for the
 // DECODER only and only when the caller opts in (the encoder and the RVQ, hence every index, stay exact fp32).
 //
-// Same tiling, B-operand policies (gemm_lin.h) and epilogues (gemm_epilogues.h) as the fp32 core: a workgroup =
-// 32*MB rows x 128 columns, wave w owns column block w.  Differences:
+// Same B-operand policies (gemm_lin.h) and epilogues (gemm_epilogues.h) as the fp32 core.  Two workgroup shapes: the
+// fp32 core's (32*MB rows x 128 columns, 4 waves, wave w owns column block w) and, where M is a multiple of 192 or 256,
+// an 8-wave form on 64*MB rows (gemm_x3w_kernel).  Differences from the fp32 core:
 //   * a staged step is X3_KS 32x32x16 MFMA steps deep; global loads run X3_DEPTH staged steps ahead; K % 32 == 0
 //   * the weights arrive pre-split (hilc_x3_split_weights: [2][K][M] bf16, once per checkpoint) and are copied to LDS;
 //     the activations go through the layer's own prologue (Scale / ELU / transposed-conv taps) in fp32 and are split
@@ -203,16 +204,144 @@ __global__ __launch_bounds__(NT, X3_MIN_WAVES) void gemm_x3_kernel(const unsigne
   ep.template run<MB>(acc, smem, m0, ntile, wave, lane, tid);
 }
 
+// ---- 8-wave form: a workgroup = 64*MB rows x 128 columns; waves w and w + 4 share column block w & 3 and own the
+// lower / upper MB row blocks.  Against the 4-wave form every staged activation (prologue + split: the dominant VALU
+// work at bf16 rates) feeds twice as many MFMAs and every activation row tile is read from L2 half as often, at the
+// same number of waves per SIMD (two workgroups of 8 waves per CU instead of four of 4).  The two wave groups run the
+// (4-wave) epilogue side by side on their own half tile and their own LDS region; barriers inside it are hit by all
+// 512 threads the same number of times.
+constexpr int X3W_RSA = 288;         // weight-image row stride (bf16): 256 columns + 32, same bank argument as X3_RS
+template <int MB, class BOp, class Epilogue>
+__global__ __launch_bounds__(2 * NT) void gemm_x3w_kernel(const unsigned short* __restrict__ wsplit, int M, int K, int ldw,
+                                                          long ntiles, int mtiles, BOp bop, Epilogue ep) {
+  constexpr int BM = 64 * MB;
+  constexpr int AG = BK * BM / 8;               // 16-B chunks of one weight part per step (<= 512)
+  constexpr int APART = BK * X3W_RSA;           // elements of one weight part of one buffer
+  constexpr int BPART = BK * X3_RS;
+  constexpr int BUF = 2 * APART + 2 * BPART;    // elements of one buffer: [A1 | A2 | B1 | B2]
+  constexpr int STG = 2 * BUF / 2;              // floats
+  constexpr int EPI1 = Epilogue::template lds_floats<MB>();
+  constexpr int SM = STG > 2 * EPI1 ? STG : 2 * EPI1;
+  static_assert(AG <= 2 * NT, "one weight chunk per thread and part");
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  unsigned short* const lds = reinterpret_cast<unsigned short*>(smem);
+  auto a_at = [](int buf, int part) { return buf * BUF + part * APART; };
+  auto b_at = [](int buf, int part) { return buf * BUF + 2 * APART + part * BPART; };
+
+  long id = blockIdx.x;
+  long grp = id / (8L * mtiles);
+  int within = (int)(id - grp * 8L * mtiles);
+  long ntile = grp * 8 + (within & 7);
+  int mtile = within >> 3;
+  if (ntile >= ntiles) return;
+  const int m0 = mtile * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp8 = wave >> 2;                   // 0: lower row blocks, 1: upper
+  const int t256 = tid & (NT - 1);
+  const int ksteps = K / BK;
+  const long part_stride = (long)K * ldw;
+
+  const int kr = tid / (BM / 8), m8 = (tid % (BM / 8)) * 8;
+  int acol = m0 + m8;
+  acol = acol < ldw - 8 ? acol : ldw - 8;
+  const bool a_live = tid < AG;
+  const unsigned aoff = a_live ? (unsigned)(kr * ldw + acol) * 2u : 0u;
+  const int alds = kr * X3W_RSA + m8;
+  const unsigned a_step = (unsigned)BK * (unsigned)ldw * 2u;
+  const typename BOp::State bs = bop.init(ntile, t256, BK);   // this thread stages row (t256 >> 5) + 8 * grp8 of every step
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  f32x4 ra[2];
+  typename BOp::Raw rb;
+  auto fetch = [&](int kt) {
+    const char* sa = reinterpret_cast<const char*>(wsplit) + (size_t)kt * a_step;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+      ra[part] = *reinterpret_cast<const f32x4*>(sa + (size_t)part * part_stride * 2u + aoff);
+    rb = grp8 == 0 ? bop.fetch(bs, kt, false, 0) : bop.fetch(bs, kt, false, 1);
+  };
+  auto stage = [&](int buf) {
+    if (a_live) {
+#pragma unroll
+      for (int part = 0; part < 2; ++part) *reinterpret_cast<f32x4*>(lds + a_at(buf, part) + alds) = ra[part];
+    }
+    uint2 hi, lo;
+    x3_split4(grp8 == 0 ? bop.xform(bs, rb, false, 0) : bop.xform(bs, rb, false, 1), hi, lo);
+    const int e = ((t256 >> 5) + 8 * grp8) * X3_RS + (t256 & 31) * 4;
+    *reinterpret_cast<uint2*>(lds + b_at(buf, 0) + e) = hi;
+    *reinterpret_cast<uint2*>(lds + b_at(buf, 1) + e) = lo;
+  };
+  const int g16 = lane >> 4, p16 = lane & 15;
+  const int trow = 8 * (g16 >> 1) + (p16 >> 2), tcol = 16 * (g16 & 1) + 4 * (p16 & 3);
+  auto operand = [&](int base, int rs, int col0) -> bf16x8 {
+    const unsigned short* p = lds + base + trow * rs + tcol + col0;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p + 4 * rs));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < ksteps; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ksteps;
+    if (more) fetch(kt + 1);
+    const bf16x8 b1 = operand(b_at(buf, 0), X3_RS, (wave & 3) * 32);
+    const bf16x8 b2 = operand(b_at(buf, 1), X3_RS, (wave & 3) * 32);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const bf16x8 a1 = operand(a_at(buf, 0), X3W_RSA, (grp8 * MB + i) * 32);
+      const bf16x8 a2 = operand(a_at(buf, 1), X3W_RSA, (grp8 * MB + i) * 32);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[i], 0, 0, 0);
+    }
+    if (more) {
+      stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  ep.template run<MB>(acc, smem + grp8 * EPI1, m0 + grp8 * 32 * MB, ntile, wave & 3, lane, t256);
+}
+
+#ifndef HILC_X3_WIDE
+#define HILC_X3_WIDE 1
+#endif
+
 template <class BOp, class Epilogue>
 int launch_x3(const unsigned short* wsplit, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep,
               hipStream_t s) {
   if (K % 32 != 0 || ldw % 8 != 0 || (reinterpret_cast<uintptr_t>(wsplit) & 15)) return HILC_ERR_UNSUPPORTED;
   const int m32 = (M + 31) / 32;
-  const int MB = pick_mb(m32, ntiles);
   const long groups = (ntiles + 7) / 8;
+  if (ntiles <= 0) return HILC_ERR_SHAPE;
+  if (HILC_X3_WIDE && (M % 256 == 0 || M % 192 == 0) && groups * 8 * (M / 192 + 1) >= 2L * device_cus()) {
+    const int MBW = M % 256 == 0 ? 4 : 3;
+    const int mt = M / (64 * MBW);
+    const long nb = groups * 8 * mt;
+    if (nb > 0x7fffffffL) return HILC_ERR_SHAPE;
+    HILC_CLEAR_ERROR();
+    if (MBW == 4)
+      hipLaunchKernelGGL((gemm_x3w_kernel<4, BOp, Epilogue>), dim3((unsigned)nb), dim3(2 * NT), 0, s, wsplit, M, K, ldw, ntiles, mt, bop, ep);
+    else
+      hipLaunchKernelGGL((gemm_x3w_kernel<3, BOp, Epilogue>), dim3((unsigned)nb), dim3(2 * NT), 0, s, wsplit, M, K, ldw, ntiles, mt, bop, ep);
+    HILC_CHECK_LAUNCH();
+    return HILC_OK;
+  }
+  const int MB = pick_mb(m32, ntiles);
   int mtiles = (m32 + MB - 1) / MB;
   long blocks = groups * 8 * mtiles;
-  if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+  if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   dim3 grid((unsigned)blocks), block(NT);
   HILC_CLEAR_ERROR();
   switch (MB) {

@@ -469,11 +469,17 @@ def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
     assert torch.equal(y_h, ops.pw_conv(s_h, wt, bias, res=x.to(dev), out_scale=0.37))
     assert not torch.equal(y_h, ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x.to(dev), n_fft, hop, -4.0, 2.8, 0, 0.37))
     if n_fft == 64:
-        # (in_scale 1: the streaming model merges 1/wav_std into the weights, `streaming.py:472-480`)
-        x0h = ops.conv_pre(wav.to(dev), (rnd(71, 64, 5) * 0.5).to(dev), None, in_scale=1.0, hist=hist)
-        y_1 = ops.spec_block_conv_pre(wav.to(dev), dft_p, nyq, pw_p, bias, (rnd(71, 64, 5) * 0.5).to(dev), None, 1.0, n_fft,
-                                      hop, -4.0, 2.8, 0, 0.37, hist=hist)
-        assert torch.equal(y_1, ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x0h, n_fft, hop, -4.0, 2.8, 0, 0.37, hist=hist))
+        # the waveform cache holds RAW samples: both kernels scale them like the hop's own samples (the streaming model
+        # merges 1/wav_std into the weights, `streaming.py:472-480`, so it calls with 1.0; 2.5 exercises the general case)
+        for isc in (1.0, 2.5):
+            x0h = ops.conv_pre(wav.to(dev), (rnd(71, 64, 5) * 0.5).to(dev), None, in_scale=isc, hist=hist)
+            y_1 = ops.spec_block_conv_pre(wav.to(dev), dft_p, nyq, pw_p, bias, (rnd(71, 64, 5) * 0.5).to(dev), None, isc, n_fft,
+                                          hop, -4.0, 2.8, 0, 0.37, hist=hist)
+            assert torch.equal(y_1, ops.spec_block(wav.to(dev), dft_p, nyq, pw_p, bias, x0h, n_fft, hop, -4.0, 2.8, 0, 0.37, hist=hist))
+        # and against the oracle's causal conv over [cache | hop]
+        full = torch.cat([hist.cpu()[:, :, -4:], wav], dim=2) * 2.5
+        ref0 = F.conv1d(full, (rnd(71, 64, 5) * 0.5).view(64, 1, 5))
+        close(x0h, ref0, 2e-5, "conv_pre with a raw waveform cache")
     if n_fft == 64:
         # first encoder stage: conv_pre computed inside the SpecBlock launch == conv_pre launch + SpecBlock launch
         pw_, pb_ = (rnd(71, 64, 5) * 0.5).to(dev), (rnd(72, 64) * 0.1).to(dev)
