@@ -11,6 +11,7 @@ behaviours of the reference's two decoders are data in the spe
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -32,15 +33,16 @@ FUSE_RESBLOCK_MAX_C = 192
 # encoder and the RVQ — hence every index — are never touched.  Default "fp32" = the reference's arithmetic.
 DECODER_GEMM = "fp32"
 X3_FUSED_BLOCK_MIN_C = 10 ** 9   # residual blocks of at least this width leave the fused fp32 kernel for two bf16x3 launches
-_X3_SPLIT = {}            # id(weight tensor) -> (weight tensor, its split form); built on first use
+_X3_SPLIT = {}            # id(weight tensor) -> (weak reference, version, split form); built on first use, dies with the weight
 
 
 def _x3(wt: Tensor) -> Tensor:
-    hit = _X3_SPLIT.get(id(wt))
-    if hit is None or hit[0] is not wt:
-        hit = (wt, ops.x3_split(wt))
-        _X3_SPLIT[id(wt)] = hit
-    return hit[1]
+    key = id(wt)
+    hit = _X3_SPLIT.get(key)
+    if hit is None or hit[0]() is not wt or hit[1] != wt._version:      # new tensor at a recycled id, or weights updated in place
+        hit = (weakref.ref(wt, lambda _, k=key: _X3_SPLIT.pop(k, None)), wt._version, ops.x3_split(wt))
+        _X3_SPLIT[key] = hit
+    return hit[2]
 
 
 SIDE_STREAM = None        # set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves
@@ -364,7 +366,9 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     q = q.contiguous().float()
     if DECODER_GEMM not in ("fp32", "bf16x3"):
         raise RuntimeError(f"engine.DECODER_GEMM must be 'fp32' or 'bf16x3', got {DECODER_GEMM!r}")
-    x3 = DECODER_GEMM == "bf16x3" and not streaming and not torch.compiler.is_compiling()
+    if DECODER_GEMM != "fp32" and torch.compiler.is_compiling():
+        raise RuntimeError("engine.DECODER_GEMM = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
+    x3 = DECODER_GEMM == "bf16x3" and not streaming
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
