@@ -304,31 +304,59 @@ struct DwStrideEpilogue {
     const int k = KR > 0 ? KR : 2 * r;
     const int o = o0 + lane;
     const bool live = lane < n_out && o < To;
+    const bool first = hist != nullptr && o0 == 0;          // uniform: a clip's first tile in a streaming hop
+    const bool last = hist_out != nullptr && o0 + n_out >= To;
+    // rows in groups of RG: the taps and biases of the whole group are requested (scalar loads) before the first row is
+    // computed — one exposed scalar-memory round trip per group instead of one per row (at K = 64 / 128 this epilogue,
+    // not the K loop, is most of the tile)
+#ifdef HILC_DWS_RG
+    constexpr int RG = HILC_DWS_RG;
+#else
+    constexpr int RG = KR > 0 && KR <= 8 ? 4 : 2;
+#endif
 #pragma unroll
     for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
       const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
-      for (int s = 0; s < 8 * nblk; ++s) {
-        const int row = __builtin_amdgcn_readfirstlane(wave + 4 * s);
-        const int m = m0 + ch * CH * 32 + row;
-        if (m >= M) break;                      // uniform
-        const float* w = dw_w + (long)m * k;
-        const float* h = smem + row * HS + (H - r) + (live ? lane : 0) * r;
-        float a = 0.f;
-        if (hist != nullptr && o0 == 0) {        // uniform: a clip's first tile in a streaming hop — output 0's first
-          const bool from_cache = lane == 0;     // r taps lie before t = 0 and come from the cache, not the zero halo
-          const float* hc = hist + (b * M + m) * (long)r;
-          for (int j = 0; j < k; ++j) a = fmaf(w[j], (from_cache && j < r) ? hc[j] : h[j], a);
-        } else if (KR > 0) {
+      for (int s0 = 0; s0 < 8 * nblk; s0 += RG) {
+        float wv[RG][KR > 0 ? KR : 1];
+        float bv[RG];
+        int mrow[RG];
 #pragma unroll
-          for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(w[j], h[j], a);
-        } else {
-          for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+        for (int g = 0; g < RG; ++g) {
+          const int row = __builtin_amdgcn_readfirstlane(wave + 4 * (s0 + g));
+          const int m = m0 + ch * CH * 32 + row;
+          mrow[g] = m;
+          const int mc = m < M ? m : M - 1;     // uniform clamp: rows past M are computed on row M-1's taps and not stored
+          if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) wv[g][j] = dw_w[(long)mc * k + j];
+          }
+          bv[g] = dw_b ? dw_b[mc] : 0.f;
         }
-        if (dw_b) a = __fadd_rn(a, dw_b[m]);
-        if (live) y[(b * M + m) * (long)To + o] = a;
-        if (hist_out != nullptr && o0 + n_out >= To && lane < r) {      // the clip's last tile: columns of t = T-r .. T-1
-          const int c = (T - r + lane) - (o0 * r - H);
-          hist_out[(b * M + m) * (long)r + lane] = smem[row * HS + c];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const int row = __builtin_amdgcn_readfirstlane(wave + 4 * (s0 + g));
+          const int m = mrow[g];
+          if (s0 + g >= 8 * nblk || m >= M) continue;      // uniform
+          const float* w = dw_w + (long)m * k;
+          const float* h = smem + row * HS + (H - r) + (live ? lane : 0) * r;
+          float a = 0.f;
+          if (first) {                             // output 0's first r taps lie before t = 0: the cache, not the zero halo
+            const bool from_cache = lane == 0;
+            const float* hc = hist + (b * M + m) * (long)r;
+            for (int j = 0; j < k; ++j) a = fmaf(w[j], (from_cache && j < r) ? hc[j] : h[j], a);
+          } else if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(wv[g][j], h[j], a);
+          } else {
+            for (int j = 0; j < k; ++j) a = fmaf(w[j], h[j], a);
+          }
+          if (dw_b) a = __fadd_rn(a, bv[g]);
+          if (live) y[(b * M + m) * (long)To + o] = a;
+          if (last && lane < r) {                  // the clip's last tile: columns of t = T-r .. T-1
+            const int c = (T - r + lane) - (o0 * r - H);
+            hist_out[(b * M + m) * (long)r + lane] = smem[row * HS + c];
+          }
         }
       }
     }
