@@ -535,3 +535,9 @@ extern "C" int hilc_stft_logmag(const float* wav, const float* hist, int hist_le
   }
   return launch_gemm(basis_t, M, n_fft, m_pad, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
 }
+
+#ifdef HILC_DEBUG_STAMPS
+extern "C" int hilc_debug_set_lin_stamp_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(hilc::g_lin_dbg), &p, sizeof(p)) == hipSuccess ? HILC_OK : HILC_ERR_LAUNCH;
+}
+#endif

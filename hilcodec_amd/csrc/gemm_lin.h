@@ -258,6 +258,13 @@ struct StftSegB {
   __device__ f32x4 xform(const State&, Raw v, bool, int) const { return v; }
 };
 
+#ifdef HILC_DEBUG_STAMPS
+__device__ unsigned long long* g_lin_dbg = nullptr;    // [workgroup][8]: 4 s_memtime stamps, HW_ID | XCC_ID << 32 (tools/lin_phase_times.py builds its own library)
+#define LIN_STAMP(i) do { if (g_lin_dbg && threadIdx.x == 0) g_lin_dbg[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LIN_STAMP(i) do { } while (0)
+#endif
+
 template <int MB, class BOp, class Epilogue>
 __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ wt, int M, int K, int ldw, long ntiles,
                                                       int mtiles, BOp bop, Epilogue ep) {
@@ -277,6 +284,15 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
   long ntile = grp * 8 + (within & 7);
   int mtile = within >> 3;
   if (ntile >= ntiles) return;
+  LIN_STAMP(0);
+#ifdef HILC_DEBUG_STAMPS
+  if (g_lin_dbg && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_lin_dbg[(long)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int m0 = mtile * BM;
 
   const int tid = threadIdx.x;
@@ -335,6 +351,7 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
   fetch(0, ktiles == 1);
   stage(0, ktiles == 1);
   __syncthreads();
+  LIN_STAMP(1);
   for (int kt = 0; kt < ktiles; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < ktiles;
@@ -361,7 +378,9 @@ __global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ 
       __syncthreads();
     }
   }
+  LIN_STAMP(2);
   ep.template run<MB>(acc, smem, m0, ntile, wave, lane, tid);
+  LIN_STAMP(3);
 }
 
 template <class BOp, class Epilogue>
