@@ -237,6 +237,20 @@ struct Dw5Epilogue {
       for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
       float bias = dw_b ? dw_b[m] : 0.f;
       long rowoff = (b * M + m) * (long)T;
+      // the shortcut rows of all four column groups are requested before the first store: `res` may alias `y`, so the
+      // compiler keeps every later shortcut load behind the earlier stores — four exposed HBM round trips per segment
+      // (the epilogue is ~20 % of a workgroup's life at K = 384, tools/lin_phase_times.py)
+      float4 rq[4];
+#ifndef HILC_DW5_RES_PREFETCH
+#define HILC_DW5_RES_PREFETCH 1
+#endif
+      if (HILC_DW5_RES_PREFETCH && vec && res != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = c0 + 4 * g, t = t0 + c;
+          if (c >= 4 && t < T) rq[g] = *reinterpret_cast<const float4*>(res + rowoff + t);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         int c = c0 + 4 * g;
@@ -254,7 +268,7 @@ struct Dw5Epilogue {
         }
         if (vec) {
           if (res != nullptr) {
-            float4 rr = *reinterpret_cast<const float4*>(res + rowoff + t);
+            const float4 rr = HILC_DW5_RES_PREFETCH ? rq[g] : *reinterpret_cast<const float4*>(res + rowoff + t);
             o[0] = __fadd_rn(o[0], rr.x); o[1] = __fadd_rn(o[1], rr.y);
             o[2] = __fadd_rn(o[2], rr.z); o[3] = __fadd_rn(o[3], rr.w);
           }

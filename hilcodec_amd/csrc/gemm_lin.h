@@ -54,6 +54,7 @@ struct TileCols {
 // rows of a [.., K, T] tensor through the Scale / ELU prologue
 template <class Cols, bool ELU>
 struct RowsB {
+  static constexpr int kMinWaves = 4;   // register budget: four waves per SIMD (54 + 64 registers at MB = 4; the epilogues may use the rest)
   const float* x;
   int T;
   float in_scale;
@@ -102,6 +103,7 @@ struct RowsB {
 // per row like R = 8 / 4 (every VMEM instruction in this loop costs ~16 cycles of MFMA issue).
 template <int R, bool ELU, bool HIST>
 struct UpB {
+  static constexpr int kMinWaves = 1;   // the tap arithmetic needs ~80 registers beside the 64 accumulators: three waves per SIMD
   const float* x;      // [B][K][Tin]
   const float* w;      // [K][2r], or [K][r][8] for R == 1
   const float* hist;   // [B][K] activated x[-1] (HIST)
@@ -218,6 +220,7 @@ struct UpB {
 // still a constant step (17 words).  n_fft % 16 == 0;  SEG >= (127*hop + n_fft) * 17 / 16.
 template <int SEG>
 struct StftSegB {
+  static constexpr int kMinWaves = 1;
   const float* wav;
   int T, Tf, n_fft, hop, tiles;   // tiles per clip = ceil(Tf / 128)
   typedef f32x4 Raw;
@@ -266,7 +269,7 @@ __device__ unsigned long long* g_lin_dbg = nullptr;    // [workgroup][8]: 4 s_me
 #endif
 
 template <int MB, class BOp, class Epilogue>
-__global__ __launch_bounds__(NT) void gemm_lin_kernel(const float* __restrict__ wt, int M, int K, int ldw, long ntiles,
+__global__ __launch_bounds__(NT, BOp::kMinWaves) void gemm_lin_kernel(const float* __restrict__ wt, int M, int K, int ldw, long ntiles,
                                                       int mtiles, BOp bop, Epilogue ep) {
   constexpr int BM = 32 * MB;
   constexpr int AG = BK * BM / 4;
