@@ -169,11 +169,25 @@ struct PwLdsEpilogue {
         unsigned b = __umulhi((unsigned)(n0 < ncols ? n0 : 0), t_magic) >> t_shift;
         int t = (int)((n0 < ncols ? n0 : 0) - (long)b * T);
         const float* hrow = smem + row * HS + c0;
+        // offsets of the four column groups first, then ALL shortcut loads, then the stores: `res` may alias `y`, so a
+        // shortcut load written after a store stays behind it (one exposed HBM round trip per group otherwise)
+        long offs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          offs[g] = ((long)b * M + m) * (long)T + t;
+          t += 4;
+          if (t >= T) { t = 0; ++b; }
+        }
+        f32x4 rq[4];
+        if (res != nullptr) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (n0 + 4 * g < ncols) rq[g] = *reinterpret_cast<const f32x4*>(res + offs[g]);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           if (n0 + 4 * g < ncols) {
             f32x4 v = *reinterpret_cast<const f32x4*>(hrow + 4 * g);
-            const long off = ((long)b * M + m) * (long)T + t;
             // separate roundings, like the reference's `y.mul_(scale)` then `x.add_(y)` (no FMA contraction)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -182,14 +196,11 @@ struct PwLdsEpilogue {
               v[e] = __fmul_rn(a, out_scale);
             }
             if (res != nullptr) {
-              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], rr[e]);
+              for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], rq[g][e]);
             }
-            *reinterpret_cast<f32x4*>(y + off) = v;
+            *reinterpret_cast<f32x4*>(y + offs[g]) = v;
           }
-          t += 4;
-          if (t >= T) { t = 0; ++b; }
         }
       }
     }
@@ -494,6 +505,17 @@ struct Dw5SegEpilogue {
         const float bias = dw_b ? dw_b[m] : 0.f;
         int q = (int)(__umulhi((unsigned)c0, t_magic) >> t_shift);   // clip of the first column
         int t = c0 - q * T;
+        f32x4 rq[4];
+        if (res != nullptr) {                 // all shortcut loads before the first store (see PwLdsEpilogue)
+          int q2 = q, t2 = t;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const long b2 = ntile * cpt + q2;
+            if ((c0 + 4 * g) < cpt * T && b2 < B) rq[g] = *reinterpret_cast<const f32x4*>(res + (b2 * M + m) * (long)T + t2);
+            t2 += 4;
+            if (t2 >= T) { t2 = 0; ++q2; }
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const long b = ntile * cpt + q;
@@ -521,9 +543,8 @@ struct Dw5SegEpilogue {
             }
             const long off = bm * (long)T + t;
             if (res != nullptr) {
-              const f32x4 rr = *reinterpret_cast<const f32x4*>(res + off);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], rr[e]);
+              for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], rq[g][e]);
             }
             if (out_elu) {
 #pragma unroll

@@ -239,6 +239,12 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
       const float bv = a.bias != nullptr ? a.bias[m] : 0.f;
       const float* er = E + row * ES + c0;
       const long off0 = ybase + (long)m * a.Tf + f0 + c0;
+      f32x4 rq[4];
+      if constexpr (!PRE) {       // all residual loads before the first store (x may alias y: later loads would wait behind it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (f0 + c0 + 4 * g < a.Tf) rq[g] = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (f0 + c0 + 4 * g < a.Tf) {                    // Tf % 4 == 0: whole groups
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
               rr[e] = a.pre_b != nullptr ? __fadd_rn(acc5, a.pre_b[m]) : acc5;
             }
           } else {
-            rr = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+            rr = rq[g];
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
