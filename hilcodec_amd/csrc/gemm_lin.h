@@ -103,7 +103,10 @@ struct RowsB {
 // per row like R = 8 / 4 (every VMEM instruction in this loop costs ~16 cycles of MFMA issue).
 template <int R, bool ELU, bool HIST>
 struct UpB {
-  static constexpr int kMinWaves = 1;   // the tap arithmetic needs ~80 registers beside the 64 accumulators: three waves per SIMD
+  // register budget: the tap arithmetic needs ~80 registers beside the 64 accumulators = three waves per SIMD.  Pinning
+  // it to four (a few spilled registers) pays for the stride-2 and expanded-table (stride-5) forms: -5.5 % / -4 % on the
+  // K = 192 and K = 768 decoder layers; neutral to slightly negative for strides 8 and 4, which keep three.
+  static constexpr int kMinWaves = (R == 1 || R == 2) ? 4 : 1;
   const float* x;      // [B][K][Tin]
   const float* w;      // [K][2r], or [K][r][8] for R == 1
   const float* hist;   // [B][K] activated x[-1] (HIST)
