@@ -238,7 +238,7 @@ def main():
             if args.x3_blocks_from > 0:
                 engine.X3_FUSED_BLOCK_MIN_C = args.x3_blocks_from
             idx_x, wav_x = step(0)
-        numerics = {"mode": args.decoder_gemm, "scope": "offline decoder: up-sampling and depthwise-separable GEMMs"
+        numerics = {"mode": args.decoder_gemm, "scope": "offline decoder: up-sampling and depthwise-separable GEMMs, GEMM phases of the fused residual blocks"
                     + (f", residual blocks of width >= {args.x3_blocks_from}" if args.x3_blocks_from > 0 else "")
                     + "; encoder and RVQ exact fp32",
                     "indices_equal_to_fp32_path": bool(torch.equal(idx_f, idx_x)),

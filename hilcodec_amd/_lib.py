@@ -33,6 +33,8 @@ SIGNATURES = {
     "hilc_x3_split_weights": [_p, _p, _i, _i, _p],
     "hilc_dws_conv_x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_up_conv_x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "hilc_resblock_pack_weights_x3": [_p, _p, _i, _p],
+    "hilc_resblock_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_up_conv_expanded": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

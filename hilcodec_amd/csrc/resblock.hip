@@ -38,6 +38,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "gemm_core.h"
 
@@ -62,8 +63,9 @@ constexpr bool wide_shape() {
   return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
 }
 
-template <int C, bool STREAM>
+template <int C, bool STREAM, bool X3_ = false>
 struct Cfg {
+  static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
   static constexpr bool WIDE = !STREAM && wide_shape<C>();
@@ -206,7 +208,7 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
         // phase's MFMAs below all of its operand loads (every operand then spills); a volatile asm keeps its place
         // among the loads.  D == C (same registers): back-to-back accumulation needs no software wait states.
         if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
         else
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
       }
@@ -220,6 +222,123 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
   // the accumulators are read next by non-MFMA instructions (ds_write after a barrier): the compiler cannot see
   // into the asm, so the 16-pass MFMA -> VALU/DS read hazard (18 wait states) is covered by hand
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+}
+
+// ---- EXPERIMENTAL bf16x3 GEMM phases (hilc_resblock_x3; opt-in, offline decoder only; see gemm_x3.h for the arithmetic) ----
+// Only the two GEMM phases change: the tile in LDS stays fp32 (the depthwise / ELU phases are untouched).  A wave reads
+// the 8 consecutive k of its column for a 16-deep step with eight ds_read_b32, splits them in registers (2.5 VALU per
+// value) and feeds three v_mfma_f32_32x32x16_bf16 per row block; the weights arrive pre-split and packed in lane order
+//   packed16[((((h * C/16 + ks) * CBW + i) * 2 + part) * 64 + lane) * 8 + e] = part(W[ks*16 + 8*(lane >> 5) + e][32*(h*CBW + i) + (lane & 31)])
+// (one 16-B word per lane, row block and part: hilc_resblock_pack_weights_x3; same byte size as the fp32 packing).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+template <class K>
+struct X3Pipe {
+  static constexpr int CBW = K::CBW;
+  static constexpr int DEPTH = 3;                 // 16-deep steps between a weight load and its use
+  static constexpr int WPS = 2 * CBW;             // 16-B words per lane and step
+  f32x4 a[DEPTH][CBW][2];
+  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
+    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+    a[slot][q >> 1][q & 1] = *(gvec_t)(wset + q * 256 + lane * 4);
+  }
+  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d)
+#pragma unroll
+      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
+  }
+};
+
+// 8 fp32 -> bf16 heads and bf16 heads of the remainders, as two 4-register MFMA operands
+__device__ __forceinline__ void split8(const float (&v)[8], f32x4& hi, f32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f32x2 x = {v[2 * p], v[2 * p + 1]};
+    const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+    hi[p] = __builtin_bit_cast(float, h);
+    lo[p] = __builtin_bit_cast(float, l);
+  }
+}
+
+template <class K>
+__device__ __forceinline__ void gemm_phase_x3(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
+                                              X3Pipe<K>& wp, int colblk, int lane) {
+  constexpr int C = K::CH, XS = K::XS, CBW = K::CBW;
+  constexpr int DEPTH = X3Pipe<K>::DEPTH, WPS = X3Pipe<K>::WPS;
+  constexpr int KS = C / 16;
+  const int kh = lane >> 5, l31 = lane & 31;
+  lptr_t xn = (lptr_t)(X + 8 * kh * XS + colblk * 32 + l31);   // this lane's column, rows 8 kh .. 8 kh + 7 of step 0
+  float br[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) br[0][j] = xn[j * XS];
+  const float* wn = wt + (DEPTH - 1) * WPS * 256;
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
+    const bool more = s + DEPTH - 1 < KS;
+    if (s + 1 < KS) {
+      xn += 16 * XS;
+      asm volatile("" : "+v"(xn));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) br[(s + 1) & 1][j] = xn[j * XS];
+    }
+    f32x4 b1, b2;
+    split8(br[s & 1], b1, b2);
+    // Three passes over the row blocks (small terms first).  Builtins, not asm (unlike gemm_phase): with asm MFMAs fed by
+    // VALU conversions this phase produced rare garbage tiles (more often with two workgroups per CU) that neither
+    // early-clobber outputs nor spacing the dependent MFMAs removed — the compiler cannot place hazard wait states or
+    // protect operand registers around an instruction it cannot see into.  A 16-deep step is only 9 MFMAs, and the
+    // scheduling barrier per step keeps the builtin MFMAs from being sunk below the next steps' loads.
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const bf16x8_t vb1 = __builtin_bit_cast(bf16x8_t, b1), vb2 = __builtin_bit_cast(bf16x8_t, b2);
+#pragma unroll
+    for (int i = 0; i < CBW; ++i) {
+      if (more) {
+        wp.load_word((gptr_t)wn, nxt, 2 * i, lane);
+        wp.load_word((gptr_t)wn, nxt, 2 * i + 1, lane);
+      }
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][1]), vb1, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb2, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < CBW; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb1, acc[i], 0, 0, 0);
+    if (more) {
+      wn += WPS * 256;
+      asm volatile("" : "+s"(wn));
+    }
+    // pin the step: an empty asm that "updates" the accumulators and clobbers memory keeps this step's MFMAs above it and
+    // the next steps' loads below it (the builtins are pure: without it hipcc sinks them under every later load and
+    // spills ~120 registers at C = 192)
+    if constexpr (CBW == 3) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) :: "memory");
+    else {
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* wt, unsigned short* packed, int C, int RH) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed` (bf16 elements)
+  if (idx >= 2 * C * C) return;
+  const int CBW = C / 32 / RH, WPS = 2 * CBW, KS = C / 16;
+  const int e = idx & 7, lane = (idx >> 3) & 63, w = idx >> 9;
+  const int q = w % WPS, ks = (w / WPS) % KS, h = w / (WPS * KS);
+  const int i = q >> 1, part = q & 1;
+  const int k = ks * 16 + 8 * (lane >> 5) + e, m = 32 * (h * CBW + i) + (lane & 31);
+  const float v = wt[(long)k * C + m];
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  packed[idx] = __builtin_bit_cast(unsigned short, part ? lo : hi);
 }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C, int RH) {
@@ -262,9 +381,10 @@ struct Cols {
   bool head, tail;     // STREAM: t == 0 (previous 4 samples live in the cache) / t == T-4 on an output column
 };
 
-template <int C, bool STREAM>
-__global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM>;
+template <int C, bool STREAM, bool X3 = false>
+__global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, X3>;
+  using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
   // plain base + constant address instead of a select
@@ -389,7 +509,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void 
         }
       }
     }
-    WeightPipe<K> wp;
+    Pipe wp;
     wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
     // ---- P0: the prologue on the x registers (they stay live: shortcut of P6)
     {
@@ -413,7 +533,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void 
 
     f32x16 acc[CBW];
     // ---- P1, P2
-    gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
+    if constexpr (X3) gemm_phase_x3<K>(w1t, X, acc, wp, colblk, lane);
+    else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
     lds_barrier();
     STAMP(2);
     acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -483,7 +604,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void 
     STAMP(4);
 
     // ---- P4
-    gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
+    if constexpr (X3) gemm_phase_x3<K>(w2t, X, acc, wp, colblk, lane);
+    else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     const bool have_next = next < a.total_tiles;
@@ -585,7 +707,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM>::NT), (Cfg<C, STREAM>::MINW)) void 
 #undef STAMP
 }
 
-template <int C, bool STREAM>
+template <int C, bool STREAM, bool X3 = false>
 int launch_res(ResArgs a, int B, hipStream_t s) {
   a.B = B;
   {  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
@@ -596,7 +718,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
     a.div_shift = (unsigned)(l - 1);
   }
-  using K = Cfg<C, STREAM>;
+  using K = Cfg<C, STREAM, X3>;
   constexpr int TO = K::TO;
   a.tiles = (a.T + TO - 1) / TO;
   a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
@@ -611,7 +733,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     int n_cu = 0, occ = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
       return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM>, K::NT, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, X3>, K::NT, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
     cached = n_cu * occ;
     if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
@@ -619,7 +741,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
   const long resident = cached;
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
@@ -627,7 +749,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
 }  // namespace
 
 namespace {
-int resblock_entry(bool streaming, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                    const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
                    float* hist1_out, float* hist2_out, float* y, int* sched, int B, int C, int T, float pre_scale,
                    float out_scale, void* stream) {
@@ -657,6 +779,13 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
+  if (x3) {            // EXPERIMENTAL bf16x3 GEMM phases: the decoder's widths only
+    switch (C) {
+      case 96: return launch_res<96, false, true>(a, B, (hipStream_t)stream);
+      case 192: return launch_res<192, false, true>(a, B, (hipStream_t)stream);
+      default: return HILC_ERR_UNSUPPORTED;
+    }
+  }
   switch (C) {
     case 64: return launch_res<64, false>(a, B, (hipStream_t)stream);
     case 96: return launch_res<96, false>(a, B, (hipStream_t)stream);
@@ -683,7 +812,7 @@ extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C,
 extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                              const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,
                              int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, nullptr,
+  return resblock_entry(false, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, nullptr,
                         B, C, T, pre_scale, out_scale, stream);
 }
 
@@ -691,7 +820,7 @@ extern "C" int hilc_resblock_stream(const float* x, const float* w1t, const floa
                                     const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
                                     const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C,
                                     int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(true, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, nullptr,
+  return resblock_entry(true, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, nullptr,
                         B, C, T, pre_scale, out_scale, stream);
 }
 
@@ -700,8 +829,27 @@ extern "C" int hilc_resblock_balanced(const float* x, const float* w1t, const fl
                                       const float* hist2, float* hist1_out, float* hist2_out, float* y, int* sched,
                                       int streaming, int B, int C, int T, float pre_scale, float out_scale,
                                       void* stream) {
-  return resblock_entry(streaming != 0, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y,
+  return resblock_entry(streaming != 0, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y,
                         sched, B, C, T, pre_scale, out_scale, stream);
+}
+
+extern "C" int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int C, void* stream) {
+  if (!wt || !packed) return HILC_ERR_NULL;
+  if (!(C == 96 || C == 192)) return HILC_ERR_UNSUPPORTED;
+  if ((const void*)wt == packed) return HILC_ERR_UNSUPPORTED;
+  const int RH = C == 192 ? 2 : 1;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((2 * C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt,
+                     reinterpret_cast<unsigned short*>(packed), C, RH);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
+                                const float* dw2_w, const float* dw2_b, float* y, int* sched, int B, int C, int T,
+                                float pre_scale, float out_scale, void* stream) {
+  return resblock_entry(false, true, x, reinterpret_cast<const float*>(w1s), dw1_w, dw1_b, reinterpret_cast<const float*>(w2s),
+                        dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, sched, B, C, T, pre_scale, out_scale, stream);
 }
 
 #ifdef HILC_DEBUG_STAMPS

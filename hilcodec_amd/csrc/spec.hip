@@ -115,7 +115,7 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ wt, f32x16
         if (more && n % LD_EVERY == 0) load_word((gptr_t)wn, nxt, n / LD_EVERY);
         // asm, not the builtin: see resblock.hip (hipcc sinks builtin MFMAs below all operand loads of the phase)
         if (s == 0 && j == 0)
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
         else
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
       }

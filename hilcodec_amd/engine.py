@@ -32,15 +32,18 @@ FUSE_RESBLOCK_MAX_C = 192
 # on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32 accumulation).  The
 # encoder and the RVQ — hence every index — are never touched.  Default "fp32" = the reference's arithmetic.
 DECODER_GEMM = "fp32"
-X3_FUSED_BLOCK_MIN_C = 10 ** 9   # residual blocks of at least this width leave the fused fp32 kernel for two bf16x3 launches
+X3_FUSED_BLOCK_MIN_C = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
+X3_FUSED_BLOCKS = True            # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
 _X3_SPLIT = {}            # id(weight tensor) -> (weak reference, version, split form); built on first use, dies with the weight
 
 
-def _x3(wt: Tensor) -> Tensor:
-    key = id(wt)
+def _x3(wt: Tensor, pack=None) -> Tensor:
+    """split form of a k-major weight matrix (`pack` = ops.resblock_x3_pack for the fused block's lane-ordered layout)"""
+    pack = pack or ops.x3_split
+    key = (id(wt), pack.__name__)
     hit = _X3_SPLIT.get(key)
     if hit is None or hit[0]() is not wt or hit[1] != wt._version:      # new tensor at a recycled id, or weights updated in place
-        hit = (weakref.ref(wt, lambda _, k=key: _X3_SPLIT.pop(k, None)), wt._version, ops.x3_split(wt))
+        hit = (weakref.ref(wt, lambda _, k=key: _X3_SPLIT.pop(k, None)), wt._version, pack(wt))
         _X3_SPLIT[key] = hit
     return hit[2]
 
@@ -199,6 +202,9 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
             and (not _fusable(rb, x) or x.shape[1] >= X3_FUSED_BLOCK_MIN_C)):
         g = ops.dws_conv_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
         return ops.dws_conv_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
+    if (x3 and X3_FUSED_BLOCKS and caches is None and _fusable(rb, x) and ops.resblock_x3_supported(x.shape[1], x.shape[2])):
+        return ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
+                               _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)
     if caches is None and _fusable(rb, x):
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,

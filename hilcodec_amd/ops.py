@@ -228,6 +228,46 @@ _register("up_conv_x3", "(Tensor x, Tensor tr_w, Tensor? taps, Tensor wsplit, Te
           x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2] * stride))
 
 
+def _resblock_x3_pack(wt):
+    Cc = wt.shape[0]
+    out = _new(wt, Cc * Cc)                       # C*C*4 bytes: bf16 heads and remainders in MFMA lane order
+    check(lib.hilc_resblock_pack_weights_x3(_ptr(wt), _ptr(out), Cc, _stream()), "hilc_resblock_pack_weights_x3")
+    return out
+
+
+_register("resblock_x3_pack", "(Tensor wt) -> Tensor", _resblock_x3_pack, lambda wt: wt.new_empty(wt.shape[0] * wt.shape[0]))
+
+
+def _resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, pre_scale, out_scale):
+    B, Cc, T = x.shape
+    y = torch.empty_like(x)
+    with _timed("resblock_x3", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} bf16x3"):
+        check(lib.hilc_resblock_x3(_ptr(x), _ptr(w1s), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2s), _ptr(dw2_w), _ptr(dw2_b), _ptr(y),
+                                   _ptr(_sched_buffer(x.device), torch.int32), B, Cc, T, pre_scale, out_scale, _stream()),
+              "hilc_resblock_x3")
+    return y
+
+
+_register("resblock_x3", "(Tensor x, Tensor w1s, Tensor dw1_w, Tensor dw1_b, Tensor w2s, Tensor dw2_w, Tensor dw2_b, "
+          "float pre_scale, float out_scale) -> Tensor", _resblock_x3,
+          lambda x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, pre_scale, out_scale: torch.empty_like(x))
+
+
+def resblock_x3_supported(C: int, T: int) -> bool:
+    return C in (96, 192) and T % 4 == 0
+
+
+def resblock_x3_pack(wt: Tensor) -> Tensor:
+    """k-major `[C,C]` pointwise weights -> the split, lane-ordered form of hilc_resblock_x3"""
+    return _OPS.resblock_x3_pack(wt)
+
+
+def resblock_x3(x: Tensor, w1s: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2s: Tensor, dw2_w: Tensor, dw2_b: Tensor,
+                pre_scale: float, out_scale: float) -> Tensor:
+    """`resblock` (offline) with its two GEMM phases in the EXPERIMENTAL bf16x3 mode (hilc_resblock_x3)"""
+    return _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, float(pre_scale), float(out_scale))
+
+
 def x3_supported(K: int, M: int, T: int) -> bool:
     """mirror of hilc_x3_supported"""
     return K % 32 == 0 and M % 8 == 0 and T % 4 == 0

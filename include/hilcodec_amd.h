@@ -124,6 +124,14 @@ int hilc_dws_conv_x3(const float* x, const void* wsplit, const float* dw_w, cons
                      int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
 int hilc_up_conv_x3(const float* x, const float* tr_w, const float* tr_w_expanded, const void* wsplit, const float* bias,
                     float* y, int B, int K, int M, int Tin, int stride, float in_scale, void* stream);
+/* hilc_resblock_x3: hilc_resblock_balanced (offline) with the two GEMM phases in the same split-operand arithmetic; the
+ * tile in LDS and the depthwise / ELU phases stay fp32.  C = 96 or 192 (the decoder's narrow widths).  w1s / w2s = the
+ * k-major `[C][C]` matrices packed by hilc_resblock_pack_weights_x3 (C*C*4 bytes: bf16 head and remainder in MFMA lane
+ * order). */
+int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int C, void* stream);
+int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
+                     const float* dw2_w, const float* dw2_b, float* y, int* sched, int B, int C, int T, float pre_scale,
+                     float out_scale, void* stream);
 
 /* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv
  * takes) into "MFMA lane order": the operands one lane feeds to the matrix pipe for a 16-deep K slice become

@@ -66,6 +66,26 @@ def test_up_conv_x3_vs_fp32(K, M, Tin, r, B):
     assert 0.0 < err <= 4e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("C,Tn,B", [(96, 1000, 2), (192, 600, 2), (96, 120, 1), (192, 124, 3)])
+def test_fused_resblock_x3_vs_fp32(C, Tn, B):
+    """the fused residual block with bf16x3 GEMM phases against the same block in fp32 (same kernel, same LDS tile, same
+    depthwise / ELU phases; only the two matrix products change)"""
+    from hilcodec_amd import ops, fold
+    x = rnd(C + Tn, B, C, Tn).to(DEV)
+    w1 = fold.pointwise_layout(rnd(C, C, C, 1) / C ** 0.5).to(DEV)
+    w2 = fold.pointwise_layout(rnd(C + 1, C, C, 1) / C ** 0.5).to(DEV)
+    d1, b1 = (rnd(3, C, 5) * 0.4).to(DEV), (rnd(4, C) * 0.2).to(DEV)
+    d2, b2 = (rnd(5, C, 5) * 0.4).to(DEV), (rnd(6, C) * 0.2).to(DEV)
+    ref = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
+    y = ops.resblock_x3(x, ops.resblock_x3_pack(w1), d1, b1, ops.resblock_x3_pack(w2), d2, b2, 0.9, 0.5)
+    err = (y - ref).abs().max().item()
+    assert 0.0 < err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+    assert ops.resblock_x3_supported(96, 120) and not ops.resblock_x3_supported(64, 120)
+    with pytest.raises(RuntimeError):
+        ops.resblock_x3(x[:, :64].contiguous(), ops.resblock_pack(w1[:64, :64].contiguous()), d1[:64], b1[:64],
+                        ops.resblock_pack(w2[:64, :64].contiguous()), d2[:64], b2[:64], 0.9, 0.5)     # C = 64: no such kernel
+
+
 @pytest.mark.parametrize("name", ["hil_speech", "hil_music"])
 def test_decoder_in_bf16x3_mode(golden, name):
     import hilcodec_amd
