@@ -207,10 +207,18 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
         // inline asm, not the builtin: the pure intrinsic is free to move at IR level and hipcc sinks a whole GEMM
         // phase's MFMAs below all of its operand loads (every operand then spills); a volatile asm keeps its place
         // among the loads.  D == C (same registers): back-to-back accumulation needs no software wait states.
+#ifndef HILC_RES_ASM_MFMA        // builtin MFMAs, pinned per register set (below); HILC_RES_ASM_MFMA = the former asm form, for A/B
+        if (s == 0 && j == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
+#else
         if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
         else
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
+#endif
       }
     }
     if (more) {
@@ -218,7 +226,19 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
       wn += WPS * 256;
       asm volatile("" : "+v"(xn), "+s"(wn));
     }
+#ifndef HILC_RES_ASM_MFMA
+    // pin the set: an empty asm that "updates" the accumulators and clobbers memory keeps this set's MFMAs above it and
+    // the later sets' loads below it.  The builtins are pure, and left alone hipcc sinks a whole phase's MFMAs under all of
+    // its operand loads (~300 spilled registers); pinned, they schedule as written, need fewer registers than the asm form
+    // (C = 192: 202 instead of 219) and — unlike asm — carry their hazard information: the bf16x3 phases, first written
+    // with asm MFMAs fed by VALU conversions, produced rare garbage tiles that no manual wait state fixed.
+#pragma unroll
+    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
+#endif
   }
+#ifndef HILC_RES_ASM_MFMA
+  return;
+#endif
   // the accumulators are read next by non-MFMA instructions (ds_write after a barrier): the compiler cannot see
   // into the asm, so the 16-pass MFMA -> VALU/DS read hazard (18 wait states) is covered by hand
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
