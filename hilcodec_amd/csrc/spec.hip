@@ -113,19 +113,22 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ wt, f32x16
       for (int i = 0; i < CB; ++i) {
         const int n = j * CB + i;
         if (more && n % LD_EVERY == 0) load_word((gptr_t)wn, nxt, n / LD_EVERY);
-        // asm, not the builtin: see resblock.hip (hipcc sinks builtin MFMAs below all operand loads of the phase)
-        if (s == 0 && j == 0)
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
-        else
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[cur][j][i]), "v"(b[cur][j]));
+        // builtin MFMAs pinned per register set (see resblock.hip: the pure builtins would otherwise be sunk under the
+        // phase's later loads; asm MFMAs hide their hazards from the compiler)
+        if (s == 0 && j == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
       }
     }
     if (more) {
       wn += WPS * 256;
       asm volatile("" : "+s"(wn));
     }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
   }
-  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read hazard (the compiler cannot see into the asm)
 }
 
 __device__ __forceinline__ int padded(int u) { return u + (u >> 4); }
