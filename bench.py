@@ -136,6 +136,7 @@ def cpu_baseline(name, mk, sd, clips: int, samples: int):
     z_o, idx_o, wav_o, dt, threads = census.oracle_clips(name, sd, mk, x, chunk=8, threads=ncpu)
     runs = {threads: (clips * clip_s / dt, f"{clips} clips in chunks of 8, {dt:.2f} s wall")}
     for th, n in ((1, 2), (8, 8), (16, 16)):
+        n = min(n, clips)
         if th < ncpu:
             _, _, _, dtt, _ = census.oracle_clips(name, sd, mk, x[:n], chunk=min(n, 8), threads=th)
             runs[th] = (n * clip_s / dtt, f"{n} clips in chunks of {min(n, 8)}, {dtt:.2f} s wall")
