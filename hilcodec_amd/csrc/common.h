@@ -29,7 +29,7 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
 // itself; for x <= 0, e^x - 1 >= x.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1, i.e. one fp32 ulp
 // of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on a dense grid) — relative accuracy
 // near 0- is given up, which a following dot product cannot see.  Justified by data, not taste: the full-size parity
-// census (profiles/r02_parity_census.json) finds 0 index flips in 67 200 argmins with this form AND with expm1f.
+// census (profiles/r02_parity_census_final.json) finds 0 index flips in 67 200 argmins with this form AND with expm1f.
 // (max instead of compare + select: in the VALU-bound phases every instruction is ~2.8 cycles of the pipe the fp32
 // MFMAs need, profiles/r02_mfma_shadow_microbench.txt.)
 __device__ __forceinline__ float elu_fast(float x) {
