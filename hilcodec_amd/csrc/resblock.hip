@@ -204,9 +204,10 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
       for (int i = 0; i < CBW; ++i) {
         const int n = j * CBW + i;                   // MFMA index inside the set
         if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        // inline asm, not the builtin: the pure intrinsic is free to move at IR level and hipcc sinks a whole GEMM
-        // phase's MFMAs below all of its operand loads (every operand then spills); a volatile asm keeps its place
-        // among the loads.  D == C (same registers): back-to-back accumulation needs no software wait states.
+        // The pure MFMA intrinsic is free to move at IR level and hipcc sinks a whole GEMM phase's MFMAs below all of
+        // its operand loads (every operand then spills).  Default: builtins pinned per register set (end of this loop);
+        // -DHILC_RES_ASM_MFMA: the former form, a volatile asm per MFMA (keeps its place among the loads, but hides the
+        // instruction's hazards from the compiler).
 #ifndef HILC_RES_ASM_MFMA        // builtin MFMAs, pinned per register set (below); HILC_RES_ASM_MFMA = the former asm form, for A/B
         if (s == 0 && j == 0) {
 #pragma unroll
