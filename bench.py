@@ -230,16 +230,29 @@ def main():
 
     numerics = None
     if args.decoder_gemm != "fp32":
-        if args.mode != "offline":
-            raise SystemExit("--decoder-gemm applies to --mode offline")
         from hilcodec_amd import engine
-        with torch.no_grad():
-            idx_f, wav_f = step(0)                          # the fp32 product path on the same inputs, outside the timed region
-            engine.DECODER_GEMM = args.decoder_gemm
-            if args.x3_blocks_from > 0:
-                engine.X3_FUSED_BLOCK_MIN_C = args.x3_blocks_from
-            idx_x, wav_x = step(0)
-        numerics = {"mode": args.decoder_gemm, "scope": "offline decoder: up-sampling and depthwise-separable GEMMs, GEMM phases of the fused residual blocks"
+        if args.mode == "offline":
+            with torch.no_grad():
+                idx_f, wav_f = step(0)                      # the fp32 product path on the same inputs, outside the timed region
+                engine.DECODER_GEMM = args.decoder_gemm
+                if args.x3_blocks_from > 0:
+                    engine.X3_FUSED_BLOCK_MIN_C = args.x3_blocks_from
+                idx_x, wav_x = step(0)
+        else:
+            # streaming: one hop from zero caches in both arithmetics (eager, outside the timed region and the state blocks)
+            with torch.no_grad():
+                ce, cd = model.initialize_cache(xs[0])
+                def one_hop():
+                    z, _ = model.encoder(xs[0], *ce)
+                    i_ = model.quantizer(z, nq)
+                    w_, _ = model.decoder(model.dequantizer(i_, nq), *cd)
+                    return i_, w_
+                idx_f, wav_f = one_hop()
+                engine.DECODER_GEMM = args.decoder_gemm
+                idx_x, wav_x = one_hop()
+            if args.graph:                                   # the graphs were captured in fp32: capture again in the new mode
+                hopper = type(hopper)(model, hi - lo, hop, nq, dev)
+        numerics = {"mode": args.decoder_gemm, "scope": args.mode + " decoder: up-sampling and depthwise-separable GEMMs, GEMM phases of the fused residual blocks"
                     + (f", residual blocks of width >= {args.x3_blocks_from}" if args.x3_blocks_from > 0 else "")
                     + "; encoder and RVQ exact fp32",
                     "indices_equal_to_fp32_path": bool(torch.equal(idx_f, idx_x)),

@@ -32,9 +32,10 @@ SIGNATURES = {
     "hilc_x3_supported": [_i, _i, _i],
     "hilc_x3_split_weights": [_p, _p, _i, _i, _p],
     "hilc_dws_conv_x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
-    "hilc_up_conv_x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "hilc_up_conv_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "hilc_dws_conv_stream_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_resblock_pack_weights_x3": [_p, _p, _i, _p],
-    "hilc_resblock_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
+    "hilc_resblock_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "hilc_up_conv_expanded": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -60,7 +61,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HilcodecLibraryError(RuntimeError):

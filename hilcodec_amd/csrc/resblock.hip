@@ -792,6 +792,13 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
   if (streaming) {
     if ((hist1 && hist1 == hist1_out) || (hist2 && hist2 == hist2_out)) return HILC_ERR_UNSUPPORTED;   // first / last tiles of a clip race
     if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
+    if (x3) {
+      switch (C) {
+        case 96: return launch_res<96, true, true>(a, B, (hipStream_t)stream);
+        case 192: return launch_res<192, true, true>(a, B, (hipStream_t)stream);
+        default: return HILC_ERR_UNSUPPORTED;
+      }
+    }
     switch (C) {
       case 64: return launch_res<64, true>(a, B, (hipStream_t)stream);
       case 96: return launch_res<96, true>(a, B, (hipStream_t)stream);
@@ -800,7 +807,7 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
-  if (x3) {            // EXPERIMENTAL bf16x3 GEMM phases: the decoder's widths only
+  if (x3 && !streaming) {            // EXPERIMENTAL bf16x3 GEMM phases: the decoder's widths only
     switch (C) {
       case 96: return launch_res<96, false, true>(a, B, (hipStream_t)stream);
       case 192: return launch_res<192, false, true>(a, B, (hipStream_t)stream);
@@ -867,10 +874,12 @@ extern "C" int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int 
 }
 
 extern "C" int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
-                                const float* dw2_w, const float* dw2_b, float* y, int* sched, int B, int C, int T,
+                                const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
+                                float* hist1_out, float* hist2_out, float* y, int* sched, int streaming, int B, int C, int T,
                                 float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(false, true, x, reinterpret_cast<const float*>(w1s), dw1_w, dw1_b, reinterpret_cast<const float*>(w2s),
-                        dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, sched, B, C, T, pre_scale, out_scale, stream);
+  return resblock_entry(streaming != 0, true, x, reinterpret_cast<const float*>(w1s), dw1_w, dw1_b,
+                        reinterpret_cast<const float*>(w2s), dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, sched, B, C, T,
+                        pre_scale, out_scale, stream);
 }
 
 #ifdef HILC_DEBUG_STAMPS

@@ -28,7 +28,8 @@ FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside
 FUSE_RESBLOCK = True
 FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
-# EXPERIMENTAL, opt-in: "bf16x3" runs the GEMMs of the OFFLINE DECODER's wide depthwise-separable and up-sampling layers
+# EXPERIMENTAL, opt-in: "bf16x3" runs the GEMMs of the DECODER (offline and streaming: up-sampling, wide depthwise-separable
+# layers, the GEMM phases of the fused residual blocks)
 # on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32 accumulation).  The
 # encoder and the RVQ — hence every index — are never touched.  Default "fp32" = the reference's arithmetic.
 DECODER_GEMM = "fp32"
@@ -209,11 +210,27 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
+    if (x3 and X3_FUSED_BLOCKS and caches is not None and x.shape[2] >= 4 and _fusable(rb, x)
+            and ops.resblock_x3_supported(x.shape[1], x.shape[2])):
+        y, cs = ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
+                                _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale,
+                                hist=(caches[0], caches[1]), hist_out=outs)
+        new_caches.extend(cs)
+        return y
     if caches is not None and x.shape[2] >= 4 and _fusable(rb, x):
         # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns
         y, cs = ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                              rb.pre_scale, rb.out_scale, hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
+        return y
+    if (x3 and caches is not None and FUSE_STREAM
+            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw1_w.shape[1], 1)
+            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw2_w.shape[1], 1)):
+        g, c0 = ops.dws_conv_stream_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, caches[0], in_scale=rb.pre_scale, in_elu=True,
+                                       out_elu=True, hist_out=o0)
+        y, c1 = ops.dws_conv_stream_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, caches[1], res=x, out_scale=rb.out_scale,
+                                       hist_out=o1)
+        new_caches.extend([c0, c1])
         return y
     if (caches is not None and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], rb.dw1_w.shape[1], 1)
             and ops.dws_conv_stream_profitable(x.shape[2], rb.dw2_w.shape[1], 1)):
@@ -374,7 +391,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         raise RuntimeError(f"engine.DECODER_GEMM must be 'fp32' or 'bf16x3', got {DECODER_GEMM!r}")
     if DECODER_GEMM != "fp32" and torch.compiler.is_compiling():
         raise RuntimeError("engine.DECODER_GEMM = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
-    x3 = DECODER_GEMM == "bf16x3" and not streaming
+    x3 = DECODER_GEMM == "bf16x3"
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
@@ -391,7 +408,12 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     ci = 1
     for st in ds.stages:
         fused_up = FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0
-        if streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
+        if (streaming and FUSE_STREAM and x3 and (x.shape[2] * st.ratio) % 4 == 0
+                and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio)):
+            x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
+                                  hist=caches[ci], want_hist=True, hist_out=out(ci))
+            new_caches.append(c)
+        elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
             x, c = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True,
                                hist=caches[ci], want_hist=True, taps=st.taps, hist_out=out(ci))
             new_caches.append(c)

@@ -213,19 +213,44 @@ _register("dws_conv_x3", "(Tensor x, Tensor wsplit, Tensor dw_w, Tensor? dw_b, T
           x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2]))
 
 
-def _up_conv_x3(x, tr_w, taps, wsplit, bias, stride, in_scale):
+def _up_conv_x3(x, hist, hist_out, tr_w, taps, wsplit, bias, stride, in_scale):
     B, K, Tin = x.shape
     M = wsplit.shape[2]
+    for h in (hist, hist_out):
+        if h is not None and h.numel() != B * K:
+            raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(h.shape)}")
     y = _new(x, B, M, Tin * stride)
-    with _timed("up_conv_x3", 2.0 * B * Tin * stride * K * M, f"K{K} M{M} Tin{Tin} r{stride} bf16x3"):
-        check(lib.hilc_up_conv_x3(_ptr(x), _ptr(tr_w), _ptr(taps), _ptr(wsplit, torch.int16), _ptr(bias), _ptr(y), B, K, M,
-                                  Tin, stride, in_scale, _stream()), "hilc_up_conv_x3")
+    with _timed("up_conv_x3", 2.0 * B * Tin * stride * K * M,
+                f"K{K} M{M} Tin{Tin} r{stride} bf16x3" + (" stream" if hist is not None or hist_out is not None else "")):
+        check(lib.hilc_up_conv_x3(_ptr(x), _ptr(hist), _ptr(hist_out), _ptr(tr_w), _ptr(taps), _ptr(wsplit, torch.int16),
+                                  _ptr(bias), _ptr(y), B, K, M, Tin, stride, in_scale, _stream()), "hilc_up_conv_x3")
     return y
 
 
-_register("up_conv_x3", "(Tensor x, Tensor tr_w, Tensor? taps, Tensor wsplit, Tensor? bias, int stride, float in_scale) -> Tensor",
-          _up_conv_x3, lambda x, tr_w, taps, wsplit, bias, stride, in_scale:
+_register("up_conv_x3", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor tr_w, Tensor? taps, Tensor wsplit, Tensor? bias, "
+          "int stride, float in_scale) -> Tensor", _up_conv_x3,
+          lambda x, hist, hist_out, tr_w, taps, wsplit, bias, stride, in_scale:
           x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2] * stride))
+
+
+def _dws_conv_stream_x3(x, wsplit, dw_w, dw_b, hist, hist_out, res, in_scale, in_elu, out_scale, out_elu):
+    B, K, T = x.shape
+    M = wsplit.shape[2]
+    for h in (hist, hist_out):
+        if h is not None and tuple(h.shape) != (B, M, 4):
+            raise RuntimeError(f"cache must be [{B},{M},4], got {tuple(h.shape)}")
+    y = _new(x, B, M, T)
+    with _timed("dws_conv_x3", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k5 s1 bf16x3 stream"):
+        check(lib.hilc_dws_conv_stream_x3(_ptr(x), _ptr(wsplit, torch.int16), _ptr(dw_w), _ptr(dw_b), _ptr(hist),
+                                          _ptr(hist_out), _ptr(res), _ptr(y), B, K, M, T, in_scale, int(in_elu), out_scale,
+                                          int(out_elu), _stream()), "hilc_dws_conv_stream_x3")
+    return y
+
+
+_register("dws_conv_stream_x3", "(Tensor x, Tensor wsplit, Tensor dw_w, Tensor? dw_b, Tensor? hist, Tensor(a!) hist_out, "
+          "Tensor? res, float in_scale, bool in_elu, float out_scale, bool out_elu) -> Tensor", _dws_conv_stream_x3,
+          lambda x, wsplit, dw_w, dw_b, hist, hist_out, res, in_scale, in_elu, out_scale, out_elu:
+          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2]))
 
 
 def _resblock_x3_pack(wt):
@@ -238,19 +263,26 @@ def _resblock_x3_pack(wt):
 _register("resblock_x3_pack", "(Tensor wt) -> Tensor", _resblock_x3_pack, lambda wt: wt.new_empty(wt.shape[0] * wt.shape[0]))
 
 
-def _resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, pre_scale, out_scale):
+def _resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale):
     B, Cc, T = x.shape
+    streaming = hist1_out is not None or hist1 is not None
+    for h in (hist1, hist2, hist1_out, hist2_out):
+        if h is not None and tuple(h.shape) != (B, Cc, 4):
+            raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h.shape)}")
     y = torch.empty_like(x)
-    with _timed("resblock_x3", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} bf16x3"):
-        check(lib.hilc_resblock_x3(_ptr(x), _ptr(w1s), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2s), _ptr(dw2_w), _ptr(dw2_b), _ptr(y),
-                                   _ptr(_sched_buffer(x.device), torch.int32), B, Cc, T, pre_scale, out_scale, _stream()),
-              "hilc_resblock_x3")
+    with _timed("resblock_x3", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} bf16x3" + (" stream" if streaming else "")):
+        check(lib.hilc_resblock_x3(_ptr(x), _ptr(w1s), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2s), _ptr(dw2_w), _ptr(dw2_b),
+                                   _ptr(hist1), _ptr(hist2), _ptr(hist1_out), _ptr(hist2_out), _ptr(y),
+                                   _ptr(_sched_buffer(x.device), torch.int32), int(streaming), B, Cc, T, pre_scale, out_scale,
+                                   _stream()), "hilc_resblock_x3")
     return y
 
 
 _register("resblock_x3", "(Tensor x, Tensor w1s, Tensor dw1_w, Tensor dw1_b, Tensor w2s, Tensor dw2_w, Tensor dw2_b, "
-          "float pre_scale, float out_scale) -> Tensor", _resblock_x3,
-          lambda x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, pre_scale, out_scale: torch.empty_like(x))
+          "Tensor? hist1, Tensor? hist2, Tensor(a!)? hist1_out, Tensor(b!)? hist2_out, float pre_scale, float out_scale) -> Tensor",
+          _resblock_x3,
+          lambda x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale:
+          torch.empty_like(x))
 
 
 def resblock_x3_supported(C: int, T: int) -> bool:
@@ -263,9 +295,17 @@ def resblock_x3_pack(wt: Tensor) -> Tensor:
 
 
 def resblock_x3(x: Tensor, w1s: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2s: Tensor, dw2_w: Tensor, dw2_b: Tensor,
-                pre_scale: float, out_scale: float) -> Tensor:
-    """`resblock` (offline) with its two GEMM phases in the EXPERIMENTAL bf16x3 mode (hilc_resblock_x3)"""
-    return _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, float(pre_scale), float(out_scale))
+                pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None,
+                hist_out: Optional[Sequence[Tensor]] = None):
+    """`resblock` (offline, or a streaming hop with its two caches) with its two GEMM phases in the EXPERIMENTAL bf16x3 mode"""
+    if hist is None:
+        return _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, None, None, None, None, float(pre_scale),
+                                float(out_scale))
+    B, Cc, _ = x.shape
+    o1 = _state_out(hist_out[0] if hist_out is not None else None, x, B, Cc, 4)
+    o2 = _state_out(hist_out[1] if hist_out is not None else None, x, B, Cc, 4)
+    y = _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist[0], hist[1], o1, o2, float(pre_scale), float(out_scale))
+    return y, [o1, o2]
 
 
 def x3_supported(K: int, M: int, T: int) -> bool:
@@ -285,11 +325,29 @@ def dws_conv_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor],
 
 
 def up_conv_x3(x: Tensor, tr_w: Tensor, wsplit: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
-               taps: Optional[Tensor] = None) -> Tensor:
-    """`up_conv` (ELU prologue, no cache) with the pointwise GEMM in the EXPERIMENTAL bf16x3 mode (hilc_up_conv_x3)"""
+               taps: Optional[Tensor] = None, hist: Optional[Tensor] = None, want_hist: bool = False,
+               hist_out: Optional[Tensor] = None):
+    """`up_conv` (ELU prologue; streaming: the transposed conv's one-frame cache -> (y, new cache)) with the pointwise GEMM
+    in the EXPERIMENTAL bf16x3 mode (hilc_up_conv_x3)"""
     if taps is None and stride not in (2, 4, 8):
         taps = up_conv_taps(tr_w, stride)
-    return _OPS.up_conv_x3(x, tr_w, taps, wsplit, bias, int(stride), float(in_scale))
+    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], 1) if want_hist else None
+    y = _OPS.up_conv_x3(x, hist, hout, tr_w, taps, wsplit, bias, int(stride), float(in_scale))
+    return (y, hout) if want_hist else y
+
+
+def dws_conv_stream_x3_supported(K: int, M: int, T: int, k: int, stride: int) -> bool:
+    return k == 5 and stride == 1 and T <= 128 and T % 4 == 0 and x3_supported(K, M, T)
+
+
+def dws_conv_stream_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
+                       res: Optional[Tensor] = None, in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0,
+                       out_elu: bool = False, hist_out: Optional[Tensor] = None):
+    """streaming hop of a wide k5 / stride-1 depthwise-separable layer in the EXPERIMENTAL bf16x3 mode -> (y, new cache)"""
+    hout = _state_out(hist_out, x, x.shape[0], wsplit.shape[2], 4)
+    y = _OPS.dws_conv_stream_x3(x, wsplit, dw_w, dw_b, hist, hout, res, float(in_scale), bool(in_elu), float(out_scale),
+                                bool(out_elu))
+    return y, hout
 
 
 def _resblock_pack(wt):

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 6   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental) */
+#define HILC_ABI_VERSION 7   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -116,21 +116,28 @@ int hilc_resblock_supported(int C, int T);
  * product calls these entry points only when the caller asks for it (hilcodec_amd.engine.DECODER_GEMM = "bf16x3"),
  * and only for decoder layers, so the encoder, the RVQ and therefore every index stay exact fp32.
  * hilc_x3_split_weights: k-major fp32 `[K][M]` -> `wsplit` = `[2][K][M]` bf16 (head, head of the remainder).
- * hilc_dws_conv_x3 / hilc_up_conv_x3: as hilc_dws_conv (ksize 5, stride 1) / hilc_up_conv_expanded (in_elu = 1, no cache)
+ * hilc_dws_conv_x3 / hilc_up_conv_x3: as hilc_dws_conv (ksize 5, stride 1) / hilc_up_conv_expanded (in_elu = 1)
  * with `wsplit` in place of `wt`; K % 32 == 0, M % 8 == 0, T % 4 == 0 (hilc_x3_supported), else HILC_ERR_UNSUPPORTED. */
 int hilc_x3_supported(int K, int M, int T);
 int hilc_x3_split_weights(const float* wt, void* wsplit, int K, int M, void* stream);
 int hilc_dws_conv_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* res, float* y,
                      int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
-int hilc_up_conv_x3(const float* x, const float* tr_w, const float* tr_w_expanded, const void* wsplit, const float* bias,
-                    float* y, int B, int K, int M, int Tin, int stride, float in_scale, void* stream);
-/* hilc_resblock_x3: hilc_resblock_balanced (offline) with the two GEMM phases in the same split-operand arithmetic; the
+int hilc_up_conv_x3(const float* x, const float* hist, float* hist_out, const float* tr_w, const float* tr_w_expanded,
+                    const void* wsplit, const float* bias, float* y, int B, int K, int M, int Tin, int stride, float in_scale,
+                    void* stream);
+/* streaming hop (hist / hist_out as in hilc_dws_conv_stream, T <= 128, ksize 5, stride 1; hilc_up_conv_x3 takes the
+ * transposed conv's one-frame cache like hilc_up_conv_stream) */
+int hilc_dws_conv_stream_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* hist,
+                            float* hist_out, const float* res, float* y, int B, int K, int M, int T, float in_scale,
+                            int in_elu, float out_scale, int out_elu, void* stream);
+/* hilc_resblock_x3: hilc_resblock_balanced (offline or streaming, same argument meaning) with the two GEMM phases in the same split-operand arithmetic; the
  * tile in LDS and the depthwise / ELU phases stay fp32.  C = 96 or 192 (the decoder's narrow widths).  w1s / w2s = the
  * k-major `[C][C]` matrices packed by hilc_resblock_pack_weights_x3 (C*C*4 bytes: bf16 head and remainder in MFMA lane
  * order). */
 int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int C, void* stream);
 int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
-                     const float* dw2_w, const float* dw2_b, float* y, int* sched, int B, int C, int T, float pre_scale,
+                     const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2, float* hist1_out,
+                     float* hist2_out, float* y, int* sched, int streaming, int B, int C, int T, float pre_scale,
                      float out_scale, void* stream);
 
 /* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv

@@ -62,6 +62,11 @@ def test_up_conv_x3_vs_fp32(K, M, Tin, r, B):
     b = (rnd(M, M) * 0.1).to(DEV)
     ref = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True)
     y = ops.up_conv_x3(x, tw, ops.x3_split(wt), b, r, in_scale=0.7071)
+    # streaming form: the frame before the hop from the cache, new cache = the activated last frame (as the fp32 op)
+    hist = torch.nn.functional.elu(rnd(9, B, K, 1)).to(DEV)
+    ref_s, c_ref = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=hist, want_hist=True)
+    y_s, c_x3 = ops.up_conv_x3(x, tw, ops.x3_split(wt), b, r, in_scale=0.7071, hist=hist, want_hist=True)
+    assert torch.equal(c_x3, c_ref) and (y_s - ref_s).abs().max().item() <= 4e-5 * max(1.0, ref_s.abs().max().item())
     err = (y - ref).abs().max().item()
     assert 0.0 < err <= 4e-5 * max(1.0, ref.abs().max().item()), err
 
@@ -124,3 +129,50 @@ def test_decoder_in_bf16x3_mode(golden, name):
             run()
     finally:
         engine.DECODER_GEMM = "fp32"
+
+
+@pytest.mark.parametrize("B,hop_frames", [(3, 1), (40, 1), (2, 3)])
+def test_streaming_decoder_in_bf16x3_mode(B, hop_frames):
+    """streaming hops with the decoder's GEMMs in bf16x3 (cache-carrying forms of the same kernels): indices identical (the
+    encoder and the RVQ are not touched), decoded audio and every decoder cache within 5e-5 of the fp32 hops over several
+    hops; the pipelined graph captured in this mode replays the eager bf16x3 hops bit for bit."""
+    from hilcodec_amd import engine
+    from hilcodec_amd.graph_step import PipelinedHop
+    from tests.test_gpu_streaming import build_streaming
+    model, mk, sd = build_streaming()
+    L, hops = 320 * hop_frames, 4
+    x = synth.synth_clips(B, L * hops, seed=31).to(DEV)
+
+    def run():
+        ce, cd = model.initialize_cache(x)
+        outs = []
+        with torch.no_grad():
+            for h in range(hops):
+                z, ce = model.encoder(x[:, :, L * h: L * (h + 1)].contiguous(), *ce)
+                idx = model.quantizer(z, 8)
+                wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+                outs.append((idx.clone(), wav.clone()))
+        return outs, [c.clone() for c in cd]
+
+    ref, cd_ref = run()
+    engine.DECODER_GEMM = "bf16x3"
+    try:
+        got, cd_got = run()
+        for h in range(hops):
+            assert torch.equal(got[h][0], ref[h][0])
+            d = (got[h][1] - ref[h][1]).abs().max().item()
+            assert 0.0 < d < 5e-5, (h, d)
+        for a, b in zip(cd_got, cd_ref):
+            assert (a - b).abs().max().item() <= 5e-5 * max(1.0, b.abs().max().item())
+        if hop_frames == 1:
+            g = PipelinedHop(model, B, 320, 8, DEV)
+            for h in range(hops):
+                idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])
+                assert torch.equal(idx, got[h][0])
+                if h > 0:
+                    assert torch.equal(wav, got[h - 1][1])
+            assert torch.equal(g.flush(), got[hops - 1][1])
+    finally:
+        engine.DECODER_GEMM = "fp32"
+    again, _ = run()
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(again, ref))
