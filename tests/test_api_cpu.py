@@ -202,3 +202,33 @@ def test_scalar_n_accepts_any_integer_like():
         ops.per_clip_n([1, 9], 2, 8, torch.device("cpu"))
     with pytest.raises(RuntimeError):
         ops.per_clip_n([1, 2], 3, 8, torch.device("cpu"))
+
+
+def test_x3_weight_cache_follows_the_weight(monkeypatch):
+    """engine._x3 (EXPERIMENTAL bf16x3 mode): the split form of a weight matrix is built once per tensor and version, is
+    rebuilt after an in-place update, is keyed by the layout that was asked for, and dies with the weight (no leak when
+    models are re-created)."""
+    import gc
+    from hilcodec_amd import engine
+    calls = []
+
+    def split(w):
+        calls.append(("split", w._version))
+        return w.clone()
+
+    def pack(w):
+        calls.append(("pack", w._version))
+        return w.clone()
+
+    engine._X3_SPLIT.clear()
+    w = torch.zeros(4, 4)
+    a = engine._x3(w, split)
+    assert engine._x3(w, split) is a and len(calls) == 1
+    b = engine._x3(w, pack)
+    assert b is not a and len(calls) == 2 and len(engine._X3_SPLIT) == 2
+    w.add_(1.0)
+    assert engine._x3(w, split) is not a and len(calls) == 3
+    del w
+    gc.collect()
+    assert len(engine._X3_SPLIT) == 0
+    assert engine.DECODER_GEMM == "fp32"            # the default arithmetic is the reference's
