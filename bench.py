@@ -9,9 +9,15 @@ inputs resident in HBM.  Metric = audio-seconds processed per wall second (xRT),
 shard embarrassingly: rank r processes clips [r*256, (r+1)*256) (weak scaling); the only collective
 is an all_gather of per-rank counters over RCCL after the timed region.
 
-Other workloads (parity-test configs, not the headline line): `--model hil_music` (configs[2]),
-`--mode streaming` (configs[3]: 1024 concurrent streams per GPU, one 320-sample hop per step, the 52
-cache tensors of every stream resident in HBM).
+Other workloads: `--model hil_music` (configs[2]), `--mode streaming` (configs[3]: 1024 concurrent
+streams per GPU, one 320-sample hop per step, the 52 cache tensors of every stream resident in HBM).
+The DEFAULT invocation also times short runs of configs[2] and configs[3] after the headline region and
+reports them under `other_configs` of the same JSON line (they are never part of `value`).
+
+Multi-GPU on one GPU: `--force-dist` initialises the RCCL process group even at world size 1 (so that
+`init_process_group("nccl", device_id=...)`, the barriers and the counters all_gather really execute);
+`--emulate-rank r --emulate-world W` runs rank r's shard of the W-GPU job (e.g. configs[4]: hil_music,
+2048 clips over 8 GPUs) in a single process — a shard check, not a scaling measurement.
 
 Prints ONE JSON line (rank 0) with
   roofline     — dominant kernel = the fp32-MFMA GEMM core (pointwise convs and everything fused
@@ -19,7 +25,8 @@ Prints ONE JSON line (rank 0) with
                  region; achieved = algorithmic FLOPs / summed launch time; peak 157.3 TFLOP/s.
   cpu_baseline — the CPU oracle (restatement of the reference in plain torch fp32 ops, bit-identical
                  to the reference, tests/test_oracle_vs_reference.py) timed on this box's host cores
-                 over a bounded sample of the same workload."""
+                 over a bounded sample of the same workload (1 warm-up + 3 timed passes per thread
+                 setting, median)."""
 from __future__ import annotations
 
 import argparse
@@ -44,26 +51,38 @@ def parse():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--model", default=None, choices=["hil_speech", "hil_music"],
-                    help="default: hil_speech (BASELINE configs[1]); with --gpus 8: hil_music (configs[4], 2048 clips over 8 GPUs)")
+                    help="default: hil_speech (BASELINE configs[1]); with --gpus 8 / --emulate-world 8: hil_music (configs[4], 2048 clips over 8 GPUs)")
     ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
     ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
     ap.add_argument("--decoder-gemm", default="fp32", choices=["fp32", "bf16x3"],
-                    help="EXPERIMENTAL, offline only: run the decoder's wide GEMMs in the bf16 split-operand mode "
+                    help="EXPERIMENTAL: run the decoder's wide GEMMs in the bf16 split-operand mode "
                          "(csrc/gemm_x3.h).  A separately labelled line; the headline is the fp32 default.")
     ap.add_argument("--x3-blocks-from", type=int, default=0, help="with --decoder-gemm bf16x3: residual blocks of at least "
                     "this width leave the fused fp32 kernel for two bf16x3 launches (0 = keep the fused kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2.5 s sustained clock / power sample")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the short configs[2] / configs[3] lines")
+    ap.add_argument("--other-configs", action="store_true", help="add the short configs[2] / configs[3] lines to a non-default offline "
+                    "invocation too (sizes follow --batch: that many clips, four times as many streams)")
     ap.add_argument("--pipeline", action="store_true", help="with --graph: two-stage software pipeline over hops "
                     "(decoder of hop i-1 beside the encoder of hop i on a second HIP stream; +1 hop output latency)")
     ap.add_argument("--graph", action="store_true", help="streaming mode: replay each hop as one HIP graph "
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
-    ap.add_argument("--cpu-clips", type=int, default=16)
+    ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="with --emulate-world W: run rank r's shard of the W-GPU job in this one process")
+    ap.add_argument("--emulate-world", type=int, default=None)
     a = ap.parse_args()
+    a.is_default = (a.model is None and a.mode == "offline" and a.batch is None and a.samples == 24000 and a.gpus == 1
+                    and a.decoder_gemm == "fp32" and a.emulate_world is None)
+    if (a.emulate_rank is None) != (a.emulate_world is None):
+        ap.error("--emulate-rank and --emulate-world go together")
+    if a.emulate_world is not None and not 0 <= a.emulate_rank < a.emulate_world:
+        ap.error("--emulate-rank must be in [0, --emulate-world)")
     if a.model is None:
-        a.model = "hil_music" if (a.gpus == 8 and a.mode == "offline") else "hil_speech"
+        a.model = "hil_music" if ((a.gpus == 8 or a.emulate_world == 8) and a.mode == "offline") else "hil_speech"
     if a.mode == "offline":
         a.steps = 5 if a.steps is None else a.steps
         a.warmup = 2 if a.warmup is None else a.warmup
@@ -82,7 +101,6 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5):
     import shutil
     import subprocess
     import threading
-    import torch
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
@@ -123,30 +141,46 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5):
             "how": "rocm-smi medians over %.1f s of the same steps after the timed region" % seconds}
 
 
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(name, mk, sd, clips: int, samples: int):
     """The CPU oracle (= the reference's arithmetic) timed on this box's host cores over a bounded sample of the same
-    workload, at 1 thread, 8, 16 and all cores (torch's intra-op threading does not scale on this graph: the best
-    setting is reported as `value`, every setting under `by_threads`).  The oracle's outputs for the sample are
-    returned too: they double as the checker of the parity census below."""
+    workload: for N = 1 thread and N = all physical cores, one untimed warm-up pass (2 clips) and THREE timed
+    passes over the same `clips` clips; the MEDIAN pass is the setting's figure.  torch's intra-op threading does not
+    scale on this graph of small ops, so `value` is the better setting (named in `cores`), both are under `by_threads`.
+    The oracle's outputs for the sample are returned too: they double as the checker of the parity census below."""
     from hilcodec_amd import synth
     from tests import census                            # test infrastructure: the checker doubles as the timed CPU baseline
     x = synth.synth_clips(clips, samples, seed=1234)
-    ncpu = min(os.cpu_count() or 1, 64)
     clip_s = samples / 24000.0
-    z_o, idx_o, wav_o, dt, threads = census.oracle_clips(name, sd, mk, x, chunk=8, threads=ncpu)
-    runs = {threads: (clips * clip_s / dt, f"{clips} clips in chunks of 8, {dt:.2f} s wall")}
-    for th, n in ((1, 2), (8, 8), (16, 16)):
-        n = min(n, clips)
-        if th < ncpu:
-            _, _, _, dtt, _ = census.oracle_clips(name, sd, mk, x[:n], chunk=min(n, 8), threads=th)
-            runs[th] = (n * clip_s / dtt, f"{n} clips in chunks of {min(n, 8)}, {dtt:.2f} s wall")
-    torch.set_num_threads(ncpu)
-    best = max(runs, key=lambda t: runs[t][0])
-    base = {"value": runs[best][0], "unit": "audio-seconds/sec", "cores": best, "kind": "port",
-            "sample": f"{runs[best][1]}; {clip_s:g} s clips, {name}, fp32, torch CPU ops (oracle = the reference's arithmetic), "
-                      f"best of {sorted(runs)} threads on a {os.cpu_count()}-core host",
-            "by_threads": {str(t): {"value": v, "sample": smp} for t, (v, smp) in sorted(runs.items())}}
-    return base, (z_o, idx_o, wav_o)
+    phys = physical_cores()
+    runs, keep = {}, None
+    for th in sorted({1, phys}):
+        census.oracle_clips(name, sd, mk, x[:min(2, clips)], chunk=2, threads=th)           # warm-up (untimed)
+        times = []
+        for _ in range(3):
+            z_o, idx_o, wav_o, dt, _ = census.oracle_clips(name, sd, mk, x, chunk=min(clips, 8), threads=th)
+            times.append(dt)
+        keep = (z_o, idx_o, wav_o)
+        med = sorted(times)[1]
+        runs[th] = {"value": clips * clip_s / med, "passes_s": [round(t, 3) for t in times], "median_s": med,
+                    "sample": f"{clips} clips in chunks of {min(clips, 8)}, 1 warm-up + 3 timed passes, median {med:.2f} s"}
+    torch.set_num_threads(min(phys, 64))
+    best = max(runs, key=lambda t: runs[t]["value"])
+    base = {"value": runs[best]["value"], "unit": "audio-seconds/sec", "cores": best, "kind": "port",
+            "sample": f"{runs[best]['sample']}; {clip_s:g} s clips, {name}, fp32, torch CPU ops (oracle = the reference's arithmetic), "
+                      f"better of 1 and {phys} (all physical) threads on a host with {os.cpu_count()} logical CPUs",
+            "by_threads": {str(t): r for t, r in sorted(runs.items())}}
+    return base, keep
 
 
 def parity_census(model, sd, nq, z, idx, wav, oracle_out):
@@ -162,55 +196,55 @@ def parity_census(model, sd, nq, z, idx, wav, oracle_out):
     return out
 
 
-def main():
-    args = parse()
-    from hilcodec_amd import distributed as D
-    rank, world, local = D.env_rank_world()
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    D.init("nccl", dev)
-
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: each returns (step, audio_seconds_per_step, context)
+# ---------------------------------------------------------------------------------------------------------------------
+def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
     import hilcodec_amd
-    from hilcodec_amd import ops, synth
+    from hilcodec_amd import synth
+    mk = synth.model_kwargs(name)
+    sd = synth.synth_state_dict(name, seed=7)
+    model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+    model.load_state_dict(sd, strict=False)
+    for l in model.quantizer.layers:
+        l.initted = True
+    x = synth.synth_clips(n_clips, T, seed=1234, first=first).to(dev)
+    last = {}
 
-    name = args.model
+    def step(i):
+        z = model.encoder(x)
+        q, _, _, idx = model.quantizer(z, None, return_indices=True)
+        wav = model.decoder(q)
+        last["z"] = z
+        return idx, wav
+
+    return step, n_clips * T / 24000.0, {"model": model, "sd": sd, "mk": mk, "last": last}
+
+
+def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool):
+    from hilcodec_amd import synth
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
     mk = synth.model_kwargs(name)
     sd = synth.synth_state_dict(name, seed=7)
     nq = mk["vq_kwargs"]["num_quantizers"]
-    B, T = args.batch, args.samples
-    lo, hi = D.shard_range(B * world, rank, world)     # this rank's clips / streams of the global batch
-
-    if args.mode == "offline":
-        model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
-        model.load_state_dict(sd, strict=False)
-        for l in model.quantizer.layers:
-            l.initted = True
-        x = synth.synth_clips(hi - lo, T, seed=1234, first=lo).to(dev)
-        audio_per_step = (hi - lo) * T / 24000.0
-
-        last = {}
+    smk = {k: v for k, v in mk.items() if k not in ("spec_learnable", "causal", "pad_mode")}
+    model = StreamingHILCodec(24000, **smk).eval()
+    model.load_offline_state_dict(sd)
+    model.remove_weight_reparameterizations()
+    hop = 320
+    nbuf = 8                                           # distinct input hops, cycled
+    xs = [synth.synth_clips(n_streams, hop, seed=4321 + 7 * j, first=first).to(dev) for j in range(nbuf)]
+    ctx = {"model": model, "sd": sd, "mk": mk, "xs": xs, "hop": hop, "nq": nq}
+    if graph:
+        from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
+        ctx["make_hopper"] = lambda: (PipelinedHop if pipeline else GraphedHop)(model, n_streams, hop, nq, dev)
+        ctx["hopper"] = ctx["make_hopper"]()
 
         def step(i):
-            z = model.encoder(x)
-            q, _, _, idx = model.quantizer(z, None, return_indices=True)
-            wav = model.decoder(q)
-            last["z"] = z
-            return idx, wav
+            return ctx["hopper"].step(xs[i % nbuf])
     else:
-        from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
-        smk = {k: v for k, v in mk.items() if k not in ("spec_learnable", "causal", "pad_mode")}
-        model = StreamingHILCodec(24000, **smk).eval()
-        model.load_offline_state_dict(sd)
-        model.remove_weight_reparameterizations()
-        hop = 320
-        nbuf = 8                                           # distinct input hops, cycled
-        xs = [synth.synth_clips(hi - lo, hop, seed=4321 + 7 * j, first=lo).to(dev) for j in range(nbuf)]
         from hilcodec_amd.graph_step import StateBlock
-        blocks = (StateBlock(model, hi - lo, dev), StateBlock(model, hi - lo, dev))   # persistent ping-pong state in HBM
-        audio_per_step = (hi - lo) * hop / 24000.0
+        blocks = (StateBlock(model, n_streams, dev), StateBlock(model, n_streams, dev))   # persistent ping-pong state in HBM
 
         def step(i):
             src, dst = blocks[i & 1], blocks[(i & 1) ^ 1]
@@ -220,38 +254,114 @@ def main():
             wav, _ = model.decoder(q, *src.dec, cache_out=dst.dec)
             return idx, wav
 
-        if args.graph:
-            from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
-            hopper = (PipelinedHop if args.pipeline else GraphedHop)(model, hi - lo, hop, nq, dev)
-            args.no_launch_timing = True
+    return step, n_streams * hop / 24000.0, ctx
 
-            def step(i):                                   # noqa: F811
-                return hopper.step(xs[i % nbuf])
+
+def timed_region(step, steps: int, warmup: int, D, launch_timing: bool):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides."""
+    import contextlib
+    from hilcodec_amd import ops
+    with torch.no_grad():
+        for i in range(warmup):
+            idx, wav = step(i)
+        torch.cuda.synchronize()
+        cm = ops.timed_launches() if launch_timing else contextlib.nullcontext()
+        with cm as timer:
+            D.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                idx, wav = step(warmup + i)
+            torch.cuda.synchronize()
+            D.barrier()
+            dt = time.perf_counter() - t0
+    return dt, idx, wav, timer
+
+
+def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
+    """Short, separately reported runs of BASELINE configs[2] and configs[3] (never part of `value`): the driver sees them in
+    the one JSON line of the default invocation."""
+    out = {}
+
+    def line(workload, name, step, audio, steps, warmup, extra=None):
+        dt, idx, _wav, _ = timed_region(step, steps, warmup, D, False)
+        xrt = audio * steps / dt
+        tf = xrt * FLOP_PER_AUDIO_SECOND[name] / 1e12
+        d = {"workload": workload, "value": xrt, "unit": "audio-seconds/sec", "ms_per_step": dt / steps * 1e3, "steps": steps,
+             "warmup": warmup, "whole_path_tflops": tf, "whole_path_frac": tf / FP32_MFMA_PEAK_TFLOPS,
+             "index_checksum": int(idx.sum().item()), "dtype": "f32"}
+        d.update(extra or {})
+        return d
+
+    step, audio, _ctx = offline_workload("hil_music", clips, 0, 24000, dev)
+    out["configs[2]"] = line(f"hil_music, batch={clips}x1 s 24 kHz, Nq=12, offline encode+RVQ+decode", "hil_music", step, audio, 3, 1)
+    del step, _ctx
+    torch.cuda.empty_cache()
+    for key, pipeline in (("configs[3] graph", False), ("configs[3] pipelined graph", True)):
+        step, audio, _ctx = streaming_workload("hil_speech", streams, 0, dev, True, pipeline)
+        out[key] = line(f"hil_speech streaming, hop=320, {streams} concurrent streams, Nq=8, 22+30 caches per stream resident in HBM, "
+                        "one HIP-graph replay per hop" + (", decoder of hop i-1 pipelined beside the encoder of hop i "
+                                                          "(+1 hop = 13.3 ms output latency)" if pipeline else ""),
+                        "hil_speech", step, audio, 40, 4)
+        del step, _ctx
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    from hilcodec_amd import distributed as D
+    rank, world, local = D.env_rank_world()
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    D.init("nccl", dev, force=args.force_dist)
+
+    from hilcodec_amd import _lib
+
+    name = args.model
+    B, T = args.batch, args.samples
+    # this process's clips / streams of the global batch: its own rank's slice, or (emulation) another rank's
+    shard_rank, shard_world = (args.emulate_rank, args.emulate_world) if args.emulate_world else (rank, world)
+    lo, hi = D.shard_range(B * shard_world, shard_rank, shard_world)
+
+    if args.mode == "offline":
+        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev)
+    else:
+        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline)
+        if args.graph:
+            args.no_launch_timing = True
+    model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]
+    nq = mk["vq_kwargs"]["num_quantizers"]
 
     numerics = None
     if args.decoder_gemm != "fp32":
-        from hilcodec_amd import engine
+        dec_opts = model.decoder.exec_options          # this model's own switch (hilcodec_amd.engine.ExecOptions)
         if args.mode == "offline":
             with torch.no_grad():
                 idx_f, wav_f = step(0)                      # the fp32 product path on the same inputs, outside the timed region
-                engine.DECODER_GEMM = args.decoder_gemm
+                dec_opts.decoder_gemm = args.decoder_gemm
                 if args.x3_blocks_from > 0:
-                    engine.X3_FUSED_BLOCK_MIN_C = args.x3_blocks_from
+                    dec_opts.x3_fused_block_min_c = args.x3_blocks_from
                 idx_x, wav_x = step(0)
         else:
             # streaming: one hop from zero caches in both arithmetics (eager, outside the timed region and the state blocks)
+            xs = ctx["xs"]
             with torch.no_grad():
                 ce, cd = model.initialize_cache(xs[0])
+
                 def one_hop():
                     z, _ = model.encoder(xs[0], *ce)
                     i_ = model.quantizer(z, nq)
                     w_, _ = model.decoder(model.dequantizer(i_, nq), *cd)
                     return i_, w_
                 idx_f, wav_f = one_hop()
-                engine.DECODER_GEMM = args.decoder_gemm
+                dec_opts.decoder_gemm = args.decoder_gemm
                 idx_x, wav_x = one_hop()
             if args.graph:                                   # the graphs were captured in fp32: capture again in the new mode
-                hopper = type(hopper)(model, hi - lo, hop, nq, dev)
+                ctx["hopper"] = ctx["make_hopper"]()
         numerics = {"mode": args.decoder_gemm, "scope": args.mode + " decoder: up-sampling and depthwise-separable GEMMs, GEMM phases of the fused residual blocks"
                     + (f", residual blocks of width >= {args.x3_blocks_from}" if args.x3_blocks_from > 0 else "")
                     + "; encoder and RVQ exact fp32",
@@ -259,23 +369,8 @@ def main():
                     "dwav_max_vs_fp32_path": float((wav_f - wav_x).abs().max()),
                     "operand_bits": 16}
         del idx_f, wav_f, idx_x, wav_x
-    with torch.no_grad():
-        for i in range(args.warmup):
-            idx, wav = step(i)
-        torch.cuda.synchronize()
-        timer = None
-        if not args.no_launch_timing:
-            timer = ops.LaunchTimer()
-            ops.TIMER = timer
-        D.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            idx, wav = step(args.warmup + i)
-        torch.cuda.synchronize()
-        D.barrier()
-        dt = time.perf_counter() - t0
-        ops.TIMER = None
+
+    dt, idx, wav, timer = timed_region(step, args.steps, args.warmup, D, not args.no_launch_timing)
 
     per_rank = D.gather_counters({"clips": float((hi - lo) * args.steps), "audio_s": audio_per_step * args.steps,
                                   "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)   # the ONLY collective
@@ -284,7 +379,7 @@ def main():
         value = agg["xrt"]
         cfg_ix = {("offline", "hil_speech"): 1, ("offline", "hil_music"): 2, ("streaming", "hil_speech"): 3}.get(
             (args.mode, name), None)
-        if args.mode == "offline" and name == "hil_music" and world == 8 and B == 256:
+        if args.mode == "offline" and name == "hil_music" and shard_world == 8 and B == 256:
             cfg_ix = 4                                   # hil_music, 2048 clips sharded over 8 GPUs
         if args.mode == "offline":
             workload = (f"{name}, batch={B}x{T / 24000.0:g} s 24 kHz per GPU, Nq={nq}, offline encode+RVQ+decode "
@@ -294,19 +389,24 @@ def main():
                         f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else "")
                         + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop output latency)"
                            if args.graph and args.pipeline else ""))
+        if args.emulate_world:
+            workload += (f" — EMULATED rank {shard_rank} of {shard_world}: this process ran clips [{lo}, {hi}) of the "
+                         f"{B * shard_world}-clip job on one GPU (a shard check, not a scaling measurement)")
         out = {
             "metric": "audio-seconds/sec (xRT) encode+RVQ+decode, 24 kHz batch=256",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": agg["wall_s"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "global_batch": B * world, "samples_per_clip": T if args.mode == "offline" else 320,
-                       "parallelism": f"clip-sharded x{world}, replicated weights, counters all_gather only"},
+            "config": {"workload": workload, "global_batch": B * shard_world, "samples_per_clip": T if args.mode == "offline" else 320,
+                       "parallelism": f"clip-sharded x{shard_world}, replicated weights, counters all_gather only",
+                       "shard": [lo, hi]},
             "frames_per_sec": value * 75.0,
             "index_checksum": int(agg["index_checksum"]),
-            "ranks": {"backend": "rccl (torch.distributed nccl)" if world > 1 else "none (single process)",
-                      "rccl_ranks": world, "collectives_in_timed_region": 0,
+            "ranks": {"backend": D.backend_name(), "rccl_ranks": world if D.is_initialized() else 0,
+                      "process_group_initialized": D.is_initialized(), "collectives_in_timed_region": 0,
                       "wall_s_per_rank": [r["wall_s"] for r in per_rank],
                       "wall_skew_s": max(r["wall_s"] for r in per_rank) - min(r["wall_s"] for r in per_rank)},
+            "build": {"csrc_sha16": _lib.source_hash(), "abi": _lib.ABI_VERSION},
         }
         if numerics is not None:
             out["metric"] += " — EXPERIMENTAL decoder GEMMs in bf16x3, NOT the fp32 headline"
@@ -323,7 +423,7 @@ def main():
             flops = sum(tot[k][1] for k in kinds)
             secs = sum(tot[k][2] for k in kinds)
             roof.update({
-                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM> + spec_block_kernel<N> ("
+                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_lin_wr_kernel<BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM> + spec_block_kernel<N> ("
                           + "+".join(kinds) + "; fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": flops / secs / 1e12, "frac": flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "launches_per_step": launches // args.steps, "avg_launch_us": secs / launches * 1e6,
@@ -335,13 +435,16 @@ def main():
                                          if k in ("dw_conv", "dw_convtr", "conv_pre", "conv_post")}
         # HBM traffic of the dominant kernel family comes from rocprofv3 PMC passes of this same command
         # (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate passes; tools/summarize_profile.py) — it cannot be
-        # sampled from inside the process, so the committed summary of the latest profiled build is quoted.
+        # sampled from inside the process, so the committed summary of the latest profiled build is quoted, together with
+        # the build it was measured on: `stale` = the kernel sources have changed since.
         try:
             with open(os.path.join(ROOT, "profiles", "latest_mfma_family.json")) as f:
                 prof = json.load(f)
             if args.mode == "offline" and name == "hil_speech" and B == 256 and T == 24000:
                 roof["traffic"] = prof["hbm_bytes_per_launch"]
                 roof["traffic_unit"] = "bytes per launch (avg over the family), rocprofv3 PMC, profiles/latest_mfma_family.json"
+                roof["traffic_build"] = {"csrc_sha16": prof.get("csrc_sha16"), "git_sha": prof.get("git_sha"),
+                                         "stale": prof.get("csrc_sha16") != _lib.source_hash()}
                 roof["algorithmic_bytes_per_step"] = 196800 * B + 38150404 + nq * 524288 + 5602816
         except (OSError, KeyError, ValueError):
             pass
@@ -357,14 +460,14 @@ def main():
             roof["note"] = ("EXPERIMENTAL line: part of the work runs on the bf16 matrix pipe; every fraction here is "
                             "fp32-EQUIVALENT flops against the fp32 peak, not a utilisation")
         out["roofline"] = roof
+        if world == 1 and not args.no_other_configs and (args.is_default or (args.other_configs and args.mode == "offline")):
+            out["other_configs"] = other_config_lines(dev, D, B, 4 * B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)
             if args.mode == "offline" and lo == 0 and hi - lo >= args.cpu_clips:
-                out["parity_census"] = parity_census(model, sd, nq, last["z"], idx, wav, oracle_out)
+                out["parity_census"] = parity_census(model, sd, nq, ctx["last"]["z"], idx, wav, oracle_out)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -64,6 +64,21 @@ SIGNATURES = {
 ABI_VERSION = 7
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the C header the library is built from: the build id that
+    profiles/latest_mfma_family.json is stamped with (tools/summarize_profile.py) and bench.py compares against."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h*"))) + [os.path.join(root, "include", "hilcodec_amd.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class HilcodecLibraryError(RuntimeError):
     pass
 

@@ -24,7 +24,7 @@ extern thread_local int hilc_last_hip_error_code;   // rvq.hip
     }                                                         \
   } while (0)
 
-// Hot-path ELU: max(x, 2^(min(x,0)*log2 e) - 1) with the hardware v_exp_f32 (1 ulp): 4 VALU + the transcendental
+// Hot-path ELU: max(x, 2^(min(x,0)*log2 e) - 1) with the hardware v_exp_f32 (1 ulp): 3 VALU + the transcendental
 // instead of ~32 + a divergent branch for expm1f.  For x > 0 the exponential term is exactly 0 and the max returns x
 // itself; for x <= 0, e^x - 1 >= x.  |elu_fast - expm1| <= 1.2e-7 ABSOLUTE (the rounding of e ~ 1, i.e. one fp32 ulp
 // of an O(1) activation; tests/test_gpu_ops.py::test_elu_fast_error bounds it on a dense grid) — relative accuracy
@@ -36,7 +36,10 @@ __device__ __forceinline__ float elu_fast(float x) {
 #ifdef HILC_ELU_EXPM1
   return x > 0.0f ? x : expm1f(x);   // A/B build for the parity census (tools/census_run.sh): torch's own ELU form
 #endif
-  const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f);
+  // min(x, 0) is not an instruction: exp2(x * log2 e) >= 1 exactly when x >= 0, so clamping the EXPONENTIAL to [0, 1]
+  // (med3 with 0 and 1 folds into the clamp bit of v_exp_f32: free) gives the same bits as exp2(min(x, 0) * log2 e)
+  // for every x (x <= 0: the clamp is the identity; x > 0: both are exactly 1) — 3 VALU + the transcendental
+  const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * 1.44269504088896341f), 0.f, 1.f);
   return fmaxf(x, e - 1.0f);
 }
 

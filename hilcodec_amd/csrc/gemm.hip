@@ -409,6 +409,29 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
     if (ld.vec && lin_ok(B, K, T)) {
       TileCols cols;
       cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
+#ifndef HILC_NO_WAVE_ROW
+      // depthwise taps on the accumulator registers (gemm_lin.h: wave-row form).  Not for launches with a shortcut: there a
+      // lane would fetch its 16-B pieces of 64 different rows per load (measured: K = 384 2.1 -> 3.0 ms, L1 thrash), the
+      // LDS epilogue reads the shortcut as 64-B runs per lane
+#ifndef HILC_WR_RES
+#define HILC_WR_RES 0
+#endif
+      if (ep.vec && (HILC_WR_RES || res == nullptr) && wr_shape(M, (long)B * ep.tiles)) {
+        auto go = [&](auto er) {
+          er.y = y; er.dw_w = dw_w; er.dw_b = dw_b; er.res = res; er.M = M; er.T = T; er.tiles = ep.tiles; er.out_scale = out_scale;
+          if (in_elu) {
+            RowsB<TileCols, true> bo;
+            bo.x = x; bo.T = T; bo.in_scale = in_scale; bo.cols = cols;
+            return launch_lin_wr(wt, M, K, M, (long)B * ep.tiles, bo, er, (hipStream_t)stream);
+          }
+          RowsB<TileCols, false> bo;
+          bo.x = x; bo.T = T; bo.in_scale = in_scale; bo.cols = cols;
+          return launch_lin_wr(wt, M, K, M, (long)B * ep.tiles, bo, er, (hipStream_t)stream);
+        };
+        if (res != nullptr) return out_elu ? go(Dw5RegEpilogue<true, true>{}) : go(Dw5RegEpilogue<true, false>{});
+        return out_elu ? go(Dw5RegEpilogue<false, true>{}) : go(Dw5RegEpilogue<false, false>{});
+      }
+#endif
       return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
     }
     return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);

@@ -305,6 +305,98 @@ struct Dw5Epilogue {
   }
 };
 
+// The same depthwise k = 5, stride 1 epilogue for the wave-row GEMM form (gemm_lin.h: gemm_lin_wr_kernel): after
+// wr_time_order() lane (c, h) holds columns 64 h .. 64 h + 63 of channel m0 + c in registers, so the five taps are FMAs on
+// the accumulators with per-lane (= per-channel) tap registers; the only cross-lane traffic are the 4 columns in front of
+// the upper half (v_permlane32_swap from the lower half's last 4).  No LDS, no barrier; same taps-in-order fmaf chain and
+// the same separately rounded bias / scale / shortcut steps as Dw5Epilogue (bit-identical).  M % 128 == 0, T % 4 == 0,
+// y / res 16-B aligned (the launcher checks); `res` may alias `y` (each lane reads its own addresses before it writes them).
+template <bool RES, bool OELU>
+struct Dw5RegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][5]
+  const float* dw_b;   // [M] or null
+  const float* res;    // [B][M][T] (RES; may alias y)
+  int M, T, tiles;
+  float out_scale;
+  static constexpr int STEP = BN - 4;
+#ifndef HILC_WR_GB
+#define HILC_WR_GB 4     // 4-column groups per batch (the shortcut loads of a batch are in flight while the previous batch computes)
+#endif
+
+  // FULL: every column of the tile lies inside [0, T) (uniform) — only the tile's first 4 columns (halo) are not stored
+  template <bool FULL>
+  __device__ __forceinline__ void body(f32x16 (&acc)[4], int mrow0, long b, int t0, int lane) const {
+    constexpr int GB = HILC_WR_GB;
+    const int h = lane >> 5;
+    const int m = mrow0 + (lane & 31);
+    const int tb = t0 + 64 * h;                                       // time of this lane's column 0
+    float* yrow = y + (b * M + m) * (long)T + tb;
+    const float* rrow = res + (b * M + m) * (long)T + tb;
+    float w[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[j] = dw_w[(long)m * 5 + j];
+    const float bias = dw_b ? dw_b[m] : 0.f;
+    // group G = columns 4G .. 4G+3 of the lane's half; the tile's first 4 columns (h == 0, G == 0) are halo only
+    auto live = [&](int G) { return (G > 0 || h != 0) && (FULL || tb + 4 * G < T); };
+    f32x4 rq[2][GB];
+    auto load_res = [&](int batch) {
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const int G = batch * GB + g;
+        if ((G > 0 && FULL) || live(G)) rq[batch & 1][g] = *reinterpret_cast<const f32x4*>(rrow + 4 * G);
+      }
+    };
+    if (RES) load_res(0);
+    wr_time_order(acc);
+    float prev[4];                      // the 4 columns in front of the current group
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // lower half: zeros (its first outputs are discarded); upper half: the lower half's columns 60..63
+      const float src = HILC_WR_V(acc, 60 + j);
+      const auto p = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(src), false, false);
+      const unsigned p0 = p[0];
+      prev[j] = __uint_as_float(p0);
+    }
+#pragma unroll
+    for (int batch = 0; batch < 16 / GB; ++batch) {
+      if (RES && batch + 1 < 16 / GB) load_res(batch + 1);
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const int G = batch * GB + g;
+        const float v[8] = {prev[0], prev[1], prev[2], prev[3], HILC_WR_V(acc, 4 * G), HILC_WR_V(acc, 4 * G + 1),
+                            HILC_WR_V(acc, 4 * G + 2), HILC_WR_V(acc, 4 * G + 3)};
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) a = fmaf(w[j], v[e + j], a);   // taps in order j = 0..4
+          a = __fadd_rn(a, bias);
+          o[e] = __fmul_rn(a, out_scale);
+        }
+        if (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], rq[batch & 1][g][e]);
+        }
+        if (OELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
+        }
+        if ((G > 0 && FULL) || live(G)) *reinterpret_cast<f32x4*>(yrow + 4 * G) = o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prev[j] = v[4 + j];
+      }
+    }
+  }
+
+  __device__ void run_wr(f32x16 (&acc)[4], int mrow0, long ntile, int lane) const {
+    const long b = ntile / tiles;
+    const int t0 = (int)(ntile - b * tiles) * STEP - 4;
+    if (t0 + BN <= T) body<true>(acc, mrow0, b, t0, lane);
+    else body<false>(acc, mrow0, b, t0, lane);
+  }
+};
+
 // depthwise causal conv k = 2r, stride r (down-sampling): tile covers times [o0*r - H, +128) with
 // H = round_up(r, 4); output o0 + i reads columns H - r + i*r + j, j < 2r.
 struct DwStrideEpilogue {

@@ -389,6 +389,149 @@ __global__ __launch_bounds__(NT, BOp::kMinWaves) void gemm_lin_kernel(const floa
   LIN_STAMP(3);
 }
 
+// ---- "wave = row block" form of the same tile (MB = 4 only): wave w owns the 32 channels [32w, 32w+32) of the tile
+// and ALL four 32-column blocks, and the MFMA operand roles are swapped — the activations go in as the A operand
+// (M index = time), the weights as B (N index = channel) — so that D comes out as D[time][channel]: a lane holds one
+// CHANNEL (lane & 31) and, after 32 v_permlane32_swap, 64 CONTIGUOUS time steps of it in its accumulator registers
+// (lanes 0-31: columns 0-63 of the tile, lanes 32-63: columns 64-127; see wr_time_order).  A depthwise conv along time
+// is then register arithmetic with per-lane taps, the output rows are 16-B stores straight from the accumulators: no
+// accumulator -> LDS -> register round trip and no barrier in the epilogue (the LDS epilogues cost a K-independent
+// ~51 k cycles per workgroup, 11-28 % of its life: profiles/r02_experiments.md).  The LDS traffic of the K loop is
+// unchanged (per k-pair: 4 activation + 1 weight operand reads for 4 MFMAs), products and k order are the same, so the
+// results are bit-identical to the column-block form.
+//
+// After wr_time_order():  V[i] (column i of the lane's 64-column half, i = 32 cb + 8 g + 4 q + e)  =  acc[cb + 2 q][4 g + e].
+__device__ __forceinline__ void wr_time_order(f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // v_permlane32_swap vdst, src0: lanes 32-63 of vdst <-> lanes 0-31 of src0
+      // (scalar temporaries: this hipcc's __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
+      const float lo = acc[cb][r], hi = acc[cb + 2][r];
+      const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+      const unsigned p0 = p[0], p1 = p[1];
+      acc[cb][r] = __uint_as_float(p0);
+      acc[cb + 2][r] = __uint_as_float(p1);
+    }
+}
+#define HILC_WR_V(acc, i) ((acc)[(((i) >> 5) & 1) + 2 * (((i) >> 2) & 1)][4 * (((i) >> 3) & 3) + ((i) & 3)])
+
+template <class BOp, class Epilogue>
+__global__ __launch_bounds__(NT, BOp::kMinWaves) void gemm_lin_wr_kernel(const float* __restrict__ wt, int M, int K, int ldw,
+                                                                         long ntiles, int mtiles, BOp bop, Epilogue ep) {
+  constexpr int MB = 4;
+  constexpr int BM = 32 * MB;
+  constexpr int AG = BK * BM / 4;
+  constexpr int AP = (AG + NT - 1) / NT;
+  constexpr int STG = 2 * BK * (BM + BN);
+  __shared__ __attribute__((aligned(16))) float smem[STG];
+  float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
+  float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
+
+  long id = blockIdx.x;   // XCD-aware tile order, as in gemm_core.h
+  long grp = id / (8L * mtiles);
+  int within = (int)(id - grp * 8L * mtiles);
+  long ntile = grp * 8 + (within & 7);
+  int mtile = within >> 3;
+  if (ntile >= ntiles) return;
+  const int m0 = mtile * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ktiles = (K + BK - 1) / BK;
+  const int krem = K - (ktiles - 1) * BK;
+
+  unsigned aoff[AP], aoff_last[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int g = tid + p * NT;
+    const int kr = g / (BM / 4), m4 = (g % (BM / 4)) * 4;
+    int col = m0 + m4;
+    col = col < ldw - 4 ? col : ldw - 4;
+    const int krl = kr < krem ? kr : krem - 1;
+    aoff[p] = (unsigned)(kr * ldw + col) * 4u;
+    aoff_last[p] = (unsigned)(krl * ldw + col) * 4u;
+  }
+  const unsigned a_slice = (unsigned)BK * (unsigned)ldw * 4u;
+  const typename BOp::State bs = bop.init(ntile, tid, krem);
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  f32x4 ra[AP];
+  typename BOp::Raw rb[BP];
+  auto fetch = [&](int kt, bool last) {
+    const char* sa = reinterpret_cast<const char*>(wt) + (size_t)kt * a_slice;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) ra[p] = *reinterpret_cast<const f32x4*>(sa + (last ? aoff_last[p] : aoff[p]));
+#pragma unroll
+    for (int h = 0; h < BP; ++h) rb[h] = bop.fetch(bs, kt, last, h);
+  };
+  auto stage = [&](int buf, bool last) {
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int g = tid + p * NT;
+      const int k = g / (BM / 4), m4 = (g % (BM / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&As[buf][k][m4]) = ra[p];
+    }
+#pragma unroll
+    for (int h = 0; h < BP; ++h)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(tid >> 5) + 8 * h][(tid & 31) * 4]) = bop.xform(bs, rb[h], last, h);
+  };
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  fetch(0, ktiles == 1);
+  stage(0, ktiles == 1);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    const bool last = kt + 2 == ktiles;
+    if (more) fetch(kt + 1, last);
+    float wv[2], xv[2][MB];
+    wv[0] = As[buf][kh][wave * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) xv[0][i] = Bs[buf][kh][i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < BK / 2; ++j) {
+      const int cur = j & 1, nxt = cur ^ 1;
+      if (j + 1 < BK / 2) {
+        wv[nxt] = As[buf][2 * j + 2 + kh][wave * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) xv[nxt][i] = Bs[buf][2 * j + 2 + kh][i * 32 + l31];
+      }
+#pragma unroll
+      for (int i = 0; i < MB; ++i)     // D[time][channel] += x[k][time] * w[k][channel]
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[cur][i], wv[cur], acc[i], 0, 0, 0);
+    }
+    if (more) {
+      stage(buf ^ 1, last);
+      __syncthreads();
+    }
+  }
+  ep.run_wr(acc, m0 + wave * 32, ntile, lane);
+}
+
+template <class BOp, class Epilogue>
+int launch_lin_wr(const float* wt, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep, hipStream_t s) {
+  const int mtiles = (M + 127) / 128;
+  const long groups = (ntiles + 7) / 8;
+  const long blocks = groups * 8 * mtiles;
+  if (ntiles <= 0 || blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL((gemm_lin_wr_kernel<BOp, Epilogue>), dim3((unsigned)blocks), dim3(NT), 0, s, wt, M, K, ldw, ntiles, mtiles, bop, ep);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+// the wave-row form pays where the column-block form would run 128-row tiles anyway
+inline bool wr_shape(int M, long ntiles) { return M % 128 == 0 && pick_mb(M / 32, ntiles) == 4; }
+
 template <class BOp, class Epilogue>
 int launch_lin(const float* wt, int M, int K, int ldw, long ntiles, const BOp& bop, const Epilogue& ep, hipStream_t s) {
   const int m32 = (M + 31) / 32;

@@ -16,9 +16,13 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend: str, device: torch.device = None) -> Tuple[int, int]:
+def init(backend: str, device: torch.device = None, force: bool = False) -> Tuple[int, int]:
+    """One process per GPU (`/root/reference/train.py:51-61` does the same with NCCL).  A single process needs no process
+    group; `force=True` (or HILC_FORCE_DIST=1) creates it anyway, so that the RCCL initialisation, the barriers and the
+    counters all_gather below execute for real at world size 1 (the only way to exercise them on a 1-GPU box)."""
     rank, world, _ = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("HILC_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {}
@@ -26,6 +30,23 @@ def init(backend: str, device: torch.device = None) -> Tuple[int, int]:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
+
+
+def is_initialized() -> bool:
+    return dist.is_initialized()
+
+
+def backend_name() -> str:
+    """what the counters travel over: "rccl (torch.distributed nccl)" on GPUs, "gloo" in the CPU tests, or no group at all"""
+    if not dist.is_initialized():
+        return "none (single process, no process group)"
+    b = dist.get_backend()
+    return "rccl (torch.distributed nccl)" if b == "nccl" else str(b)
+
+
+def shutdown() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -61,7 +82,7 @@ def gather_counters(counters: Dict[str, float], device: torch.device) -> List[Di
     """all_gather of a small dict of scalars (<= 64 B per rank); returns one dict per rank, on every rank."""
     keys = sorted(counters)
     t = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():          # also at world size 1 (forced group): the collective really runs
         out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
         dist.all_gather(out, t)
     else:

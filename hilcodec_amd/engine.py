@@ -28,13 +28,25 @@ FUSE_UPSAMPLE = True      # decoder up-sampling: transposed conv computed inside
 FUSE_RESBLOCK = True
 FUSE_STREAM = True        # streaming hops: cache-aware fused kernels instead of pointwise GEMM + depthwise launches
 FUSE_RESBLOCK_MAX_C = 192
-# EXPERIMENTAL, opt-in: "bf16x3" runs the GEMMs of the DECODER (offline and streaming: up-sampling, wide depthwise-separable
-# layers, the GEMM phases of the fused residual blocks)
-# on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32 accumulation).  The
-# encoder and the RVQ — hence every index — are never touched.  Default "fp32" = the reference's arithmetic.
-DECODER_GEMM = "fp32"
-X3_FUSED_BLOCK_MIN_C = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
-X3_FUSED_BLOCKS = True            # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
+
+
+@dataclass
+class ExecOptions:
+    """Execution options of ONE model's encoder or decoder (held by the module, passed to run_encoder / run_decoder):
+    two models in one process may run different arithmetic and schedules side by side — nothing here is process-global.
+
+    decoder_gemm: "fp32" = the reference's arithmetic (default).  "bf16x3" is EXPERIMENTAL and opt-in: the GEMMs of the
+    DECODER (offline and streaming: up-sampling, wide depthwise-separable layers, the GEMM phases of the fused residual
+    blocks) run on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32
+    accumulation).  The encoder and the RVQ — hence every index — are never touched by it.
+    side_stream: set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves."""
+    decoder_gemm: str = "fp32"
+    x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
+    x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
+    side_stream: Optional[object] = None
+
+
+_DEFAULT_OPTIONS = ExecOptions()
 _X3_SPLIT = {}            # id(weight tensor) -> (weak reference, version, split form); built on first use, dies with the weight
 
 
@@ -49,7 +61,6 @@ def _x3(wt: Tensor, pack=None) -> Tensor:
     return hit[2]
 
 
-SIDE_STREAM = None        # set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
 
 
@@ -186,46 +197,46 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
-def _fusable(rb: ResBlockSpec, x: Tensor) -> bool:
+def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False) -> bool:
     return (FUSE_RESBLOCK and rb.pw1_packed is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
             and rb.dw1_b is not None and rb.dw2_b is not None and x.shape[1] <= FUSE_RESBLOCK_MAX_C
-            and ops.resblock_supported(x.shape[1], x.shape[2]))
+            and ops.resblock_supported(x.shape[1], x.shape[2], x.shape[0], streaming))
 
 
 def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list],
-              outs: Optional[Sequence[Tensor]] = None, x3: bool = False) -> Tensor:
+              outs: Optional[Sequence[Tensor]] = None, x3: bool = False, opts: ExecOptions = _DEFAULT_OPTIONS) -> Tensor:
     """One residual block; streaming: `caches` = its two depthwise caches, `outs` = where the next hop's caches go
     (persistent state block) or None (fresh tensors, the reference's protocol).  `x3`: offline decoder block in the
     experimental bf16x3 mode."""
     o0, o1 = (outs[0], outs[1]) if outs is not None else (None, None)
     if (x3 and caches is None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-            and ops.x3_supported(x.shape[1], x.shape[1], x.shape[2])
-            and (not _fusable(rb, x) or x.shape[1] >= X3_FUSED_BLOCK_MIN_C)):
+            and ops.x3_supported(x.shape[1], x.shape[1], x.shape[2], x.shape[0])
+            and (not _fusable(rb, x) or x.shape[1] >= opts.x3_fused_block_min_c)):
         g = ops.dws_conv_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
         return ops.dws_conv_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
-    if (x3 and X3_FUSED_BLOCKS and caches is None and _fusable(rb, x) and ops.resblock_x3_supported(x.shape[1], x.shape[2])):
+    if (x3 and opts.x3_fused_blocks and caches is None and _fusable(rb, x) and ops.resblock_x3_supported(x.shape[1], x.shape[2], x.shape[0])):
         return ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
                                _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)
     if caches is None and _fusable(rb, x):
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
-    if (x3 and X3_FUSED_BLOCKS and caches is not None and x.shape[2] >= 4 and _fusable(rb, x)
-            and ops.resblock_x3_supported(x.shape[1], x.shape[2])):
+    if (x3 and opts.x3_fused_blocks and caches is not None and x.shape[2] >= 4 and _fusable(rb, x, True)
+            and ops.resblock_x3_supported(x.shape[1], x.shape[2], x.shape[0])):
         y, cs = ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
                                 _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale,
                                 hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
         return y
-    if caches is not None and x.shape[2] >= 4 and _fusable(rb, x):
+    if caches is not None and x.shape[2] >= 4 and _fusable(rb, x, True):
         # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns
         y, cs = ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                              rb.pre_scale, rb.out_scale, hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
         return y
     if (x3 and caches is not None and FUSE_STREAM
-            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw1_w.shape[1], 1)
-            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw2_w.shape[1], 1)):
+            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw1_w.shape[1], 1, x.shape[0])
+            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw2_w.shape[1], 1, x.shape[0])):
         g, c0 = ops.dws_conv_stream_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, caches[0], in_scale=rb.pre_scale, in_elu=True,
                                        out_elu=True, hist_out=o0)
         y, c1 = ops.dws_conv_stream_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, caches[1], res=x, out_scale=rb.out_scale,
@@ -276,22 +287,23 @@ def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Te
     return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
 
 
-def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor]) -> Optional[dict]:
+def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor], side, skip=()) -> Optional[dict]:
     """Streaming hop inside a captured graph: the log-magnitude spectra of the un-fused SpecBlocks depend on the
-    waveform only, so they are computed on SIDE_STREAM beside the first encoder stages (their small launches fill
+    waveform only, so they are computed on `side` (ExecOptions.side_stream) beside the first encoder stages (their small launches fill
     idle CUs instead of standing in the chain); `_spec_block` waits for each one's event.  Same launches, same
     results."""
-    side = SIDE_STREAM
     if side is None or torch.compiler.is_compiling() or not wav.is_cuda:
+        return None
+    todo = [sb for sb in [st.spec for st in es.stages] + [es.spec_post]
+            if not _spec_fused(sb, wav, wav_hist) and not any(sb is k for k in skip)]
+    if not todo:                      # nothing un-fused: do not fork a stream that nothing joins
         return None
     main = torch.cuda.current_stream(wav.device)
     capturing = torch.cuda.is_current_stream_capturing()
     early = {}
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        for sb in [st.spec for st in es.stages] + [es.spec_post]:
-            if _spec_fused(sb, wav, wav_hist):
-                continue
+        for sb in todo:
             s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
             if not capturing:
                 s.record_stream(main)
@@ -306,7 +318,8 @@ def _contig(caches: Optional[Sequence[Tensor]]):
 
 
 def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]] = None,
-                channel_last_out: bool = False, caches_out: Optional[Sequence[Tensor]] = None):
+                channel_last_out: bool = False, caches_out: Optional[Sequence[Tensor]] = None,
+                opts: ExecOptions = _DEFAULT_OPTIONS):
     """wav `[B,1,T]` -> z `[B,dim,ceil(T/hop)]` (or `[B,T',dim]`), and the new cache list if streaming.
     `caches_out` (streaming, optional): persistent buffers, same shapes as `caches` and distinct from them, that
     receive the next hop's caches (ping-pong state block); without it every cache is a fresh tensor, which is the
@@ -337,7 +350,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
-    early = _early_spectra(es, wav, wav_hist) if streaming else None
+    early = _early_spectra(es, wav, wav_hist, opts.side_stream, skip=(sb0,) if fuse_pre else ()) if streaming else None
     for si, st in enumerate(es.stages):
         if not (fuse_pre and si == 0):
             x = _spec_block(st.spec, x, wav, wav_hist, early)
@@ -376,7 +389,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
 
 
 def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] = None,
-                caches_out: Optional[Sequence[Tensor]] = None):
+                caches_out: Optional[Sequence[Tensor]] = None, opts: ExecOptions = _DEFAULT_OPTIONS):
     """q `[B,dim,F]` (channel-major) -> wav `[B,1,F*hop]`, and the new cache list if streaming (`caches_out` as in
     run_encoder)."""
     streaming = caches is not None
@@ -387,11 +400,11 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         return caches_out[i] if caches_out is not None else None
 
     q = q.contiguous().float()
-    if DECODER_GEMM not in ("fp32", "bf16x3"):
-        raise RuntimeError(f"engine.DECODER_GEMM must be 'fp32' or 'bf16x3', got {DECODER_GEMM!r}")
-    if DECODER_GEMM != "fp32" and torch.compiler.is_compiling():
-        raise RuntimeError("engine.DECODER_GEMM = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
-    x3 = DECODER_GEMM == "bf16x3"
+    if opts.decoder_gemm not in ("fp32", "bf16x3"):
+        raise RuntimeError(f"ExecOptions.decoder_gemm must be 'fp32' or 'bf16x3', got {opts.decoder_gemm!r}")
+    if opts.decoder_gemm != "fp32" and torch.compiler.is_compiling():
+        raise RuntimeError("decoder_gemm = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
+    x3 = opts.decoder_gemm == "bf16x3"
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
@@ -409,7 +422,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     for st in ds.stages:
         fused_up = FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0
         if (streaming and FUSE_STREAM and x3 and (x.shape[2] * st.ratio) % 4 == 0
-                and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio)):
+                and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0])):
             x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
                                   hist=caches[ci], want_hist=True, hist_out=out(ci))
             new_caches.append(c)
@@ -422,7 +435,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
                                  in_scale=st.in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
-        elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio):
+        elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0]):
             x = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps)
         elif fused_up:
             # the up-sampled tensor only exists inside the GEMM's loader
@@ -433,7 +446,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         ci += 1
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
-                          caches_out[ci:ci + 2] if caches_out is not None else None, x3=x3)
+                          caches_out[ci:ci + 2] if caches_out is not None else None, x3=x3, opts=opts)
             ci += 2
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,

@@ -22,18 +22,19 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from . import engine
+from . import engine, ops
 
 
 @contextlib.contextmanager
-def _spectra_on(stream: Optional[torch.cuda.Stream]):
-    """while a hop is warmed up / captured: the STFT front halves of the un-fused SpecBlocks go to `stream`
-    (engine._early_spectra), a branch of the graph beside the first encoder stages"""
-    prev, engine.SIDE_STREAM = engine.SIDE_STREAM, stream
+def _spectra_on(encoder, stream: Optional[torch.cuda.Stream]):
+    """while a hop of THIS model's encoder is warmed up / captured: the STFT front halves of its un-fused SpecBlocks go
+    to `stream` (engine._early_spectra), a branch of the graph beside the first encoder stages"""
+    opts = encoder.exec_options
+    prev, opts.side_stream = opts.side_stream, stream
     try:
         yield
     finally:
-        engine.SIDE_STREAM = prev
+        opts.side_stream = prev
 
 
 class StateBlock:
@@ -85,6 +86,7 @@ class GraphedHop:
         self.state = (StateBlock(model, batch, device), StateBlock(model, batch, device))
         self.parity = 0                       # the block holding the CURRENT caches (input of the next hop)
         self.spec_side = torch.cuda.Stream(device)
+        self.sched = ops.SchedWorkspace(device)      # ticket words of this object's residual-block launches (one slot each)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
@@ -108,11 +110,12 @@ class GraphedHop:
     def _hop(self, p: int) -> Tuple[Tensor, Tensor]:
         m = self.model
         src, dst = self.state[p], self.state[p ^ 1]
-        with _spectra_on(self.spec_side):
-            z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
-        idx = m.quantizer(z, self.n)
-        q = m.dequantizer(idx, self.n)
-        wav, _ = m.decoder(q, *src.dec, cache_out=dst.dec)
+        with ops.sched_workspace(self.sched):
+            with _spectra_on(m.encoder, self.spec_side):
+                z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
+            idx = m.quantizer(z, self.n)
+            q = m.dequantizer(idx, self.n)
+            wav, _ = m.decoder(q, *src.dec, cache_out=dst.dec)
         return idx, wav
 
     @property
@@ -159,6 +162,8 @@ class PipelinedHop:
         self.pending = False                  # a hop is encoded but not decoded yet
         self.side = torch.cuda.Stream(device)
         self.spec_side = torch.cuda.Stream(device)
+        # the two branches run concurrently: each has its own ticket words (encoder and decoder never share a slot)
+        self.sched_enc, self.sched_dec = ops.SchedWorkspace(device), ops.SchedWorkspace(device)
         warm = torch.cuda.Stream(device)
         warm.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(warm), torch.no_grad():
@@ -183,14 +188,15 @@ class PipelinedHop:
 
     def _encode(self, p: int) -> Tensor:
         m = self.model
-        with _spectra_on(self.spec_side):
+        with ops.sched_workspace(self.sched_enc), _spectra_on(m.encoder, self.spec_side):
             z, _ = m.encoder(self.x, *self.state[p].enc, cache_out=self.state[p ^ 1].enc)
         return m.quantizer(z, self.n)
 
     def _decode(self, p: int) -> Tensor:
         """decode the hop whose encoder ran with parity p^1 (its indices sit in idx[p^1]); decoder parity = p^1"""
         m = self.model
-        wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1], self.n), *self.state[p ^ 1].dec, cache_out=self.state[p].dec)
+        with ops.sched_workspace(self.sched_dec):
+            wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1], self.n), *self.state[p ^ 1].dec, cache_out=self.state[p].dec)
         return wav
 
     def _both(self, p: int) -> Tensor:

@@ -177,18 +177,40 @@ class SpecBlock(nn.Module):
 
 
 class _PlanModule(nn.Module):
-    """Mixin: folded plan cached per (device, parameter versions)."""
+    """Mixin: folded plan cached per (device, parameter versions); per-model execution options."""
+
+    @property
+    def exec_options(self) -> engine.ExecOptions:
+        """this module's own execution options (arithmetic mode of the decoder's GEMMs, capture side stream): never
+        shared between models, never process-global"""
+        opts = self.__dict__.get("_exec_options")
+        if opts is None:
+            opts = self.__dict__["_exec_options"] = engine.ExecOptions()
+        return opts
 
     def _plan_key(self, dev):
         return (str(dev),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
+    @staticmethod
+    def _norm_dev(dev):
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None and torch.cuda.is_available():
+            dev = torch.device("cuda", torch.cuda.current_device())      # "cuda" and "cuda:0" are one plan
+        return dev
+
     def plan(self, dev):
+        dev = self._norm_dev(dev)
         if torch.compiler.is_compiling():
             # inside torch.compile the folded plan is a constant of the graph: fold (host work, data_ptr keys) cannot be
-            # traced, so it must exist already — `prepare(device)` or any earlier eager call builds it
+            # traced, so it must exist already — `prepare(device)` or any earlier eager call builds it.  The cheap part of
+            # the key (the device) is still compared: a plan folded for another device would bake wrong-device pointers
+            # into the graph.  After in-place weight updates / merge_scaling / load_state_dict: prepare() again, recompile.
             cached = getattr(self, "_plan_cache", None)
             if cached is None:
                 raise RuntimeError("call .prepare(device) (or run the module once eagerly) before torch.compile")
+            if self._plan_cache_key[0] != str(dev):
+                raise RuntimeError(f"the folded plan was prepared for {self._plan_cache_key[0]}, the input is on {dev}: "
+                                   "call .prepare(device) for this device before compiling")
             return cached
         key = self._plan_key(dev)
         if getattr(self, "_plan_cache_key", None) != key:
@@ -298,7 +320,7 @@ class SEANetEncoder(_PlanModule):
             bool(self.l2norm), self.dimension, self.spec_post.spec.n_fft - 1)
 
     def forward(self, x: Tensor) -> Tensor:
-        return engine.run_encoder(self.plan(x.device), x)
+        return engine.run_encoder(self.plan(x.device), x, opts=self.exec_options)
 
 
 class SEANetDecoder(_PlanModule):
@@ -392,4 +414,4 @@ class SEANetDecoder(_PlanModule):
                                   None if b is None else b.to(dev), out_scale, self.final_activation == "Tanh")
 
     def forward(self, z: Tensor) -> Tensor:
-        return engine.run_decoder(self.plan(z.device), z)
+        return engine.run_decoder(self.plan(z.device), z, opts=self.exec_options)

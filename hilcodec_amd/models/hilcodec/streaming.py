@@ -354,7 +354,8 @@ class Encoder(_PlanModule):
         without it the new caches are fresh tensors, as in the reference."""
         if len(args) != self.num_cache:
             raise RuntimeError(f"expected {self.num_cache} cache tensors, got {len(args)}")
-        return engine.run_encoder(self.plan(x.device), x, list(args), channel_last_out=True, caches_out=cache_out)
+        return engine.run_encoder(self.plan(x.device), x, list(args), channel_last_out=True, caches_out=cache_out,
+                                  opts=self.exec_options)
 
 
 class Decoder(_PlanModule):
@@ -440,7 +441,7 @@ class Decoder(_PlanModule):
     def forward(self, x: Tensor, *args, cache_out: tp.Optional[tp.Sequence[Tensor]] = None
                 ) -> tp.Tuple[Tensor, tp.List[Tensor]]:
         q = x.float().transpose(1, 2).contiguous()       # [B,T',C] -> [B,C,T'] (layout copy only)
-        return engine.run_decoder(self.plan(x.device), q, list(args), caches_out=cache_out)
+        return engine.run_decoder(self.plan(x.device), q, list(args), caches_out=cache_out, opts=self.exec_options)
 
 
 class HILCodec(nn.Module):

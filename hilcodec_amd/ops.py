@@ -13,6 +13,8 @@ The public functions below are what `engine.py` and the module classes call; the
 dispatch through `torch.ops.hilcodec`.  All tensors must be fp32 (indices int64), contiguous, on a GPU."""
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import numbers
 from typing import List, Optional, Sequence, Tuple
 
@@ -62,24 +64,38 @@ class LaunchTimer:
         return out                 # kind -> [launches, work, seconds]
 
 
-TIMER: Optional[LaunchTimer] = None
+_TIMER: contextvars.ContextVar = contextvars.ContextVar("hilcodec_launch_timer", default=None)
+
+
+@contextlib.contextmanager
+def timed_launches(timer: Optional[LaunchTimer] = None):
+    """`with ops.timed_launches() as t:` — every launch issued by THIS context (thread / task) inside the block is
+    bracketed by HIP events on its launch stream and recorded in `t`.  A context variable, not a module global: another
+    thread's launches are neither timed nor slowed down."""
+    t = timer if timer is not None else LaunchTimer()
+    token = _TIMER.set(t)
+    try:
+        yield t
+    finally:
+        _TIMER.reset(token)
 
 
 class _timed:
     def __init__(self, kind: str, work: float, tag: str = ""):
         self.kind, self.work, self.tag = kind, work, tag
+        self.timer = _TIMER.get()
 
     def __enter__(self):
-        if TIMER is not None:
+        if self.timer is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if TIMER is not None:
+        if self.timer is not None:
             self.e1.record()
-            TIMER.records.append((self.kind, self.work, self.e0, self.e1, self.tag))
+            self.timer.records.append((self.kind, self.work, self.e0, self.e1, self.tag))
         return False
 
 
@@ -285,8 +301,9 @@ _register("resblock_x3", "(Tensor x, Tensor w1s, Tensor dw1_w, Tensor dw1_b, Ten
           torch.empty_like(x))
 
 
-def resblock_x3_supported(C: int, T: int) -> bool:
-    return C in (96, 192) and T % 4 == 0
+def resblock_x3_supported(C: int, T: int, B: int = 1) -> bool:
+    """mirror of hilc_resblock_x3's limits (32-bit byte offsets: the tensor must stay below 4 GiB)"""
+    return C in (96, 192) and T % 4 == 0 and B * C * T * 4 < (1 << 32)
 
 
 def resblock_x3_pack(wt: Tensor) -> Tensor:
@@ -308,9 +325,9 @@ def resblock_x3(x: Tensor, w1s: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2s: Tenso
     return y, [o1, o2]
 
 
-def x3_supported(K: int, M: int, T: int) -> bool:
-    """mirror of hilc_x3_supported"""
-    return K % 32 == 0 and M % 8 == 0 and T % 4 == 0
+def x3_supported(K: int, M: int, T: int, B: int = 1) -> bool:
+    """mirror of hilc_x3_supported, plus the entry points' 4 GiB limit on the input tensor (32-bit byte offsets)"""
+    return K % 32 == 0 and M % 8 == 0 and T % 4 == 0 and B * K * T * 4 < (1 << 32)
 
 
 def x3_split(wt: Tensor) -> Tensor:
@@ -336,8 +353,8 @@ def up_conv_x3(x: Tensor, tr_w: Tensor, wsplit: Tensor, bias: Optional[Tensor], 
     return (y, hout) if want_hist else y
 
 
-def dws_conv_stream_x3_supported(K: int, M: int, T: int, k: int, stride: int) -> bool:
-    return k == 5 and stride == 1 and T <= 128 and T % 4 == 0 and x3_supported(K, M, T)
+def dws_conv_stream_x3_supported(K: int, M: int, T: int, k: int, stride: int, B: int = 1) -> bool:
+    return k == 5 and stride == 1 and T <= 128 and T % 4 == 0 and x3_supported(K, M, T, B)
 
 
 def dws_conv_stream_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
@@ -362,9 +379,51 @@ _register("resblock_pack", "(Tensor wt) -> Tensor", _resblock_pack, lambda wt: w
 _SCHED = {}
 
 
+class SchedWorkspace:
+    """Ticket words of the residual-block kernel's tile scheduler (two ints per launch, zero at launch, re-armed by the
+    kernel itself) owned by ONE schedule object (graph_step.GraphedHop / PipelinedHop): allocated outside graph capture,
+    one slot per launch in call order, so that (i) no allocation or memset node lands inside a capture, (ii) launches that
+    run concurrently — the two branches of a pipelined hop, two graphs replayed on different streams — never share a
+    ticket (shared words would hand out duplicate or skipped tiles)."""
+
+    def __init__(self, device, slots: int = 64):
+        self.words = torch.zeros(2 * slots, dtype=torch.int32, device=device)
+        self.slots, self.next = slots, 0
+
+    def take(self) -> Tensor:
+        if self.next >= self.slots:
+            raise RuntimeError("SchedWorkspace: more residual-block launches than slots")
+        w = self.words[2 * self.next:2 * self.next + 2]
+        self.next += 1
+        return w
+
+
+_SCHED_WS: contextvars.ContextVar = contextvars.ContextVar("hilcodec_sched_workspace", default=None)
+
+
+@contextlib.contextmanager
+def sched_workspace(ws: Optional[SchedWorkspace]):
+    """the residual-block launches of this block take their ticket words from `ws`, slot 0 first"""
+    if ws is not None:
+        ws.next = 0
+    token = _SCHED_WS.set(ws)
+    try:
+        yield ws
+    finally:
+        _SCHED_WS.reset(token)
+
+
 def _sched_buffer(device) -> Tensor:
-    """Two zeroed ints per (device, stream) for the residual-block kernel's ticket scheduler; the kernel re-arms
-    them itself, so the buffer is written by the host only once."""
+    """Two zeroed ints for the residual-block kernel's ticket scheduler; the kernel re-arms them itself, so a buffer is
+    written by the host only once.  Inside `sched_workspace(...)`: the owner's next slot.  Otherwise one buffer per
+    (device, stream): launches on one stream are ordered, so they may share; eager launches only — a captured graph must
+    bring its own workspace (allocating here during capture would put a memset node and the buffer into that graph)."""
+    ws = _SCHED_WS.get()
+    if ws is not None:
+        return ws.take()
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("residual-block launch inside a graph capture without ops.sched_workspace(...): "
+                           "the ticket words must be allocated by the owner of the graph, outside the capture")
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _SCHED.get(key)
     if buf is None:
@@ -680,7 +739,7 @@ def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
     """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
     --mode streaming): not for 2- or 3-sample hops of the tiled core, whose depthwise taps are nearly all cache reads."""
     if T == 1 and stride == 1:
-        return True     # single-frame layers: the latency-bound 32 x 32-tile kernel (csrc/frame1.hip), taps in its epilogue
+        return k <= 32  # single-frame layers: the latency-bound 32 x 32-tile kernel (csrc/frame1.hip), taps in its epilogue
     return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
 
 
@@ -720,10 +779,10 @@ def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride:
     return (y, hout) if want_hist else y
 
 
-def resblock_supported(C: int, T: int) -> bool:
+def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> bool:
     """mirror of hilc_resblock_supported (plain Python so that a tracing compiler can evaluate it; the C entry point
-    is checked against this in tests/test_api_cpu.py)"""
-    return C in (64, 96, 128, 192) and T % 4 == 0
+    is checked against this in tests/test_api_cpu.py); the streaming form walks a flat 32-bit column space"""
+    return C in (64, 96, 128, 192) and T % 4 == 0 and (not streaming or B * C * T * 4 < (1 << 32))
 
 
 def resblock_pack(wt: Tensor) -> Tensor:

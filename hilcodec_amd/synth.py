@@ -86,6 +86,21 @@ def sweep_clip(samples: int = 24000, sample_rate: int = 24000) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # Model hyper-parameters (configs/hilcodec_speech.yaml:2-38, configs/hilcodec_music.yaml:2-38)
 # --------------------------------------------------------------------------------------
+def adversarial_clips(samples: int = 24000) -> torch.Tensor:
+    """`[6,1,samples]`: digital silence, silence -> signal, +-1 square wave (full-scale clipping), a single impulse,
+    DC 0.5, a full-scale 3 kHz sine — the inputs that drive the clamp branches of the log-spectrogram
+    (conv.py:357, seanet.py:232: every bin at p = 0) and the ELU's deep-negative / large-positive tails.
+    Only the reference's outputs for them are stored (tests/golden/realistic.npz)."""
+    t = torch.arange(samples, dtype=torch.float32)
+    x = torch.zeros(6, 1, samples)
+    x[1, 0, samples // 2:] = torch.from_numpy(normalish(4711, samples - samples // 2)) * 0.1      # silence -> signal
+    x[2, 0] = torch.where((t // 37) % 2 == 0, torch.tensor(1.0), torch.tensor(-1.0))                  # +-1 square wave
+    x[3, 0, 12345] = 1.0                                                                                 # lone impulse
+    x[4, 0] = 0.5                                                                                         # DC
+    x[5, 0] = torch.sin(t * (2 * 3.141592653589793 * 3000.0 / 24000.0))                                  # full-scale sine
+    return x
+
+
 def model_kwargs(name: str = "hil_speech") -> dict:
     nq = {"hil_speech": 8, "hil_music": 12}[name]
     dropout_index = {"hil_speech": [2, 4, 8], "hil_music": [2, 4, 8, 12]}[name]

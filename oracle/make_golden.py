@@ -272,10 +272,60 @@ def main():
     offline_golden(ref, "hil_music", n_clips=1, partial_n=2)
     trained_codebook_golden(ref)
     rvq_train_golden(ref)
+    realistic_golden(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 
 
+
+
+def realistic_golden(ref):
+    """Realistic and adversarial INPUTS through the REAL reference (offline `HILCodec`): the reference's own 30.6 s speech
+    recording (`onnx/input_speech.wav`) and its SHIPPED trained codebooks (`onnx/hil_speech_deq{i}.onnx`) — the only
+    trained tensors in the tree; the conv weights stay the seeded synthetic ones (`.MISSING_LARGE_BLOBS`).  Stored: the
+    waveform (int16 PCM as shipped), the 8 codebooks, and the reference's outputs for (a) the first 10 s, (b) the six
+    adversarial clips, (c) RVQ encode of vectors 1e-6-close to sums of trained code words."""
+    import wave
+    from hilcodec_amd import wire
+    onnx_dir = os.path.join(R.REFERENCE_ROOT, "onnx")
+    with wave.open(os.path.join(onnx_dir, "input_speech.wav"), "rb") as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getframerate() == 24000
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()
+    assert pcm.shape == (734760,)          # 30.6 s; the reference encodes len // 320 * 320 = 734720 of them (test_onnx.py:53)
+    cbs = np.stack([wire.read_onnx_codebook(os.path.join(onnx_dir, f"hil_speech_deq{i}.onnx")).numpy() for i in range(8)])
+    assert cbs.shape == (8, 1024, 128) and cbs.dtype == np.float32
+    mk = synth.model_kwargs("hil_speech")
+    sd = synth.synth_state_dict("hil_speech", seed=WEIGHT_SEED)
+    for i in range(8):
+        sd[f"quantizer.layers.{i}.embed"] = torch.from_numpy(cbs[i]).clone()
+    model = R.build_offline(ref, mk, sd)
+    out = dict(pcm=pcm, codebooks=cbs, weight_seed=np.int64(WEIGHT_SEED))
+    with torch.no_grad():
+        x10 = torch.from_numpy(pcm[:240000].astype(np.float32) / 32768.0).view(1, 1, -1)
+        z = model.encoder(x10.clone())
+        q, _, loss, idx = model.quantizer(z, None, return_indices=True)
+        wav = model.decoder(q)
+        out.update(speech10_indices=t2n(idx).astype(np.int16), speech10_z_probe=t2n(z[:, :, ::25]),
+                   speech10_wav_probe=t2n(wav[:, :, ::97]), speech10_loss=t2n(loss))
+        xa = synth.adversarial_clips()
+        za = model.encoder(xa.clone())
+        qa, _, lossa, idxa = model.quantizer(za, None, return_indices=True)
+        wava = model.decoder(qa)
+        out.update(adv_indices=t2n(idxa).astype(np.int16), adv_z_probe=t2n(za[:, :, ::5]), adv_wav_probe=t2n(wava[:, :, ::31]),
+                   adv_loss=t2n(lossa))
+        # (c) near-tie stress on real tables: z = sum of the trained code words the reference's own bitstream selects
+        # (onnx/hil_speech_quantized.npy) + 1e-6-scale noise, then the reference's RVQ encode
+        idx_all = np.load(os.path.join(onnx_dir, "hil_speech_quantized.npy")).astype(np.int64)          # [8,1,2296]
+        F = 600
+        sel = torch.from_numpy(idx_all[:, 0, 200:200 + F])
+        zq = sum(torch.from_numpy(cbs[i])[sel[i]] for i in range(8)).t().contiguous().view(1, 128, F)
+        zq = zq + torch.from_numpy(synth.normalish(515, 128 * F)).view(1, 128, F) * 1e-6
+        qn, _, lossn, idxn = model.quantizer(zq, None, return_indices=True)
+        out.update(near_z=t2n(zq), near_indices=t2n(idxn).astype(np.int16), near_q_probe=t2n(qn[:, :, ::7]))
+    np.savez_compressed(os.path.join(OUT, "realistic.npz"), **out)
+    same = float((torch.from_numpy(t2n(idxn))[0] == sel).float().mean())
+    print("realistic: speech10 idx", idx.shape, "adv idx", idxa.shape, "near-tie: fraction equal to the bitstream's own indices", same,
+          "bytes", os.path.getsize(os.path.join(OUT, "realistic.npz")))
 
 
 def trained_codebook_golden(ref):
@@ -307,6 +357,9 @@ if __name__ == "__main__":
     if "--trained" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         trained_codebook_golden(R.load_reference())
+    elif "--realistic" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        realistic_golden(R.load_reference())
     elif "--rvq-train" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         rvq_train_golden(R.load_reference())

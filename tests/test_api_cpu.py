@@ -231,4 +231,5 @@ def test_x3_weight_cache_follows_the_weight(monkeypatch):
     del w
     gc.collect()
     assert len(engine._X3_SPLIT) == 0
-    assert engine.DECODER_GEMM == "fp32"            # the default arithmetic is the reference's
+    assert engine.ExecOptions().decoder_gemm == "fp32"            # the default arithmetic is the reference's
+    assert not hasattr(engine, "DECODER_GEMM") and not hasattr(engine, "SIDE_STREAM")     # no process-global switches

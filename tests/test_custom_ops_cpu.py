@@ -98,12 +98,17 @@ def test_dynamo_fullgraph_traces_the_module_classes():
     shapes; the same compile on real tensors with bit-exact comparison is tests/test_gpu_compile.py."""
     model, mk, es, ds = _meta_model("hil_speech")
     model.encoder._plan_cache, model.decoder._plan_cache = es, ds
+    model.encoder._plan_cache_key = model.decoder._plan_cache_key = ("meta",)        # the device the plans were folded for
     enc = torch.compile(model.encoder, fullgraph=True, backend="aot_eager")
     dec = torch.compile(model.decoder, fullgraph=True, backend="aot_eager")
     with torch.no_grad():
         z = enc(torch.empty(2, 1, 4800, device="meta"))
         w = dec(z)
     assert z.shape == (2, 128, 15) and w.shape == (2, 1, 4800)
+    # a plan folded for another device is refused instead of being baked into the graph as wrong-device constants
+    model.encoder._plan_cache_key = ("cuda:1",)
+    with pytest.raises(Exception, match="prepared for cuda:1"):
+        torch.compile(model.encoder, fullgraph=True, backend="aot_eager")(torch.empty(2, 1, 4800, device="meta"))
     # without a prepared plan the traced region refuses instead of folding weights inside the graph
     fresh = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
     with pytest.raises(Exception, match="prepare"):

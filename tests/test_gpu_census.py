@@ -16,7 +16,7 @@ def test_parity_census(name, n_clips):
     print(json.dumps(r))
     assert r["clips"] == n_clips and r["argmins"] == n_clips * (8 if name == "hil_speech" else 12) * 75
     assert r["genuine_mismatches"] == 0, r["flips"]
-    assert r["near_tie_flips"] <= max(2, r["argmins"] // 20000), r["flips"]        # near-ties are rare events
+    assert r["near_tie_flips"] <= 1, r["flips"]        # measured: 0 in 38 400 + 28 800 argmins (profiles/r02_parity_census_final.json)
     assert r["dz_max"] < 2e-5
     assert r["dwav_max_on_reference_indices"] < 1e-4
     assert r["dwav_max_end_to_end"] is not None and r["dwav_max_end_to_end"] < 1e-4

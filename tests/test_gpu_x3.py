@@ -1,6 +1,6 @@
 """GPU: the EXPERIMENTAL bf16x3 numerics mode (csrc/gemm_x3.h; opt-in, offline decoder only, never the default).
 Layer level: the split-operand GEMM against the exact fp32 kernels it mirrors (same prologues, same epilogues), on the
-decoder's shapes.  Path level: with engine.DECODER_GEMM = "bf16x3" every index is unchanged (the encoder and the RVQ
+decoder's shapes.  Path level: with the decoder's `exec_options.decoder_gemm = "bf16x3"` every index is unchanged (the encoder and the RVQ
 are not touched), the decoded waveform stays within 5e-5 of the fp32 product path and within the codec's 1e-4 bar of
 the real reference's golden waveform; the default mode is restored and bit-identical afterwards."""
 import numpy as np
@@ -111,24 +111,31 @@ def test_decoder_in_bf16x3_mode(golden, name):
             return idx, model.decoder(q)
 
     idx0, wav0 = run()
-    assert engine.DECODER_GEMM == "fp32"
-    engine.DECODER_GEMM = "bf16x3"
+    opts = model.decoder.exec_options
+    assert opts.decoder_gemm == "fp32" and engine.ExecOptions().decoder_gemm == "fp32"
+    # a second model in the same process stays in the reference's arithmetic while this one is switched (per-model state)
+    other = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
+    other.load_state_dict(synth.synth_state_dict(name, seed=7), strict=False)
+    opts.decoder_gemm = "bf16x3"
     try:
         idx1, wav1 = run()
+        with torch.no_grad():
+            wav_other = other.decoder(model.quantizer(model.encoder(x), None, return_indices=True)[0])
+        assert other.decoder.exec_options.decoder_gemm == "fp32" and torch.equal(wav_other, wav0)
     finally:
-        engine.DECODER_GEMM = "fp32"
+        opts.decoder_gemm = "fp32"
     idx2, wav2 = run()
     assert torch.equal(idx0, idx1) and torch.equal(idx1[:n].cpu(), torch.from_numpy(np.asarray(g["indices"])).long())
     d = (wav1 - wav0).abs().max().item()
     assert 0.0 < d < 5e-5, d
     assert (wav1[:n].cpu() - torch.from_numpy(np.asarray(g["wav"]))).abs().max() < 1e-4      # the reference's golden waveform
     assert torch.equal(wav2, wav0) and torch.equal(idx2, idx0)                                # the default is untouched
-    engine.DECODER_GEMM = "tf32"
+    opts.decoder_gemm = "tf32"
     try:
         with pytest.raises(RuntimeError):
             run()
     finally:
-        engine.DECODER_GEMM = "fp32"
+        opts.decoder_gemm = "fp32"
 
 
 @pytest.mark.parametrize("B,hop_frames", [(3, 1), (40, 1), (2, 3)])
@@ -155,7 +162,7 @@ def test_streaming_decoder_in_bf16x3_mode(B, hop_frames):
         return outs, [c.clone() for c in cd]
 
     ref, cd_ref = run()
-    engine.DECODER_GEMM = "bf16x3"
+    model.decoder.exec_options.decoder_gemm = "bf16x3"
     try:
         got, cd_got = run()
         for h in range(hops):
@@ -173,6 +180,6 @@ def test_streaming_decoder_in_bf16x3_mode(B, hop_frames):
                     assert torch.equal(wav, got[h - 1][1])
             assert torch.equal(g.flush(), got[hops - 1][1])
     finally:
-        engine.DECODER_GEMM = "fp32"
+        model.decoder.exec_options.decoder_gemm = "fp32"
     again, _ = run()
     assert all(torch.equal(a[1], b[1]) for a, b in zip(again, ref))

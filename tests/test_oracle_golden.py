@@ -194,3 +194,33 @@ def test_rvq_train_kat(golden):
         assert torch.equal(st[f"layers.{i}.embed"][::16], T(g["embed_rows"][i]))
         assert torch.equal(st[f"layers.{i}.ema_embed"][::16], T(g["ema_embed_rows"][i]))
         assert abs(float(st[f"layers.{i}.embed"].double().sum()) - float(g["embed_sum"][i])) < 1e-9
+
+
+def realistic_state_dict(g):
+    """seeded synthetic conv weights + the reference's SHIPPED trained codebooks (tests/golden/realistic.npz)"""
+    sd = synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"]))
+    for i in range(8):
+        sd[f"quantizer.layers.{i}.embed"] = T(g["codebooks"][i]).clone()
+    return sd
+
+
+def test_realistic_and_adversarial_inputs(golden):
+    """The oracle on the reference's own speech recording, its trained codebooks, and six adversarial clips (digital silence,
+    silence -> signal, +-1 square wave, lone impulse, DC, full-scale sine) against the REAL reference's outputs
+    (oracle/make_golden.py: realistic_golden): bit-exact, so the oracle is pinned on realistic data and on the clamp
+    branches (conv.py:357, seanet.py:232), not only on noise-like inputs."""
+    g = golden("realistic")
+    mk = synth.model_kwargs("hil_speech")
+    sd = realistic_state_dict(g)
+    with torch.no_grad():
+        x10 = T(g["pcm"][:240000].astype(np.float32) / 32768.0).view(1, 1, -1)
+        wav, _, loss, aux = O.codec_forward(sd, x10, mk)
+        assert torch.equal(aux["indices"], T(g["speech10_indices"]).long())
+        assert torch.equal(aux["z"][:, :, ::25], T(g["speech10_z_probe"])) and torch.equal(wav[:, :, ::97], T(g["speech10_wav_probe"]))
+        assert float(loss) == float(g["speech10_loss"])
+        wav_a, _, loss_a, aux_a = O.codec_forward(sd, synth.adversarial_clips(), mk)
+        assert torch.equal(aux_a["indices"], T(g["adv_indices"]).long())
+        assert torch.equal(aux_a["z"][:, :, ::5], T(g["adv_z_probe"])) and torch.equal(wav_a[:, :, ::31], T(g["adv_wav_probe"]))
+        assert torch.isfinite(wav_a).all() and float(loss_a) == float(g["adv_loss"])
+        q, _, _, idx = O.rvq_forward(sd, T(g["near_z"]), None, 8)
+        assert torch.equal(idx, T(g["near_indices"]).long()) and torch.equal(q[:, :, ::7], T(g["near_q_probe"]))

@@ -53,12 +53,10 @@ if args.mode == "streaming":
 with torch.no_grad():
     step()
     torch.cuda.synchronize()
-    t = ops.LaunchTimer()
-    ops.TIMER = t
-    for _ in range(args.reps):
-        step()
-    torch.cuda.synchronize()
-    ops.TIMER = None
+    with ops.timed_launches() as t:
+        for _ in range(args.reps):
+            step()
+        torch.cuda.synchronize()
 n = len(t.records) // args.reps
 agg = {}
 order = []
