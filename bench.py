@@ -70,6 +70,8 @@ def parse():
                     "(decoder of hop i-1 beside the encoder of hop i on a second HIP stream; +1 hop output latency)")
     ap.add_argument("--graph", action="store_true", help="streaming mode: replay each hop as one HIP graph "
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
+    ap.add_argument("--groups", type=int, default=1, help="with --graph (not --pipeline): split the streams into this many groups whose "
+                    "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     ap.add_argument("--emulate-rank", type=int, default=None, help="with --emulate-world W: run rank r's shard of the W-GPU job in this one process")
@@ -221,7 +223,7 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
     return step, n_clips * T / 24000.0, {"model": model, "sd": sd, "mk": mk, "last": last}
 
 
-def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool):
+def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1):
     from hilcodec_amd import synth
     from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
     mk = synth.model_kwargs(name)
@@ -237,7 +239,8 @@ def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, 
     ctx = {"model": model, "sd": sd, "mk": mk, "xs": xs, "hop": hop, "nq": nq}
     if graph:
         from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
-        ctx["make_hopper"] = lambda: (PipelinedHop if pipeline else GraphedHop)(model, n_streams, hop, nq, dev)
+        ctx["make_hopper"] = lambda: (PipelinedHop(model, n_streams, hop, nq, dev) if pipeline
+                                      else GraphedHop(model, n_streams, hop, nq, dev, groups=groups))
         ctx["hopper"] = ctx["make_hopper"]()
 
         def step(i):
@@ -297,11 +300,13 @@ def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
     out["configs[2]"] = line(f"hil_music, batch={clips}x1 s 24 kHz, Nq=12, offline encode+RVQ+decode", "hil_music", step, audio, 3, 1)
     del step, _ctx
     torch.cuda.empty_cache()
-    for key, pipeline in (("configs[3] graph", False), ("configs[3] pipelined graph", True)):
-        step, audio, _ctx = streaming_workload("hil_speech", streams, 0, dev, True, pipeline)
+    for key, pipeline, groups in (("configs[3] graph", False, 1), ("configs[3] graph, 2 stream groups", False, 2),
+                                  ("configs[3] pipelined graph", True, 1)):
+        step, audio, _ctx = streaming_workload("hil_speech", streams, 0, dev, True, pipeline, groups)
         out[key] = line(f"hil_speech streaming, hop=320, {streams} concurrent streams, Nq=8, 22+30 caches per stream resident in HBM, "
-                        "one HIP-graph replay per hop" + (", decoder of hop i-1 pipelined beside the encoder of hop i "
-                                                          "(+1 hop = 13.3 ms output latency)" if pipeline else ""),
+                        "one HIP-graph replay per hop"
+                        + (", streams in 2 groups on parallel HIP streams inside the graph (same arithmetic, no added latency)" if groups > 1 else "")
+                        + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop = 13.3 ms output latency)" if pipeline else ""),
                         "hil_speech", step, audio, 40, 4)
         del step, _ctx
         torch.cuda.empty_cache()
@@ -330,7 +335,7 @@ def main():
     if args.mode == "offline":
         step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev)
     else:
-        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline)
+        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups)
         if args.graph:
             args.no_launch_timing = True
     model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]
@@ -387,6 +392,7 @@ def main():
         else:
             workload = (f"{name} streaming, hop=320, {B} concurrent streams per GPU, Nq={nq}, 22+30 caches per stream "
                         f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else "")
+                        + (f", streams in {args.groups} groups on parallel HIP streams inside the graph" if args.graph and args.groups > 1 and not args.pipeline else "")
                         + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop output latency)"
                            if args.graph and args.pipeline else ""))
         if args.emulate_world:

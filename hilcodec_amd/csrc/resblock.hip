@@ -168,10 +168,7 @@ struct WeightPipe {
 };
 
 // wt: this wave class's part of the packed matrix;  X: LDS tile;  colblk: the wave's 32-column block
-// SWAP = false: D[channel][time] (weights = A operand); true: D[time][channel] (activations = A operand) — the same
-// products in the same k order, only the accumulator layout differs (a lane then owns ONE channel and, register by
-// register, time steps of it: the depthwise convs become register arithmetic, see resblock_wave_kernel).
-template <class K, bool SWAP = false>
+template <class K>
 __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
                                            WeightPipe<K>& wp, int colblk, int lane) {
   constexpr int C = K::CH, XS = K::XS;
@@ -216,10 +213,8 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
-        if constexpr (SWAP) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j], wp.a[cur][j][i], acc[i], 0, 0, 0);
-        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
 #else
-        static_assert(!SWAP, "the asm form exists for the column-block kernel only");
         if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
         else
@@ -733,319 +728,6 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
 #undef STAMP
 }
 
-
-// =====================================================================================================================
-// Offline fp32 form with WAVE-PRIVATE COLUMNS (round 3).  Same tile (128 columns = 120 outputs + 8 halo), same arithmetic,
-// but a wave owns its 32-column block through the WHOLE tile and both GEMMs run with swapped MFMA operand roles, so the
-// accumulators come out as D[time][channel]: a lane holds one channel and — after 8 v_permlane32_swap per 32x32 block —
-// 16 CONSECUTIVE time steps of it (lanes 0-31: columns 0-15 of the block, lanes 32-63: columns 16-31).  Consequences:
-//   * the depthwise convs (+ bias, ELU / scale) are FMAs on the accumulator registers with per-lane tap registers: the
-//     accumulator -> LDS -> register round trips P2/P3 and P5 of the column-block kernel are gone;
-//   * the only data a wave needs from another wave are the 4 columns in front of its block (the previous wave's last 4
-//     pointwise outputs, per conv): 2 barriers per tile instead of 7 (4 at C = 192, where two waves share a column block
-//     and exchange their halves of the channels);
-//   * x is loaded, and y stored, by the wave that owns the columns: lane = (row r of 8, 16-B piece of the 128-B line),
-//     8 full lines per instruction; the shortcut stays in registers as before.  The output goes through the wave's own
-//     LDS columns once to get from the (channel, 16 time steps) layout to rows.
-// Per tile and wave (C = 64): ~112 LDS instructions instead of 161; VALU count unchanged (~800: ELU, taps).
-// LDS row stride 132 floats: the a2 / output writes are 16 B per lane at a stride of one row (32 lanes on 4 banks with 128).
-template <int C>
-struct WCfg {
-  static constexpr bool X3 = false;
-  static constexpr int CH = C;
-  static constexpr int CB = C / 32;
-  static constexpr int NCOL = 128;
-  static constexpr int XS = 132;
-  static constexpr int TO = NCOL - 8;
-  static constexpr int NW = C >= 192 ? 8 : 4;
-  static constexpr int NT = 64 * NW;
-  static constexpr int RH = NW / 4;                  // waves w and w + 4 share a column block, each owns CB / RH channel blocks
-  static constexpr int CBW = CB / RH;
-  static constexpr int ROWS = 32 * CBW;              // channels a wave stages in P0 and stores at the end of the tile
-  static constexpr int RW = ROWS / 8;                // x registers (float4) per lane
-  static constexpr int KP = C >= 128 ? 4 : 8;
-  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? 3 : 2);
-#ifndef HILC_RESW_MINW
-#define HILC_RESW_MINW 2
-#endif
-  static constexpr int MINW = HILC_RESW_MINW;
-  // halo exchange buffers: one per conv, or ONE shared by both where a third barrier (after E1) orders the second conv's
-  // writes behind the first conv's reads — C = 192 has that barrier anyway (two waves share a column block), C = 128 takes it
-  // to stay at two workgroups per CU (LDS: 66 KB tile + 6 KB taps + 6 KB exchange)
-  static constexpr int HXN = (RH == 2 || C >= 128) ? 1 : 2;
-  static constexpr bool MIDBAR = HXN == 1;
-};
-
-// accumulator block -> 16 consecutive time steps per lane: V(j), j = 4u + e, sits in register 4*G(u) + e with G = {0,2,1,3}
-__device__ __forceinline__ void block_time_order(f32x16& a) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const float lo = a[4 * g + e], hi = a[4 * (g + 2) + e];
-      const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-      const unsigned p0 = p[0], p1 = p[1];
-      a[4 * g + e] = __uint_as_float(p0);
-      a[4 * (g + 2) + e] = __uint_as_float(p1);
-    }
-  }
-}
-#define HILC_BV(a, j) ((a)[4 * ((((j) >> 2) & 1) * 2 + (((j) >> 3) & 1)) + ((j) & 3)])
-
-template <int C>
-__global__ __launch_bounds__((WCfg<C>::NT), (WCfg<C>::MINW)) void resblock_wave_kernel(ResArgs a) {
-  using K = WCfg<C>;
-  constexpr int CBW = K::CBW, NT = K::NT, RW = K::RW, XS = K::XS, TO = K::TO, ROWS = K::ROWS;
-  __shared__ __attribute__((aligned(16))) float X[C * XS];
-  __shared__ __attribute__((aligned(16))) float DW[C * DWS];
-  __shared__ __attribute__((aligned(16))) float HX[K::HXN][3][C][4];   // [conv][boundary after column block 0..2][channel][last 4 columns]
-  __shared__ long s_next;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int colblk = wave & 3;
-  const int wclass = wave >> 2;
-  const int rowblk0 = wclass * CBW;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int T = a.T;
-  for (int e = tid; e < C * DWS; e += NT) {
-    const int m = e / DWS, j = e - m * DWS;
-    float v;
-    if (j < 5) v = a.dw1_w[m * 5 + j];
-    else if (j == 5) v = a.dw1_b[m];
-    else if (j < 11) v = a.dw2_w[m * 5 + (j - 6)];
-    else v = a.dw2_b[m];
-    DW[e] = v;
-  }
-  // row layout of the wave's 32 columns: lane = (row r8 of 8, 16-B piece pc of the 128-B line)
-  const int r8 = lane >> 3, pc = lane & 7;
-  const int row0 = wclass * ROWS + r8;             // this lane's rows: row0 + 8 i
-  const int ccol = colblk * 32 + pc * 4;           // tile column of this lane's piece
-  struct TileCols { long b; int t; bool t_in; };
-  auto columns_of = [&](long tile) -> TileCols {
-    TileCols s;
-    s.b = tile / a.tiles;
-    s.t = (int)(tile - s.b * a.tiles) * TO - 8 + ccol;
-    s.t_in = s.t >= 0 && s.t < T;
-    return s;
-  };
-  auto xrow = [&](const TileCols& s, int m) -> const f32x4* {
-    return reinterpret_cast<const f32x4*>(a.x + s.b * (long)C * T + (long)m * T + (s.t_in ? s.t : 0));
-  };
-  float touch = 0.f;
-  constexpr int LPR = 4;                            // 128-B lines per tile row
-  constexpr int NTOUCH = (C * LPR + NT - 1) / NT;
-  float tv[NTOUCH];
-#pragma unroll
-  for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
-  long tile = blockIdx.x;
-  TileCols cs = columns_of(tile < a.total_tiles ? tile : 0);
-  f32x4 xr[RW];
-  if (tile < a.total_tiles) {
-#pragma unroll
-    for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, row0 + 8 * i);
-  }
-  lds_barrier();   // DW visible
-  while (tile < a.total_tiles) {
-    constexpr bool TICKETS = K::NW == 4;
-    if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after the first barrier
-    const float* w1t = a.w1t + (long)wclass * (C * C / K::RH);
-    const float* w2t = a.w2t + (long)wclass * (C * C / K::RH);
-    asm volatile("" : "+s"(w1t), "+s"(w2t));
-    WeightPipe<K> wp;
-    wp.prefetch(w1t, lane);
-    // ---- P0: a1 = ELU(pre * x) of the wave's own columns -> LDS (the x registers stay live: shortcut)
-    {
-      lptr_t xp = (lptr_t)(X + row0 * XS + ccol);
-#pragma unroll
-      for (int i = 0; i < RW; ++i) *(lvec_t)(xp + i * 8 * XS) = prologue4v(zero_unless(cs.t_in, xr[i]), a.pre_scale, 1);
-    }
-#pragma unroll
-    for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
-    if constexpr (K::RH == 2) lds_barrier();         // the partner wave staged the other half of the rows
-
-    f32x16 acc[CBW];
-    gemm_phase<K, true>(w1t, X, acc, wp, colblk, lane);          // H1[time][channel]
-    wp.prefetch(w2t, lane);
-    // ---- E1: a2 = ELU(dw1(H1) + b1) on the accumulators
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) block_time_order(acc[i]);
-    if (colblk < 3 && h == 1) {                                   // the next wave's lower half needs my last 4 columns
-#pragma unroll
-      for (int i = 0; i < CBW; ++i)
-        *reinterpret_cast<f32x4*>(&HX[0][colblk][32 * (rowblk0 + i) + l31][0]) =
-            f32x4{HILC_BV(acc[i], 12), HILC_BV(acc[i], 13), HILC_BV(acc[i], 14), HILC_BV(acc[i], 15)};
-    }
-    lds_barrier();
-    const long next = (TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x;
-    const bool clip_start = __builtin_amdgcn_readfirstlane(cs.t - ccol) < 0;    // uniform: t0 = -8, columns 0..7 are t < 0
-    {
-      lptr_t xo = (lptr_t)(X + (32 * rowblk0 + l31) * XS + colblk * 32 + 16 * h);
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int c = 32 * (rowblk0 + i) + l31;
-        f32x4 hl = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (colblk > 0) hl = *reinterpret_cast<const f32x4*>(&HX[0][colblk - 1][c][0]);
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(&DW[c * DWS]);
-        const f32x2 wb = *reinterpret_cast<const f32x2*>(&DW[c * DWS + 4]);
-        float v[20];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {     // lower half: the previous block's columns (LDS); upper half: the lower half's columns 12..15
-          const float own = HILC_BV(acc[i], 12 + j), below = hl[j];
-          const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(below), __float_as_uint(own), false, false);
-          const unsigned p0 = p[0];
-          v[j] = __uint_as_float(p0);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[4 + j] = HILC_BV(acc[i], j);
-        const float w[5] = {wa.x, wa.y, wa.z, wa.w, wb.x};
-        f32x4 o[4];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float s = 0.f;
-#pragma unroll
-          for (int t = 0; t < 5; ++t) s = fmaf(w[t], v[j + t], s);
-          o[j >> 2][j & 3] = elu_fast(__fadd_rn(s, wb.y));
-        }
-        if (clip_start && colblk == 0 && h == 0) {   // t < 0: the second conv's zero padding
-          o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-          o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) *(lvec_t)(xo + 4 * u) = o[u];
-        xo += 32 * XS;
-        asm volatile("" : "+v"(xo));
-        __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting every block's operands costs CBW * 30 registers
-      }
-    }
-    if constexpr (K::MIDBAR) lds_barrier();          // the partner wave's channels of a2 (C = 192) / the exchange buffer is free again
-
-    gemm_phase<K, true>(w2t, X, acc, wp, colblk, lane);          // H2[time][channel]
-    const bool have_next = next < a.total_tiles;
-    const TileCols cn = columns_of(have_next ? next : tile);
-    {
-      const long nt = have_next ? next : tile;
-      const long nb = nt / a.tiles;
-      const int nt0 = (int)(nt - nb * a.tiles) * TO - 8;
-      const float* nx = a.x + nb * (long)C * T;
-#pragma unroll
-      for (int i = 0; i < NTOUCH; ++i) {
-        int e = tid + NT * i;
-        e = e < C * LPR ? e : C * LPR - 1;
-        int tt = nt0 + (e % LPR) * 32;
-        tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-        tv[i] = nx[(long)(e / LPR) * T + tt];
-      }
-    }
-    // ---- E2: (dw2(H2) + b2) * out_scale on the accumulators -> the wave's LDS columns -> rows -> + x -> HBM
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) block_time_order(acc[i]);
-    if (colblk < 3 && h == 1) {
-#pragma unroll
-      for (int i = 0; i < CBW; ++i)
-        *reinterpret_cast<f32x4*>(&HX[K::HXN - 1][colblk][32 * (rowblk0 + i) + l31][0]) =
-            f32x4{HILC_BV(acc[i], 12), HILC_BV(acc[i], 13), HILC_BV(acc[i], 14), HILC_BV(acc[i], 15)};
-    }
-    lds_barrier();       // also: every wave is done reading a2 (the partner's rows at C = 192)
-    {
-      lptr_t xo = (lptr_t)(X + (32 * rowblk0 + l31) * XS + colblk * 32 + 16 * h);
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int c = 32 * (rowblk0 + i) + l31;
-        f32x4 hl = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (colblk > 0) hl = *reinterpret_cast<const f32x4*>(&HX[K::HXN - 1][colblk - 1][c][0]);
-        const f32x2 wb = *reinterpret_cast<const f32x2*>(&DW[c * DWS + 6]);   // w2_0, w2_1
-        const f32x4 wc = *reinterpret_cast<const f32x4*>(&DW[c * DWS + 8]);   // w2_2, w2_3, w2_4, b2
-        float v[20];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float own = HILC_BV(acc[i], 12 + j), below = hl[j];
-          const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(below), __float_as_uint(own), false, false);
-          const unsigned p0 = p[0];
-          v[j] = __uint_as_float(p0);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[4 + j] = HILC_BV(acc[i], j);
-        const float w[5] = {wb.x, wb.y, wc.x, wc.y, wc.z};
-        f32x4 o[4];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float s = 0.f;
-#pragma unroll
-          for (int t = 0; t < 5; ++t) s = fmaf(w[t], v[j + t], s);
-          o[j >> 2][j & 3] = __fmul_rn(__fadd_rn(s, wc.w), a.out_scale);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) *(lvec_t)(xo + 4 * u) = o[u];
-        xo += 32 * XS;
-        asm volatile("" : "+v"(xo));
-        __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisting every block's operands costs CBW * 30 registers
-      }
-    }
-    // rows of the wave's own columns (written by this wave just above: in-order LDS, no barrier)
-    {
-      const bool out_ok = ccol >= 8 && cs.t < T;
-      lptr_t xp = (lptr_t)(X + row0 * XS + ccol);
-      float* yb = a.y + cs.b * (long)C * T + cs.t;
-      constexpr int YB = RW < 8 ? RW : 8;          // rows per batch: all LDS reads of a batch, then the adds and stores
-#pragma unroll
-      for (int i0 = 0; i0 < RW; i0 += YB) {
-        f32x4 yv[YB];
-#pragma unroll
-        for (int i = 0; i < YB; ++i) yv[i] = *(lvec_t)(xp + (i0 + i) * 8 * XS);
-#pragma unroll
-        for (int i = 0; i < YB; ++i) {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(yv[i][e], xr[i0 + i][e]);
-          if (out_ok) *reinterpret_cast<f32x4*>(yb + (long)(row0 + 8 * (i0 + i)) * T) = o;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (have_next) {
-#pragma unroll
-        for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, row0 + 8 * i);
-      }
-    }
-    tile = next;
-    cs = cn;
-  }
-  if (K::NW == 4 && a.sched != nullptr && tid == 0) {          // last workgroup out re-arms the scheduler for the next launch
-    if (atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) {
-      a.sched[0] = 0;
-      a.sched[1] = 0;
-    }
-  }
-  if (touch == 1.2345678e-30f) a.y[0] = touch;
-}
-
-template <int C>
-int launch_res_wave(ResArgs a, int B, hipStream_t s) {
-  using K = WCfg<C>;
-  a.B = B;
-  a.div_magic = 0; a.div_shift = 0;
-  a.tiles = (a.T + K::TO - 1) / K::TO;
-  a.total_tiles = (long)B * a.tiles;
-  constexpr int MAXDEV = 64;
-  static std::atomic<int> resident_cache[MAXDEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return HILC_ERR_LAUNCH;
-  int cached = dev >= 0 && dev < MAXDEV ? resident_cache[dev].load(std::memory_order_relaxed) : 0;
-  if (cached == 0) {
-    int n_cu = 0, occ = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_wave_kernel<C>, K::NT, 0) != hipSuccess || occ < 1)
-      return HILC_ERR_LAUNCH;
-    cached = n_cu * occ;
-    if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
-  }
-  const long resident = cached;
-  const long blocks = a.total_tiles < resident ? a.total_tiles : resident;
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_wave_kernel<C>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
-
 template <int C, bool STREAM, bool X3 = false>
 int launch_res(ResArgs a, int B, hipStream_t s) {
   a.B = B;
@@ -1132,16 +814,11 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
-  // offline fp32: the wave-private-column form (resblock_wave_kernel) where it measured faster; HILC_RES_WAVE_MASK bit 0: C = 64,
-  // 1: 96, 2: 128, 3: 192 (A/B builds)
-#ifndef HILC_RES_WAVE_MASK
-#define HILC_RES_WAVE_MASK 15
-#endif
   switch (C) {
-    case 64: return (HILC_RES_WAVE_MASK & 1) ? launch_res_wave<64>(a, B, (hipStream_t)stream) : launch_res<64, false>(a, B, (hipStream_t)stream);
-    case 96: return (HILC_RES_WAVE_MASK & 2) ? launch_res_wave<96>(a, B, (hipStream_t)stream) : launch_res<96, false>(a, B, (hipStream_t)stream);
-    case 128: return (HILC_RES_WAVE_MASK & 4) ? launch_res_wave<128>(a, B, (hipStream_t)stream) : launch_res<128, false>(a, B, (hipStream_t)stream);
-    case 192: return (HILC_RES_WAVE_MASK & 8) ? launch_res_wave<192>(a, B, (hipStream_t)stream) : launch_res<192, false>(a, B, (hipStream_t)stream);
+    case 64: return launch_res<64, false>(a, B, (hipStream_t)stream);
+    case 96: return launch_res<96, false>(a, B, (hipStream_t)stream);
+    case 128: return launch_res<128, false>(a, B, (hipStream_t)stream);
+    case 192: return launch_res<192, false>(a, B, (hipStream_t)stream);
     default: return HILC_ERR_UNSUPPORTED;
   }
 }

@@ -77,24 +77,35 @@ class StateBlock:
 class GraphedHop:
     """model: `hilcodec_amd.models.hilcodec.streaming.HILCodec` (eval, reparameterisations removed).
     `step(x)` consumes `[B,1,hop]` samples (copied into the static input) and returns (indices `[n,B,T]`, wav `[B,1,hop]`)
-    as views of static buffers that a later `step` overwrites (each parity has its own pair)."""
+    as views of static buffers that a later `step` overwrites (each parity has its own pair).
 
-    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 2):
+    `groups` > 1: the streams are split into that many contiguous groups, each with its own state blocks, and the graph
+    runs the groups' chains (encoder -> RVQ -> dequantiser -> decoder) side by side on separate HIP streams.  Streams are
+    independent, so this is the same arithmetic on the same data — outputs bit-identical to `groups=1`, NO added latency
+    (unlike PipelinedHop) — but every launch of a hop covers the chip only 1.3-4 times at 1024 streams, and two or more
+    independent chains fill each other's partly-filled last rounds."""
+
+    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 2, groups: int = 1):
         self.model, self.n = model, n
         self.device = device
+        groups = max(1, min(int(groups), batch))
+        self.bounds = [(batch * g // groups, batch * (g + 1) // groups) for g in range(groups)]
         self.x = torch.zeros(batch, 1, hop, device=device)
-        self.state = (StateBlock(model, batch, device), StateBlock(model, batch, device))
+        # per group: a ping-pong pair of state blocks (a cache tensor is [streams, C, pad]: a group's slice must be contiguous)
+        self.gstate = [(StateBlock(model, hi - lo, device), StateBlock(model, hi - lo, device)) for lo, hi in self.bounds]
         self.parity = 0                       # the block holding the CURRENT caches (input of the next hop)
-        self.spec_side = torch.cuda.Stream(device)
-        self.sched = ops.SchedWorkspace(device)      # ticket words of this object's residual-block launches (one slot each)
+        # the STFT side branch (engine._early_spectra) only for a single chain: with several chains the launches of the other
+        # groups already fill the idle CUs, and a fork of a forked stream inside one capture crashes hipStreamEndCapture (ROCm 7.2)
+        self.spec_side = [torch.cuda.Stream(device) if groups == 1 else None for _ in self.bounds]
+        self.chain = [None] + [torch.cuda.Stream(device) for _ in self.bounds[1:]]      # group 0 runs on the capture stream
+        self.sched = [ops.SchedWorkspace(device) for _ in self.bounds]    # ticket words: one workspace per concurrent chain
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):          # builds every lazily cached table (folded weights, codebooks, scheduler words)
+            for _ in range(warmup):          # builds every lazily cached table (folded weights, codebooks)
                 self._hop(0)
                 self._hop(1)
-            self.state[0].zero_()
-            self.state[1].zero_()
+            self._zero()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graphs, self.outs = [], []
@@ -104,19 +115,46 @@ class GraphedHop:
                 out = self._hop(p)
             self.graphs.append(g)
             self.outs.append(out)
-        self.state[0].zero_()
-        self.state[1].zero_()
+        self._zero()
 
-    def _hop(self, p: int) -> Tuple[Tensor, Tensor]:
+    @property
+    def state(self):
+        """(block A, block B) of a single-group schedule (the form tests and callers of earlier rounds use)"""
+        if len(self.gstate) != 1:
+            raise RuntimeError("GraphedHop.state: the streams are split into groups — use .gstate[g]")
+        return self.gstate[0]
+
+    def _zero(self) -> None:
+        for a, b in self.gstate:
+            a.zero_()
+            b.zero_()
+
+    def _chain(self, g: int, p: int) -> Tuple[Tensor, Tensor]:
         m = self.model
-        src, dst = self.state[p], self.state[p ^ 1]
-        with ops.sched_workspace(self.sched):
-            with _spectra_on(m.encoder, self.spec_side):
-                z, _ = m.encoder(self.x, *src.enc, cache_out=dst.enc)
+        lo, hi = self.bounds[g]
+        src, dst = self.gstate[g][p], self.gstate[g][p ^ 1]
+        x = self.x[lo:hi]
+        with ops.sched_workspace(self.sched[g]):
+            with _spectra_on(m.encoder, self.spec_side[g]):
+                z, _ = m.encoder(x, *src.enc, cache_out=dst.enc)
             idx = m.quantizer(z, self.n)
             q = m.dequantizer(idx, self.n)
             wav, _ = m.decoder(q, *src.dec, cache_out=dst.dec)
         return idx, wav
+
+    def _hop(self, p: int) -> Tuple[Tensor, Tensor]:
+        if len(self.bounds) == 1:
+            return self._chain(0, p)
+        main = torch.cuda.current_stream(self.device)
+        outs = [None] * len(self.bounds)
+        for g in range(1, len(self.bounds)):              # fork
+            self.chain[g].wait_stream(main)
+            with torch.cuda.stream(self.chain[g]):
+                outs[g] = self._chain(g, p)
+        outs[0] = self._chain(0, p)
+        for g in range(1, len(self.bounds)):              # join
+            main.wait_stream(self.chain[g])
+        return torch.cat([o[0] for o in outs], dim=1), torch.cat([o[1] for o in outs], dim=0)
 
     @property
     def cache_enc(self) -> List[Tensor]:
@@ -130,7 +168,9 @@ class GraphedHop:
         """zero history, or resume from caches saved earlier (`wire.save_cache` / `e_in*`, `d_in*`)"""
         with torch.no_grad():
             self.parity = 0
-            self.state[0].load_(cache_enc, cache_dec)
+            for (lo, hi), (a, _b) in zip(self.bounds, self.gstate):
+                a.load_(None if cache_enc is None else [c[lo:hi] for c in cache_enc],
+                        None if cache_dec is None else [c[lo:hi] for c in cache_dec])
 
     def step(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         self.x.copy_(x)

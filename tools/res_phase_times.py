@@ -5,10 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the stamp hook is compiled out of the product library (it would be process-global state): build a debug copy
 DBG = os.path.join(ROOT, "gpurun_out", "libhilcodec_amd_stamps.so")
-if not os.path.isfile(DBG):
+EXTRA = [f for f in os.environ.get("HILC_STAMP_FLAGS", "").split() if f]
+if os.environ.get("HILC_STAMP_LIB"):          # a stamped library built beforehand (__graft_entry__.compile_library(..., defines=("HILC_DEBUG_STAMPS",)))
+    DBG = os.path.abspath(os.environ["HILC_STAMP_LIB"])
+elif not os.path.isfile(DBG) or EXTRA:
     os.makedirs(os.path.dirname(DBG), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                    "-ffp-contract=off", "-DHILC_DEBUG_STAMPS", "-o", DBG] + sorted(glob.glob(os.path.join(ROOT, "hilcodec_amd", "csrc", "*.hip"))),
+                    "-ffp-contract=off", "-DHILC_DEBUG_STAMPS", *EXTRA, "-o", DBG] + sorted(glob.glob(os.path.join(ROOT, "hilcodec_amd", "csrc", "*.hip"))),
                    check=True)
 os.environ["HILC_LIB"] = DBG
 import torch
@@ -42,5 +45,7 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
           + "/".join(f"{q:.0f}" for q in qs) + f"; kernel {ms:.3f} ms -> sum(ticks)/ms = {tt.sum().item() / ms / 1e6:.2f} G tile-ticks per second"
           f" = {tt.sum().item() / ms / 1e6 / 2.4 / 256:.2f} tiles in flight per CU if a tick is a 2.4 GHz cycle")
     names = ["P0 ELU(regs)", "G1", "P2 acc->lds", "P3 dw+ELU", "G2", "P5 acc->lds", "P6 dw+store+prefetch"]
+    if os.environ.get("HILC_STAMP_NAMES") == "wave":     # resblock_wave_kernel's stamps
+        names = ["P0 ELU->LDS", "G1", "reorder+halo out+barrier", "E1 dw1+ELU->LDS", "G2", "reorder+halo out+barrier", "E2 dw2->LDS->rows+x->HBM, next x"]
     mf = (C // 2) * (C // 32) * 64
     print(f"C={C}: total {tot:.0f} ticks; ideal MFMA per GEMM {mf} cyc; " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
