@@ -324,9 +324,10 @@ struct Dw5RegEpilogue {
 #define HILC_WR_GB 4     // 4-column groups per batch (the shortcut loads of a batch are in flight while the previous batch computes)
 #endif
 
-  // FULL: every column of the tile lies inside [0, T) (uniform) — only the tile's first 4 columns (halo) are not stored
-  template <bool FULL>
-  __device__ __forceinline__ void body(f32x16 (&acc)[4], int mrow0, long b, int t0, int lane) const {
+  __device__ void run_wr(f32x16 (&acc)[4], int mrow0, long ntile, int lane) const {
+    const long b = ntile / tiles;
+    const int t0 = (int)(ntile - b * tiles) * STEP - 4;
+    const bool FULL = t0 + BN <= T;      // uniform: every column of the tile lies inside [0, T)
     constexpr int GB = HILC_WR_GB;
     const int h = lane >> 5;
     const int m = mrow0 + (lane & 31);
@@ -344,7 +345,7 @@ struct Dw5RegEpilogue {
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
         const int G = batch * GB + g;
-        if ((G > 0 && FULL) || live(G)) rq[batch & 1][g] = *reinterpret_cast<const f32x4*>(rrow + 4 * G);
+        if (live(G)) rq[batch & 1][g] = *reinterpret_cast<const f32x4*>(rrow + 4 * G);
       }
     };
     if (RES) load_res(0);
@@ -382,18 +383,47 @@ struct Dw5RegEpilogue {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = elu_fast(o[e]);
         }
-        if ((G > 0 && FULL) || live(G)) *reinterpret_cast<f32x4*>(yrow + 4 * G) = o;
+        if (live(G)) *reinterpret_cast<f32x4*>(yrow + 4 * G) = o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) prev[j] = v[4 + j];
       }
     }
   }
+};
+
+// Pointwise epilogue of the wave-row GEMM form for flat (clip, t) columns without a shortcut (the up-sampling layers):
+// lane (c, h) holds 64 consecutive columns of channel m0 + c, so the rows leave as sixteen 16-B stores per lane straight
+// from the accumulators — no LDS transpose, no barrier.  Same arithmetic as PwEpilogue (bias, then scale, separately
+// rounded).  M % 128 == 0, T % 4 == 0 (a 4-column group never straddles clips), y 16-B aligned, ncols < 2^31.
+struct PwRegEpilogue {
+  float* y;
+  const float* bias;
+  int M, T;
+  long ncols;
+  unsigned t_magic, t_shift;   // n / T for n < 2^31
+  float out_scale;
 
   __device__ void run_wr(f32x16 (&acc)[4], int mrow0, long ntile, int lane) const {
-    const long b = ntile / tiles;
-    const int t0 = (int)(ntile - b * tiles) * STEP - 4;
-    if (t0 + BN <= T) body<true>(acc, mrow0, b, t0, lane);
-    else body<false>(acc, mrow0, b, t0, lane);
+    const int h = lane >> 5;
+    const int m = mrow0 + (lane & 31);
+    const float bv = bias != nullptr ? bias[m] : 0.f;
+    const long n0 = ntile * BN + 64 * h;                 // this lane's first column of the flattened axis
+    wr_time_order(acc);
+    unsigned b = __umulhi((unsigned)(n0 < ncols ? n0 : 0), t_magic) >> t_shift;
+    int t = (int)((n0 < ncols ? n0 : 0) - (long)b * T);
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = HILC_WR_V(acc, 4 * G + e);
+        if (bias != nullptr) a = __fadd_rn(a, bv);
+        o[e] = __fmul_rn(a, out_scale);
+      }
+      if (n0 + 4 * G < ncols) *reinterpret_cast<f32x4*>(y + ((long)b * M + m) * (long)T + t) = o;
+      t += 4;
+      if (t >= T) { t = 0; ++b; }
+    }
   }
 };
 

@@ -2,7 +2,9 @@
 # Round-end measurement on the GPU box: bench lines + rocprofv3 kernel trace + the two PMC passes
 # (FETCH_SIZE / WRITE_SIZE collected separately, never together with a trace domain), condensed by
 # tools/summarize_profile.py.  Usage (from the repo root, on the GPU box):  bash tools/profile_run.sh <tag>
-# Everything lands in gpurun_out/<tag>/ ; copy the summaries you want to keep into profiles/.
+# Everything lands in gpurun_out/<tag>/ ; copy the summaries you want to keep into profiles/.  .git does not travel to the GPU
+# box: pass the commit as HILC_GIT_SHA=$(git rev-parse --short=12 HEAD) in the gpurun command (the summary is stamped with it
+# and with a hash of the kernel sources; bench.py marks roofline.traffic stale when the sources have changed since).
 TAG=${1:-profile}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
@@ -11,6 +13,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --model hil_music --no-cpu-baseline > $O/bench_hil_music.json 2>> $O/bench.err
 python bench.py --mode streaming --no-cpu-baseline > $O/bench_streaming.json 2>> $O/bench.err
 python bench.py --mode streaming --graph --no-cpu-baseline > $O/bench_streaming_graph.json 2>> $O/bench.err
+python bench.py --mode streaming --graph --groups 2 --no-cpu-baseline > $O/bench_streaming_graph_groups2.json 2>> $O/bench.err
 python bench.py --mode streaming --graph --pipeline --no-cpu-baseline > $O/bench_streaming_pipelined.json 2>> $O/bench.err
 python tools/layer_profile.py > $O/layer_table.txt 2>> $O/bench.err
 python tools/layer_profile.py --mode streaming --batch 1024 > $O/layer_table_streaming.txt 2>> $O/bench.err
