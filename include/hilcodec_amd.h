@@ -113,7 +113,7 @@ int hilc_resblock_supported(int C, int T);
 /* ---- EXPERIMENTAL numerics mode "bf16x3" (csrc/gemm_x3.h) — opt-in, decoder side only, never the default --------
  * The layer's GEMM runs on the bf16 matrix pipe with both operands split into two bf16 parts (three products, fp32
  * accumulation): operands carry 16 significant bits instead of 24.  Nothing in the reference corresponds to it; the
- * product calls these entry points only when the caller asks for it (hilcodec_amd.engine.DECODER_GEMM = "bf16x3"),
+ * product calls these entry points only when the caller asks for it (the decoder module's `exec_options.decoder_gemm = "bf16x3"`),
  * and only for decoder layers, so the encoder, the RVQ and therefore every index stay exact fp32.
  * hilc_x3_split_weights: k-major fp32 `[K][M]` -> `wsplit` = `[2][K][M]` bf16 (head, head of the remainder).
  * hilc_dws_conv_x3 / hilc_up_conv_x3: as hilc_dws_conv (ksize 5, stride 1) / hilc_up_conv_expanded (in_elu = 1)

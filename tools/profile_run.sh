@@ -19,9 +19,9 @@ python tools/layer_profile.py > $O/layer_table.txt 2>> $O/bench.err
 python tools/layer_profile.py --mode streaming --batch 1024 > $O/layer_table_streaming.txt 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 STEPS=4; WARM=2
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o stats -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing > $O/trace_bench.json 2> $O/trace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o stats -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing --no-other-configs > $O/trace_bench.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing --no-other-configs > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-clock-probe --no-launch-timing --no-other-configs > /dev/null 2> $O/pmc_write.err
 cd $R
 mkdir -p $O/flat
 for f in $(find $O/trace $O/pmc_fetch $O/pmc_write -name "*.csv"); do cp $f $O/flat/$(basename $f); done
