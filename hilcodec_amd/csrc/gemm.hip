@@ -342,14 +342,6 @@ static int up_conv_entry(const float* x, const float* hist, float* hist_out, con
     auto lin = [&](auto bop) {
       bop.x = x; bop.w = decltype(bop)::kExpanded ? tr_w_expanded : tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
       bop.in_scale = in_scale;
-#ifndef HILC_NO_WAVE_ROW
-      if (lds_epi && wr_shape(M, (ncols + BN - 1) / BN)) {     // rows stored straight from the accumulators (gemm_lin.h: wave-row form)
-        PwRegEpilogue er;
-        er.y = y; er.bias = bias; er.M = M; er.T = (int)Tout; er.ncols = ncols; er.out_scale = 1.0f;
-        div_magic((int)Tout, er.t_magic, er.t_shift);
-        return launch_lin_wr(wt, M, K, M, (ncols + BN - 1) / BN, bop, er, (hipStream_t)stream);
-      }
-#endif
       if (lds_epi) return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, el, (hipStream_t)stream);
       return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, ep, (hipStream_t)stream);
     };

@@ -391,42 +391,6 @@ struct Dw5RegEpilogue {
   }
 };
 
-// Pointwise epilogue of the wave-row GEMM form for flat (clip, t) columns without a shortcut (the up-sampling layers):
-// lane (c, h) holds 64 consecutive columns of channel m0 + c, so the rows leave as sixteen 16-B stores per lane straight
-// from the accumulators — no LDS transpose, no barrier.  Same arithmetic as PwEpilogue (bias, then scale, separately
-// rounded).  M % 128 == 0, T % 4 == 0 (a 4-column group never straddles clips), y 16-B aligned, ncols < 2^31.
-struct PwRegEpilogue {
-  float* y;
-  const float* bias;
-  int M, T;
-  long ncols;
-  unsigned t_magic, t_shift;   // n / T for n < 2^31
-  float out_scale;
-
-  __device__ void run_wr(f32x16 (&acc)[4], int mrow0, long ntile, int lane) const {
-    const int h = lane >> 5;
-    const int m = mrow0 + (lane & 31);
-    const float bv = bias != nullptr ? bias[m] : 0.f;
-    const long n0 = ntile * BN + 64 * h;                 // this lane's first column of the flattened axis
-    wr_time_order(acc);
-    unsigned b = __umulhi((unsigned)(n0 < ncols ? n0 : 0), t_magic) >> t_shift;
-    int t = (int)((n0 < ncols ? n0 : 0) - (long)b * T);
-#pragma unroll
-    for (int G = 0; G < 16; ++G) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = HILC_WR_V(acc, 4 * G + e);
-        if (bias != nullptr) a = __fadd_rn(a, bv);
-        o[e] = __fmul_rn(a, out_scale);
-      }
-      if (n0 + 4 * G < ncols) *reinterpret_cast<f32x4*>(y + ((long)b * M + m) * (long)T + t) = o;
-      t += 4;
-      if (t >= T) { t = 0; ++b; }
-    }
-  }
-};
-
 // depthwise causal conv k = 2r, stride r (down-sampling): tile covers times [o0*r - H, +128) with
 // H = round_up(r, 4); output o0 + i reads columns H - r + i*r + j, j < 2r.
 struct DwStrideEpilogue {

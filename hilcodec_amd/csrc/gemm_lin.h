@@ -8,7 +8,7 @@
 // (compiled to exec-mask branches) and run-time loader flags.  Here every global address is
 //     uniform base (SGPR, advanced once per K slice)  +  per-thread 32-bit byte offset (loop-invariant)
 // so a load costs no VALU; the ragged K tail is handled by a second, pre-computed offset set (rows clamped to
-// K-1) plus a zero scale for rows >= K (0 * finite == 0, and a non-finite sample only ever reaches its own column);
+// K-1) plus a zero scale for rows >= K (0 * finite == 0; a non-finite sample only ever reaches columns of its own clip);
 // ELU / halo-zeroing are compile-time.  Results are bit-identical to the generic core (same fmaf chain).
 #pragma once
 #include "gemm_core.h"
@@ -45,7 +45,11 @@ struct TileCols {
     const long b = ntile / tiles;
     const int t = (int)(ntile - b * tiles) * step - halo + c;
     r.ok = t >= 0 && t < T;
-    r.off = r.ok ? (unsigned)(b * (long)K * T + t) : 0u;
+    // a group outside [0, T) is loaded from the nearest group of its OWN clip and multiplied by a zero scale (RowsB): a
+    // non-finite sample then stays inside the clip it belongs to, as in the reference (pointing every invalid group at
+    // x[0] let an Inf in clip 0's first samples turn the zero padding of EVERY clip's first tile into NaN)
+    const int tc = t < 0 ? 0 : (t > T - 4 ? T - 4 : t);
+    r.off = (unsigned)(b * (long)K * T + tc);
     return r;
   }
 };
@@ -74,8 +78,9 @@ struct RowsB {
     for (int h = 0; h < BP; ++h) {
       const int r = (tid >> 5) + 8 * h;
       const int rl = r < krem ? r : krem - 1;
-      s.off[h] = lc.ok ? (lc.off + (unsigned)r * (unsigned)T) * 4u : 0u;
-      s.off_last[h] = lc.ok ? (lc.off + (unsigned)rl * (unsigned)T) * 4u : 0u;
+      const bool mapped = lc.ok || Cols::kZeroInvalid;     // halo groups read their own clip's edge group (zero scale)
+      s.off[h] = mapped ? (lc.off + (unsigned)r * (unsigned)T) * 4u : 0u;
+      s.off_last[h] = mapped ? (lc.off + (unsigned)rl * (unsigned)T) * 4u : 0u;
       s.sc_last[h] = r < krem ? s.sc : 0.f;
     }
     return s;

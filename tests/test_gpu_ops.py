@@ -489,3 +489,28 @@ def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
             y_one = ops.spec_block_conv_pre(wav.to(dev), dft_p, nyq, pw_p, bias, pw_, pb, 1 / 0.1122080159, n_fft, hop,
                                             -4.0, 2.8, True, 0.37)
             assert torch.equal(y_one, y_two), f"{(y_one - y_two).abs().max().item():.3e}"
+
+
+def test_non_finite_sample_stays_in_its_clip(env):
+    """An Inf in the first samples of clip 0 must not reach any other clip: the zero padding in front of a clip's first tile is
+    `0 * x` of a mapped dummy group, which used to be x[0, k, 0:4] for EVERY clip (0 * Inf = NaN in every clip's halo); the
+    dummy is now the clip's own edge group, so — as in the reference — a bad clip only spoils itself."""
+    ops, fold, O, dev = env
+    B, K, M, Tn = 3, 128, 128, 248
+    x = rnd(11, B, K, Tn).to(dev)
+    w = (rnd(12, K, M) / K ** 0.5).to(dev)
+    dw, db = (rnd(13, M, 5) * 0.5).to(dev), (rnd(14, M) * 0.2).to(dev)
+    for kw in (dict(in_scale=1.0, in_elu=False), dict(in_scale=0.8, in_elu=True, out_elu=True)):
+        good = ops.dws_conv(x, w, dw, db, **kw)
+        bad_x = x.clone()
+        bad_x[0, 5, 1] = float("inf")
+        bad = ops.dws_conv(bad_x, w, dw, db, **kw)
+        assert torch.equal(bad[1:], good[1:]) and torch.isfinite(bad[1:]).all()
+        assert not torch.isfinite(bad[0]).all()                      # the bad clip itself is spoiled, as in the reference
+    # strided (down-sampling) form: same loader
+    dws, dbs = (rnd(15, M, 8) * 0.3).to(dev), (rnd(16, M) * 0.1).to(dev)
+    good = ops.dws_conv(x, w, dws, dbs, stride=4, in_scale=0.9, in_elu=True)
+    bad_x = x.clone()
+    bad_x[0, 0, 0] = float("nan")
+    bad = ops.dws_conv(bad_x, w, dws, dbs, stride=4, in_scale=0.9, in_elu=True)
+    assert torch.equal(bad[1:], good[1:])
