@@ -70,7 +70,7 @@ def parse():
                     "(decoder of hop i-1 beside the encoder of hop i on a second HIP stream; +1 hop output latency)")
     ap.add_argument("--graph", action="store_true", help="streaming mode: replay each hop as one HIP graph "
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
-    ap.add_argument("--groups", type=int, default=1, help="with --graph (not --pipeline): split the streams into this many groups whose "
+    ap.add_argument("--groups", type=int, default=1, help="with --graph: split the streams into this many groups whose "
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
@@ -239,7 +239,7 @@ def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, 
     ctx = {"model": model, "sd": sd, "mk": mk, "xs": xs, "hop": hop, "nq": nq}
     if graph:
         from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
-        ctx["make_hopper"] = lambda: (PipelinedHop(model, n_streams, hop, nq, dev) if pipeline
+        ctx["make_hopper"] = lambda: (PipelinedHop(model, n_streams, hop, nq, dev, groups=groups) if pipeline
                                       else GraphedHop(model, n_streams, hop, nq, dev, groups=groups))
         ctx["hopper"] = ctx["make_hopper"]()
 
@@ -301,11 +301,11 @@ def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
     del step, _ctx
     torch.cuda.empty_cache()
     for key, pipeline, groups in (("configs[3] graph", False, 1), ("configs[3] graph, 2 stream groups", False, 2),
-                                  ("configs[3] pipelined graph", True, 1)):
+                                  ("configs[3] pipelined graph", True, 1), ("configs[3] pipelined graph, 2 stream groups", True, 2)):
         step, audio, _ctx = streaming_workload("hil_speech", streams, 0, dev, True, pipeline, groups)
         out[key] = line(f"hil_speech streaming, hop=320, {streams} concurrent streams, Nq=8, 22+30 caches per stream resident in HBM, "
                         "one HIP-graph replay per hop"
-                        + (", streams in 2 groups on parallel HIP streams inside the graph (same arithmetic, no added latency)" if groups > 1 else "")
+                        + (", streams in 2 groups on parallel HIP streams inside the graph (same arithmetic, no latency added by the grouping)" if groups > 1 else "")
                         + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop = 13.3 ms output latency)" if pipeline else ""),
                         "hil_speech", step, audio, 40, 4)
         del step, _ctx
@@ -392,7 +392,7 @@ def main():
         else:
             workload = (f"{name} streaming, hop=320, {B} concurrent streams per GPU, Nq={nq}, 22+30 caches per stream "
                         f"resident in HBM (BASELINE configs[{cfg_ix}])" + (", one HIP-graph replay per hop" if args.graph else "")
-                        + (f", streams in {args.groups} groups on parallel HIP streams inside the graph" if args.graph and args.groups > 1 and not args.pipeline else "")
+                        + (f", streams in {args.groups} groups on parallel HIP streams inside the graph" if args.graph and args.groups > 1 else "")
                         + (", decoder of hop i-1 pipelined beside the encoder of hop i (+1 hop output latency)"
                            if args.graph and args.pipeline else ""))
         if args.emulate_world:

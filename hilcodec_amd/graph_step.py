@@ -194,26 +194,33 @@ class PipelinedHop:
     State blocks as in GraphedHop; the encoder and decoder halves of a block flip on opposite parities (the decoder is
     one hop behind), the indices travel through two fixed `[n,B,T]` buffers."""
 
-    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 2):
+    def __init__(self, model, batch: int, hop: int, n: int, device: torch.device, warmup: int = 2, groups: int = 1):
+        """`groups` > 1: additionally split the streams into contiguous groups, each with its own encoder and decoder chain
+        (2 * groups HIP streams inside the graph), as in GraphedHop."""
         self.model, self.n, self.device = model, n, device
+        groups = max(1, min(int(groups), batch))
+        self.bounds = [(batch * g // groups, batch * (g + 1) // groups) for g in range(groups)]
         self.x = torch.zeros(batch, 1, hop, device=device)
-        self.state = (StateBlock(model, batch, device), StateBlock(model, batch, device))
+        self.gstate = [(StateBlock(model, hi - lo, device), StateBlock(model, hi - lo, device)) for lo, hi in self.bounds]
         self.parity = 0                       # encoder parity: the block holding the encoder caches of the next hop
         self.pending = False                  # a hop is encoded but not decoded yet
-        self.side = torch.cuda.Stream(device)
-        self.spec_side = torch.cuda.Stream(device)
-        # the two branches run concurrently: each has its own ticket words (encoder and decoder never share a slot)
-        self.sched_enc, self.sched_dec = ops.SchedWorkspace(device), ops.SchedWorkspace(device)
+        # chains: encoder of group 0 on the capture stream, every other chain on its own stream (all forked from the capture
+        # stream; a fork of a fork crashes hipStreamEndCapture on ROCm 7.2, so the STFT side branch exists for groups == 1 only)
+        self.enc_stream = [None] + [torch.cuda.Stream(device) for _ in self.bounds[1:]]
+        self.dec_stream = [torch.cuda.Stream(device) for _ in self.bounds]
+        self.spec_side = torch.cuda.Stream(device) if groups == 1 else None
+        # concurrent chains never share ticket words
+        self.sched_enc = [ops.SchedWorkspace(device) for _ in self.bounds]
+        self.sched_dec = [ops.SchedWorkspace(device) for _ in self.bounds]
         warm = torch.cuda.Stream(device)
         warm.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(warm), torch.no_grad():
-            idx = self._encode(0)
+            idx = torch.cat([self._encode(g, 0) for g in range(groups)], dim=1)
             self.idx = (torch.zeros_like(idx), torch.zeros_like(idx))
             for _ in range(warmup):
                 for p in (0, 1):
                     self._both(p)
-            self.state[0].zero_()
-            self.state[1].zero_()
+            self._zero()
         torch.cuda.current_stream(device).wait_stream(warm)
         torch.cuda.synchronize(device)
         self.graphs, self.wavs = [], []
@@ -223,35 +230,62 @@ class PipelinedHop:
                 wav = self._both(p)
             self.graphs.append(g)
             self.wavs.append(wav)
-        self.state[0].zero_()
-        self.state[1].zero_()
+        self._zero()
 
-    def _encode(self, p: int) -> Tensor:
+    @property
+    def state(self):
+        if len(self.gstate) != 1:
+            raise RuntimeError("PipelinedHop.state: the streams are split into groups — use .gstate[g]")
+        return self.gstate[0]
+
+    def _zero(self) -> None:
+        for a, b in self.gstate:
+            a.zero_()
+            b.zero_()
+
+    def _encode(self, g: int, p: int) -> Tensor:
         m = self.model
-        with ops.sched_workspace(self.sched_enc), _spectra_on(m.encoder, self.spec_side):
-            z, _ = m.encoder(self.x, *self.state[p].enc, cache_out=self.state[p ^ 1].enc)
+        lo, hi = self.bounds[g]
+        st = self.gstate[g]
+        with ops.sched_workspace(self.sched_enc[g]), _spectra_on(m.encoder, self.spec_side):
+            z, _ = m.encoder(self.x[lo:hi], *st[p].enc, cache_out=st[p ^ 1].enc)
         return m.quantizer(z, self.n)
 
-    def _decode(self, p: int) -> Tensor:
+    def _decode(self, g: int, p: int) -> Tensor:
         """decode the hop whose encoder ran with parity p^1 (its indices sit in idx[p^1]); decoder parity = p^1"""
         m = self.model
-        with ops.sched_workspace(self.sched_dec):
-            wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1], self.n), *self.state[p ^ 1].dec, cache_out=self.state[p].dec)
+        lo, hi = self.bounds[g]
+        st = self.gstate[g]
+        with ops.sched_workspace(self.sched_dec[g]):
+            wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1][:, lo:hi].contiguous(), self.n), *st[p ^ 1].dec,
+                               cache_out=st[p].dec)
         return wav
 
     def _both(self, p: int) -> Tensor:
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)                       # fork
-        with torch.cuda.stream(self.side):
-            wav = self._decode(p)
-        self.idx[p].copy_(self._encode(p))
-        main.wait_stream(self.side)                       # join
-        return wav
+        G = len(self.bounds)
+        wavs, idxs = [None] * G, [None] * G
+        for g in range(G):                                # fork: every decoder chain, and the encoder chains of groups > 0
+            self.dec_stream[g].wait_stream(main)
+            with torch.cuda.stream(self.dec_stream[g]):
+                wavs[g] = self._decode(g, p)
+            if g > 0:
+                self.enc_stream[g].wait_stream(main)
+                with torch.cuda.stream(self.enc_stream[g]):
+                    idxs[g] = self._encode(g, p)
+        idxs[0] = self._encode(0, p)
+        for g in range(G):                                # join
+            main.wait_stream(self.dec_stream[g])
+            if g > 0:
+                main.wait_stream(self.enc_stream[g])
+        self.idx[p].copy_(idxs[0] if G == 1 else torch.cat(idxs, dim=1))
+        return wavs[0] if G == 1 else torch.cat(wavs, dim=0)
 
     def reset(self) -> None:
         with torch.no_grad():
             self.parity, self.pending = 0, False
-            self.state[0].zero_()
+            for a, _b in self.gstate:
+                a.zero_()
 
     def step(self, x: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
         """x `[B,1,hop]` -> (indices of THIS hop `[n,B,T]`, wav `[B,1,hop]` of the PREVIOUS hop or None on the first
@@ -263,7 +297,7 @@ class PipelinedHop:
             wav = self.wavs[p]
         else:                                              # first hop: nothing to decode yet
             with torch.no_grad():
-                self.idx[p].copy_(self._encode(p))
+                self.idx[p].copy_(torch.cat([self._encode(g, p) for g in range(len(self.bounds))], dim=1))
             wav = None
         self.pending = True
         self.parity ^= 1
@@ -274,6 +308,6 @@ class PipelinedHop:
         if not self.pending:
             return None
         with torch.no_grad():
-            wav = self._decode(self.parity)
+            wav = torch.cat([self._decode(g, self.parity) for g in range(len(self.bounds))], dim=0)
         self.pending = False
         return wav

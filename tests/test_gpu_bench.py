@@ -39,7 +39,8 @@ def test_headline_line_small():
     assert d["ranks"]["process_group_initialized"] is False and d["ranks"]["backend"].startswith("none")
     # the short configs[2] / configs[3] lines ride in the same JSON line (the default invocation runs them at full size)
     oc = d["other_configs"]
-    assert set(oc) == {"configs[2]", "configs[3] graph", "configs[3] graph, 2 stream groups", "configs[3] pipelined graph"}
+    assert set(oc) == {"configs[2]", "configs[3] graph", "configs[3] graph, 2 stream groups", "configs[3] pipelined graph",
+                       "configs[3] pipelined graph, 2 stream groups"}
     assert oc["configs[3] graph"]["index_checksum"] == oc["configs[3] graph, 2 stream groups"]["index_checksum"]
     assert "hil_music" in oc["configs[2]"]["workload"] and all(v["value"] > 0 and v["dtype"] == "f32" for v in oc.values())
     # the traffic figure names the build it was measured on

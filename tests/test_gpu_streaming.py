@@ -217,10 +217,12 @@ def test_graphed_hop_equals_eager(groups):
         assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1])
 
 
-def test_pipelined_hop_equals_eager():
+@pytest.mark.parametrize("groups", [1, 2])
+def test_pipelined_hop_equals_eager(groups):
     """PipelinedHop (decoder of hop i-1 beside the encoder of hop i, two HIP streams inside one graph): indices of
     every hop and — one replay later — its wav bit-identical to the eager loop; flush() delivers the last hop; a
-    second pass after reset() and a continuation after flush() give the same again."""
+    second pass after reset() and a continuation after flush() give the same again.  groups = 2: the streams in two
+    groups, four chains side by side."""
     from hilcodec_amd.graph_step import PipelinedHop
     dev = torch.device("cuda:0")
     model, mk, sd = build_streaming()
@@ -234,7 +236,7 @@ def test_pipelined_hop_equals_eager():
             idx = model.quantizer(z, 8)
             wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
             eager.append((idx.clone(), wav.clone()))
-    g = PipelinedHop(model, B, 320, 8, dev)
+    g = PipelinedHop(model, B, 320, 8, dev, groups=groups)
     for rep in range(2):
         for h in range(hops):
             idx, wav = g.step(x[:, :, 320 * h: 320 * (h + 1)])

@@ -15,6 +15,7 @@ python bench.py --mode streaming --no-cpu-baseline > $O/bench_streaming.json 2>>
 python bench.py --mode streaming --graph --no-cpu-baseline > $O/bench_streaming_graph.json 2>> $O/bench.err
 python bench.py --mode streaming --graph --groups 2 --no-cpu-baseline > $O/bench_streaming_graph_groups2.json 2>> $O/bench.err
 python bench.py --mode streaming --graph --pipeline --no-cpu-baseline > $O/bench_streaming_pipelined.json 2>> $O/bench.err
+python bench.py --mode streaming --graph --pipeline --groups 2 --no-cpu-baseline > $O/bench_streaming_pipelined_groups2.json 2>> $O/bench.err
 python tools/layer_profile.py > $O/layer_table.txt 2>> $O/bench.err
 python tools/layer_profile.py --mode streaming --batch 1024 > $O/layer_table_streaming.txt 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
