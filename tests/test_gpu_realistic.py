@@ -102,6 +102,41 @@ def test_adversarial_clips_streaming(real):
     assert flips <= 1
 
 
+def test_real_speech_streaming(real):
+    """1.6 s of the reference's speech recording (from 1.0 s in: speech, not the leading silence) hop by hop through the
+    streaming model with the trained codebooks, four streams at different offsets in one batch, against the oracle's
+    streaming path: z within 2e-5, every index equal (a differing frame must be an fp64 near-tie, at most one), audio
+    decoded from the reference's own indices within 1e-4."""
+    from oracle import hilcodec_oracle as O
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
+    g, mk, sd, _ = real
+    smk = {k: v for k, v in mk.items() if k not in ("spec_learnable", "causal", "pad_mode")}
+    sm = StreamingHILCodec(24000, **smk).eval()
+    sm.load_offline_state_dict(sd)
+    sm.remove_weight_reparameterizations()
+    hops, B = 120, 4
+    pcm = g["pcm"].astype(np.float32) / 32768.0
+    x = torch.stack([T(pcm[24000 + 7000 * b: 24000 + 7000 * b + 320 * hops]) for b in range(B)]).view(B, 1, -1)
+    p = O.stream_prepare(sd, mk)
+    ce_o, cd_o = O.stream_init_cache(mk, B)
+    ce, cd = sm.initialize_cache(x.to(DEV))
+    flips, dz, dw = 0, 0.0, 0.0
+    with torch.no_grad():
+        for h in range(hops):
+            xin = x[:, :, 320 * h: 320 * (h + 1)].contiguous()
+            z_o, ce_o = O.stream_encoder(p, mk, xin, ce_o)
+            idx_o = O.stream_quantize(p, z_o, 8)
+            w_o, cd_o = O.stream_decoder(p, mk, O.stream_dequantize(p, idx_o, 8), cd_o)
+            z, ce = sm.encoder(xin.to(DEV), *ce)
+            idx = sm.quantizer(z, 8)
+            w, cd = sm.decoder(sm.dequantizer(idx_o.to(DEV), 8), *cd)
+            dz = max(dz, float((z.cpu() - z_o).abs().max()))
+            dw = max(dw, float((w.cpu() - w_o).abs().max()))
+            flips += int((idx.cpu() != idx_o).any(dim=0).sum())
+    print(f"real speech, streaming: |dz|={dz:.2e} |dwav|={dw:.2e} flips={flips} of {8 * B * hops} argmins")
+    assert dz < 2e-5 and dw < 1e-4 and flips <= 1
+
+
 def test_rvq_near_ties_on_trained_tables(real):
     """z = sum of the trained code words the reference's bitstream selects + 1e-6 noise: many stages sit a hair away from a
     code word.  Every index equals the reference's; a differing frame must be an fp64 near-tie (none has been seen)."""
