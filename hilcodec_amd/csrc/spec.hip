@@ -37,6 +37,11 @@ constexpr int ES = 132;          // row stride of the epilogue transpose tile
 
 template <int N>
 struct SpecCfg {
+  static constexpr int HOP = N == 64 ? 1 : (N == 128 ? 2 : 8);   // the stage's hop is fixed with its n_fft (stage_hop below)
+  // One pad word per 16 samples keeps the strided frames of a DFT operand read off one LDS bank.  At hop 1 consecutive lanes
+  // read consecutive samples anyway: no padding, and every segment address of the kernel becomes base + immediate (the
+  // stage-0 launch spent ~350 of its ~1 240 VALU instructions per tile and wave on `u + (u >> 4)`).
+  static constexpr bool PAD = HOP > 1;
   static constexpr int CB = N / 32;                       // row blocks of both GEMMs (C == N)
   static constexpr int NB = N / 2 + 1;                    // bins
   static constexpr int KP = N <= 128 ? 4 : 2;             // k-pairs per weight register set
@@ -131,7 +136,8 @@ __device__ __forceinline__ void stream_gemm(const float* __restrict__ wt, f32x16
   }
 }
 
-__device__ __forceinline__ int padded(int u) { return u + (u >> 4); }
+template <bool PAD>
+__device__ __forceinline__ int padded(int u) { return PAD ? u + (u >> 4) : u; }
 
 // PRE (n_fft = 64, hop 1 only): the residual input is the first encoder conv of the SAME waveform tile,
 // x[m][t] = sum_j pre_w[m][j] * (pre_in_scale * wav[t-4+j]) + pre_b[m]   (seanet.py:280-286; hilc_conv_pre's arithmetic),
@@ -141,14 +147,17 @@ template <int N, bool PRE>
 __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   using K = SpecCfg<N>;
   constexpr int CB = K::CB, NB = K::NB;
-  constexpr int SEG_MAX = (((TF - 1) * (N == 64 ? 1 : (N == 128 ? 2 : 8)) + N) * 17) / 16 + 2;   // hop is fixed per stage
+  constexpr int HOP = K::HOP;
+  constexpr bool PAD = K::PAD;
+  constexpr int SEG_MAX = (((TF - 1) * HOP + N) * (PAD ? 17 : 16)) / 16 + 2;
   constexpr int SE_FLOATS = K::SROWS * TF > 64 * ES ? K::SROWS * TF : 64 * ES;                      // S, later the epilogue tile
   __shared__ __attribute__((aligned(16))) float seg[SEG_MAX];
+  __shared__ __attribute__((aligned(16))) float segs[PRE ? SEG_MAX : 4];   // PRE: pre_in_scale * segment (the first conv's input)
   __shared__ __attribute__((aligned(16))) float SE[SE_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = lane >> 5, l31 = lane & 31;
-  const int hop = a.hop;
+  constexpr int hop = HOP;
   const long b = blockIdx.x / a.tiles;
   const int f0 = (int)(blockIdx.x - b * a.tiles) * TF;
 
@@ -163,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
       float v = 0.f;
       if (t >= 0) { if (t < a.T) v = wb[t]; }
       else if (hb != nullptr && t >= -a.hist_len) v = hb[t];
-      seg[padded(i)] = v;
+      seg[padded<PAD>(i)] = v;
+      if constexpr (PRE) segs[padded<PAD>(i)] = v * a.pre_in_scale;     // scaled once per sample, not once per use
     }
     for (int i = tid; i < (K::SROWS - NB) * TF; i += 256) SE[NB * TF + i] = 0.f;
   }
@@ -176,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   {
     int off[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) off[p] = padded(col * hop + 2 * p + kh);
+    for (int p = 0; p < 8; ++p) off[p] = padded<PAD>(col * hop + 2 * p + kh);
     // (col*hop + 2p + kh) + 16*kt: padded() adds exactly 17*kt because the slice step is a multiple of 16
-    auto bop = [&](int P) -> float { return seg[off[P & 7] + 17 * (P >> 3)]; };
+    auto bop = [&](int P) -> float { return seg[off[P & 7] + (PAD ? 17 : 16) * (P >> 3)]; };
     stream_gemm<CB, K::KP, K::DEPTH, K::SETS_A>(a.dft, acc, lane, bop);
   }
   // ---- Nyquist bin's imaginary part: scalar chain in k order (lanes 0..31 own rows 0/1 = cos_0 / cos_{N/2})
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   {
     const int u0 = col * hop;
 #pragma unroll 8
-    for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded(u0 + k)], nyq_im);
+    for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded<PAD>(u0 + k)], nyq_im);
   }
   // ---- B: magnitude -> log -> normalise -> S[bin][frame]
   const SpecFinish finish = SpecFinish::make(a.mean, a.stdv, a.normalize);
@@ -240,6 +250,15 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
       if (row >= rows) continue;
       const int m = ch * 64 + row;
       const float bv = a.bias != nullptr ? a.bias[m] : 0.f;
+      // PRE: the row's five taps and bias once, before the stores (y may alias nothing here, but the compiler cannot know:
+      // inside the group loop every store forced them to be loaded again — 91 VMEM reads per tile and wave)
+      float w5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      float pb = 0.f;
+      if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w5[j] = a.pre_w[m * 5 + j];
+        pb = a.pre_b != nullptr ? a.pre_b[m] : 0.f;
+      }
       const float* er = E + row * ES + c0;
       const long off0 = ybase + (long)m * a.Tf + f0 + c0;
       f32x4 rq[4];
@@ -255,18 +274,15 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
           f32x4 rr;
           if constexpr (PRE) {
             // column c of the tile is time f0 + c (hop 1) = segment sample c + N - 1
-            float w5[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) w5[j] = a.pre_w[m * 5 + j];
             float sm[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sm[j] = seg[padded(c0 + 4 * g + j + N - 5)] * a.pre_in_scale;
+            for (int j = 0; j < 8; ++j) sm[j] = segs[padded<PAD>(c0 + 4 * g + j + N - 5)];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float acc5 = 0.f;
 #pragma unroll
               for (int j = 0; j < 5; ++j) acc5 = fmaf(w5[j], sm[e + j], acc5);
-              rr[e] = a.pre_b != nullptr ? __fadd_rn(acc5, a.pre_b[m]) : acc5;
+              rr[e] = a.pre_b != nullptr ? __fadd_rn(acc5, pb) : acc5;
             }
           } else {
             rr = rq[g];
