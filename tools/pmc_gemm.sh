@@ -17,7 +17,7 @@ import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "gemm_kernel" not in k and "gemm_lin_kernel" not in k: continue
+    if "gemm_kernel" not in k and "gemm_lin_kernel" not in k and "gemm_lin_wr_kernel" not in k: continue
     k = k.replace("(anonymous namespace)::", "").replace("hilc::", "")[:70]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k in agg:
