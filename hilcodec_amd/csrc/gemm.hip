@@ -10,6 +10,10 @@
 
 using namespace hilc;
 
+#ifndef HILC_WR_RES
+#define HILC_WR_RES 0     // 1: wave-row form also for launches with a shortcut (measured 1.4-1.9x slower: A/B builds only)
+#endif
+
 namespace {
 
 // ================================================================================================
@@ -413,9 +417,6 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
       // depthwise taps on the accumulator registers (gemm_lin.h: wave-row form).  Not for launches with a shortcut: there a
       // lane would fetch its 16-B pieces of 64 different rows per load (measured: K = 384 2.1 -> 3.0 ms, L1 thrash), the
       // LDS epilogue reads the shortcut as 64-B runs per lane
-#ifndef HILC_WR_RES
-#define HILC_WR_RES 0
-#endif
       if (ep.vec && (HILC_WR_RES || res == nullptr) && wr_shape(M, (long)B * ep.tiles)) {
         auto go = [&](auto er) {
           er.y = y; er.dw_w = dw_w; er.dw_b = dw_b; er.res = res; er.M = M; er.T = T; er.tiles = ep.tiles; er.out_scale = out_scale;
@@ -454,6 +455,18 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
     return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
   }
   return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);
+}
+
+// which tile form hilc_dws_conv (ksize 5, stride 1, 16-B-lane path) takes for a shape: 1 = wave-row form with the depthwise taps
+// on the accumulator registers, 0 = column-block form with the LDS epilogue (tests pin one against the other bit for bit)
+extern "C" int hilc_dws_conv_wave_row(int B, int M, int T, int has_res) {
+#ifdef HILC_NO_WAVE_ROW
+  return 0;
+#else
+  if (B <= 0 || M <= 0 || T <= 0 || T % 4 != 0) return 0;
+  const long tiles = (T + Dw5Epilogue::STEP - 1) / Dw5Epilogue::STEP;
+  return ((HILC_WR_RES || !has_res) && wr_shape(M, (long)B * tiles)) ? 1 : 0;
+#endif
 }
 
 extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, const float* dw_b,

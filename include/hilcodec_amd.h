@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 7   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms */
+#define HILC_ABI_VERSION 8   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -63,6 +63,11 @@ int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float
 int hilc_dws_conv(const float* x, const float* wt, const float* dw_w, const float* dw_b, const float* res,
                   float* y, int B, int K, int M, int T, int ksize, int stride, float in_scale, int in_elu,
                   float out_scale, int out_elu, void* stream);
+
+/* 1 if hilc_dws_conv (ksize 5, stride 1) runs this shape in the wave-row tile form (depthwise taps on the accumulator
+ * registers), 0 for the column-block form with the LDS epilogue.  Both give the same bits; a pure function of the shape and the
+ * device's CU count (diagnostics and tests). */
+int hilc_dws_conv_wave_row(int B, int M, int T, int has_res);
 
 /* ---- fused up-sampling stage: [Scale, ELU,] depthwise transposed conv (k = 2*stride) -> pointwise conv ---
  * u[b,k,q*stride+p] = tr_w[k][p] * pro(x[b,k,q]) + tr_w[k][p+stride] * pro(x[b,k,q-1])      (x[-1] = 0)

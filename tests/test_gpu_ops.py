@@ -514,3 +514,26 @@ def test_non_finite_sample_stays_in_its_clip(env):
     bad_x[0, 0, 0] = float("nan")
     bad = ops.dws_conv(bad_x, w, dws, dbs, stride=4, in_scale=0.9, in_elu=True)
     assert torch.equal(bad[1:], good[1:])
+
+
+@pytest.mark.parametrize("K,M,Tn,B,in_elu,out_elu", [(128, 256, 496, 120, True, True), (96, 128, 500, 96, False, False),
+                                                       (256, 384, 248, 240, True, False), (64, 128, 372, 160, False, True)])
+def test_wave_row_form_equals_column_block_form(env, K, M, Tn, B, in_elu, out_elu):
+    """The two tile forms of hilc_dws_conv (k5, stride 1, no shortcut): a launch big enough for 128-row tiles runs the wave-row
+    form (accumulators as D[time][channel], depthwise taps in registers); the same clips one at a time run the column-block form
+    with the LDS epilogue.  Same products in the same order: the outputs must be equal bit for bit — full tiles, a clip's ragged
+    last tile, the zero padding in front of a clip, with and without the ELUs."""
+    ops, fold, O, dev = env
+    from hilcodec_amd._lib import lib
+    assert lib.hilc_dws_conv_wave_row(B, M, Tn, 0) == 1 and lib.hilc_dws_conv_wave_row(1, M, Tn, 0) == 0
+    assert lib.hilc_dws_conv_wave_row(B, M, Tn, 1) == 0 and lib.hilc_dws_conv_wave_row(B, M + 32, Tn, 0) == 0
+    x = rnd(K + Tn, B, K, Tn).to(dev)
+    w = (rnd(1, K, M) / K ** 0.5).to(dev)
+    dw, db = (rnd(2, M, 5) * 0.5).to(dev), (rnd(3, M) * 0.2).to(dev)
+    kw = dict(in_scale=0.83, in_elu=in_elu, out_scale=0.7, out_elu=out_elu)
+    big = ops.dws_conv(x, w, dw, db, **kw)
+    one = torch.cat([ops.dws_conv(x[b:b + 1].contiguous(), w, dw, db, **kw) for b in range(B)])
+    assert torch.equal(big, one)
+    ref = O.sconv1d(torch.nn.functional.conv1d(F.elu(x[:2].cpu() * 0.83) if in_elu else x[:2].cpu() * 0.83, w.cpu().t().unsqueeze(-1)),
+                    dw.cpu().unsqueeze(1), db.cpu(), groups=M) * 0.7
+    close(big[:2], F.elu(ref) if out_elu else ref, 2e-5, "wave-row dws vs oracle")

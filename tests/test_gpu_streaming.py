@@ -342,3 +342,36 @@ def test_streaming_1024_streams_full_size(golden):
     assert torch.equal(idx_g, idx) and torch.equal(wav_g, wav)
     for a, b in zip(caches_g, caches):
         assert torch.equal(a, b)
+
+
+def test_captured_resblock_needs_its_own_scheduler_words():
+    """The fused block's ticket words inside a graph capture: without an owner-provided workspace the launch refuses (allocating
+    them during capture would put a memset node and the buffer into that graph, and every later graph would share it); with
+    `ops.sched_workspace` the captured launch replays bit-identically, and the per-launch timer only records inside its context."""
+    from hilcodec_amd import ops
+    dev = torch.device("cuda:0")
+    C, Tn, B = 64, 480, 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, Tn, generator=g).to(dev)
+    w1, w2 = ops.resblock_pack((torch.randn(C, C, generator=g) / 8).to(dev)), ops.resblock_pack((torch.randn(C, C, generator=g) / 8).to(dev))
+    d1, b1 = torch.randn(C, 5, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    d2, b2 = torch.randn(C, 5, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    with ops.timed_launches() as t:
+        ref = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
+    assert len(t.records) == 1 and t.records[0][0] == "resblock"
+    n = len(t.records)
+    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)                    # outside the context: not recorded
+    assert len(t.records) == n
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="sched_workspace"):
+        with torch.cuda.graph(graph):
+            ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
+    ws = ops.SchedWorkspace(dev, slots=2)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), ops.sched_workspace(ws):
+        y = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and int(ws.words.abs().sum()) == 0          # the kernel re-armed its ticket words
