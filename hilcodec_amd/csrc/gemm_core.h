@@ -165,14 +165,19 @@ inline int device_cus() {
 // lose a quarter of the chip against 768 tiles of half the height.  Cost = tiles on the busiest CU x (MB + fixed
 // per-tile overhead); per-output arithmetic (k order) does not depend on MB, results are bit-identical.
 inline int pick_mb(int m32, long ntiles) {
-  const long cus = device_cus();
+  long cus = device_cus();
+  double fixed = 0.5;
+#ifdef HILC_PICK_ENV      // tuning builds only (tools/): the launch heuristic's two constants from the environment
+  if (const char* e = getenv("HILC_PICK_CUS")) cus = atol(e);
+  if (const char* e = getenv("HILC_PICK_FIXED")) fixed = atof(e);
+#endif
   const long groups = (ntiles + 7) / 8;
   int best = 1;
   double best_cost = 1e300;
   for (int mb = 1; mb <= 4; ++mb) {
     const long mtiles = (m32 + mb - 1) / mb;
     const long wgs = groups * 8 * mtiles;
-    const double cost = (double)((wgs + cus - 1) / cus) * (mb + 0.5);
+    const double cost = (double)((wgs + cus - 1) / cus) * (mb + fixed);
     if (cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && mb > best)) {   // ties: the taller tile
       best_cost = cost < best_cost ? cost : best_cost;
       best = mb;
