@@ -106,21 +106,24 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5):
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
-    sclk, power, stop = [], [], [False]
+    sclk, power, cap, stop = [], [], [], [False]
 
     def sampler():
         while not stop[0]:
             try:
-                txt = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True,
-                                     timeout=10).stdout
+                txt = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True,
+                                     text=True, timeout=10).stdout
             except Exception:
                 return
             m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)
-            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            w = re.search(r"(?:Current|Average)[^\n]*Power \(W\):\s*([0-9.]+)", txt)
+            c = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
             if m:
                 sclk.append(float(m.group(1)))
             if w:
                 power.append(float(w.group(1)))
+            if c:
+                cap[:] = [float(c.group(1))]
 
     th = threading.Thread(target=sampler, daemon=True)
     with torch.no_grad():
@@ -139,7 +142,8 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5):
     if not sclk:
         return None
     med = lambda v: sorted(v)[len(v) // 2]
-    return {"sclk_mhz": med(sclk), "power_w": med(power) if power else None, "samples": len(sclk),
+    return {"sclk_mhz": med(sclk), "power_w": med(power) if power else None, "power_cap_w": cap[0] if cap else None,
+            "samples": len(sclk),
             "how": "rocm-smi medians over %.1f s of the same steps after the timed region" % seconds}
 
 
