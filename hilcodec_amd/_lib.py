@@ -26,6 +26,7 @@ SIGNATURES = {
     "hilc_up_conv": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_supported": [_i, _i],
+    "hilc_resblock_stream_supported": [_i, _i],
     "hilc_dws_conv_wave_row": [_i, _i, _i, _i],
     "hilc_resblock_pack_weights": [_p, _p, _i, _p],
     "hilc_dws_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
@@ -62,7 +63,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def source_hash() -> str:

@@ -69,9 +69,15 @@ struct Cfg {
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
   static constexpr bool WIDE = !STREAM && wide_shape<C>();
-  static constexpr int NCOL = WIDE ? 256 : 128;      // tile width = LDS row stride (floats)
+  // NARROW (STREAM, C >= 256: the wide blocks of a streaming hop, 8 or 40 frames per stream): the whole channel range of a
+  // 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).  At 32 columns a tile is
+  // whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the previous samples, so
+  // there is no halo to recompute.
+  static constexpr bool NARROW = STREAM && C >= 256;
+  static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
   static constexpr int XS = NCOL;
-  static constexpr int TO = NCOL - 8;                // output samples per tile (8 = left halo of two causal k=5 convs)
+  static constexpr int HALO = (NARROW && C >= 512) ? 0 : 8;   // left halo of two causal k=5 convs, recomputed per tile
+  static constexpr int TO = NCOL - HALO;             // output samples per tile
   static constexpr int NW = (WIDE || C >= 192) ? 8 : 4;           // waves per workgroup
   static constexpr int NT = 64 * NW;
   static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
@@ -245,6 +251,66 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 }
 
+// The same phase ROLLED, for the wide channel counts of the NARROW stream shapes (C = 768: 96 register sets of 12 MFMAs —
+// fully unrolled that is 25 KB of code per phase): a loop over groups of DEPTH sets, so that the register-set indices stay
+// compile-time; issue order, products and k order are those of gemm_phase.
+template <class K>
+__device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
+                                                  WeightPipe<K>& wp, int colblk, int lane) {
+  constexpr int C = K::CH, XS = K::XS;
+  constexpr int CBW = K::CBW;
+  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
+  constexpr int NSETS = C / 2 / KP;
+  static_assert(NSETS % DEPTH == 0 && NSETS >= 2 * DEPTH, "whole groups of register sets");
+  constexpr int NG = NSETS / DEPTH;
+  const int kh = lane >> 5, l31 = lane & 31;
+  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
+  float b[DEPTH][KP];
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
+    xn += KP * 2 * XS;
+    asm volatile("" : "+v"(xn));
+  }
+  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
+  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
+#pragma unroll
+  for (int i = 0; i < CBW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  auto one_set = [&](auto dc, bool more) {
+    constexpr int cur = decltype(dc)::value, nxt = (cur + DEPTH - 1) % DEPTH;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      if (more) b[nxt][j] = xn[j * 2 * XS];
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) {
+        const int n = j * CBW + i;
+        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
+      }
+    }
+    if (more) {
+      xn += KP * 2 * XS;
+      wn += WPS * 256;
+      asm volatile("" : "+v"(xn), "+s"(wn));
+    }
+#pragma unroll
+    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");      // pin the set (see gemm_phase)
+  };
+  auto group = [&](bool last) {
+    one_set(std::integral_constant<int, 0>{}, true);       // set s = g*DEPTH fetches set s + DEPTH - 1: inside this group
+    if constexpr (DEPTH > 1) one_set(std::integral_constant<int, 1>{}, !last);
+    if constexpr (DEPTH > 2) one_set(std::integral_constant<int, 2>{}, !last);
+    if constexpr (DEPTH > 3) one_set(std::integral_constant<int, 3>{}, !last);
+    static_assert(DEPTH <= 4, "group body");
+  };
+#pragma nounroll
+  for (int g = 0; g < NG - 1; ++g) group(false);
+  group(true);
+}
+
 // ---- EXPERIMENTAL bf16x3 GEMM phases (hilc_resblock_x3; opt-in, offline decoder only; see gemm_x3.h for the arithmetic) ----
 // Only the two GEMM phases change: the tile in LDS stays fp32 (the depthwise / ELU phases are untouched).  A wave reads
 // the 8 consecutive k of its column for a 16-deep step with eight ds_read_b32, splits them in registers (2.5 VALU per
@@ -413,7 +479,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   __shared__ __attribute__((aligned(16))) float DW[C * DWS];
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
   // do not pay one exposed global-load latency per row for the single lane that needs them
-  __shared__ __attribute__((aligned(16))) float HS[STREAM ? 2 * C * 4 : 4];
+  __shared__ __attribute__((aligned(16))) float HS[(STREAM && !K::NARROW) ? 2 * C * 4 : 4];
   float* const X = Xbuf + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
@@ -442,16 +508,17 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 2*NW*i), lane = 4 adjacent
   // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
   // wave instruction, so the in-place update of P3 needs no barrier.
-  const int rsub = wave * K::RPI + (K::RPI == 2 ? (lane >> 5) : 0);
+  const int rsub = wave * K::RPI + (K::RPI > 1 ? lane / (K::NCOL / 4) : 0);
   const int c4 = (lane & (K::NCOL / 4 - 1)) * 4;
   [[maybe_unused]] const unsigned row_b = (unsigned)T * 4u;
-  [[maybe_unused]] const bool one_head = STREAM && T >= XS;
+  [[maybe_unused]] const bool one_head = STREAM && !K::NARROW && T >= XS;
+  constexpr int HALO = K::HALO;
 
   auto columns_of = [&](long tile) -> Cols {
     Cols s;
     s.boff = 0; s.hoff = 0; s.head = false; s.tail = false;
     if constexpr (STREAM) {
-      const int flat = (int)tile * TO - 8 + c4;
+      const int flat = (int)tile * TO - HALO + c4;
       s.t_in = flat >= 0 && flat < a.B * T;
       const unsigned ub = s.t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
       s.b = ub;
@@ -459,7 +526,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
       s.boff = (ub * (unsigned)(C * T) + (unsigned)s.t) * 4u;
       s.hoff = ub * (unsigned)(C * 4);
       s.head = s.t_in && s.t == 0;
-      s.tail = s.t_in && c4 >= 8 && s.t == T - 4;
+      s.tail = s.t_in && c4 >= HALO && s.t == T - 4;
     } else {
       s.b = tile / a.tiles;
       s.t = (int)(tile - s.b * a.tiles) * TO - 8 + c4;
@@ -555,6 +622,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     f32x16 acc[CBW];
     // ---- P1, P2
     if constexpr (X3) gemm_phase_x3<K>(w1t, X, acc, wp, colblk, lane);
+    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
     lds_barrier();
     STAMP(2);
@@ -626,6 +694,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
 
     // ---- P4
     if constexpr (X3) gemm_phase_x3<K>(w2t, X, acc, wp, colblk, lane);
+    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
@@ -635,7 +704,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
       long nb;
       int nt0;
       if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
-        const int nf0 = (int)(have_next ? next : tile) * TO - 8;
+        const int nf0 = (int)(have_next ? next : tile) * TO - HALO;
         const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
         nb = q;
         nt0 = nf0 - (int)q * T;
@@ -663,7 +732,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
 
     // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for columns >= 8, t < T; then this batch's x registers take the
     //      next tile's rows
-    const bool out_ok = STREAM ? (c4 >= 8 && cs.t_in) : (c4 >= 8 && cs.t < T);
+    const bool out_ok = STREAM ? (c4 >= HALO && cs.t_in) : (c4 >= 8 && cs.t < T);
     lptr_t xp6 = (lptr_t)(X + rsub * XS + c4);
 #pragma unroll
     for (int i0 = 0; i0 < RW; i0 += RB) {
@@ -804,6 +873,11 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
       case 96: return launch_res<96, true>(a, B, (hipStream_t)stream);
       case 128: return launch_res<128, true>(a, B, (hipStream_t)stream);
       case 192: return launch_res<192, true>(a, B, (hipStream_t)stream);
+      // the wide blocks of a hop (NARROW shapes): 64-column tiles on the flat column space, or whole-stream 32-column tiles
+      case 256: return launch_res<256, true>(a, B, (hipStream_t)stream);
+      case 384: return launch_res<384, true>(a, B, (hipStream_t)stream);
+      case 512: return 32 % T == 0 ? launch_res<512, true>(a, B, (hipStream_t)stream) : HILC_ERR_UNSUPPORTED;
+      case 768: return 32 % T == 0 ? launch_res<768, true>(a, B, (hipStream_t)stream) : HILC_ERR_UNSUPPORTED;
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
@@ -826,9 +900,10 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
 
 extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C, void* stream) {
   if (!wt || !packed) return HILC_ERR_NULL;
-  if (!(C == 64 || C == 96 || C == 128 || C == 192)) return HILC_ERR_UNSUPPORTED;
+  if (!(C == 64 || C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512 || C == 768)) return HILC_ERR_UNSUPPORTED;
   if (wt == packed) return HILC_ERR_UNSUPPORTED;
-  const int RH = C == 192 ? 2 : 1;
+  const int RH = C >= 512 ? 8 : (C >= 256 ? 4 : (C == 192 ? 2 : 1));     // row classes of the one shape each width has
+  static_assert(Cfg<256, true>::RH == 4 && Cfg<384, true>::RH == 4 && Cfg<512, true>::RH == 8 && Cfg<768, true>::RH == 8, "packed layout");
   static_assert(Cfg<64, false>::RH == 1 && Cfg<96, false>::RH == 1 && Cfg<128, false>::RH == 1 && Cfg<192, false>::RH == 2 &&
                 Cfg<64, true>::RH == 1 && Cfg<96, true>::RH == 1 && Cfg<128, true>::RH == 1 && Cfg<192, true>::RH == 2, "packed layout");
   HILC_CLEAR_ERROR();
@@ -888,4 +963,12 @@ extern "C" void hilc_debug_set_stamp_buffer(unsigned long long* p) { g_dbg = p; 
 
 extern "C" int hilc_resblock_supported(int C, int T) {
   return (C == 64 || C == 96 || C == 128 || C == 192) && T % 4 == 0;
+}
+
+// widths and hop lengths hilc_resblock_stream / hilc_resblock_sched(streaming = 1) take: the offline widths, plus the wide
+// blocks of a hop — C = 256 / 384 at any T % 4 == 0, C = 512 / 768 where whole streams tile 32 columns (T = 4, 8, 16, 32)
+extern "C" int hilc_resblock_stream_supported(int C, int T) {
+  if (T <= 0 || T % 4 != 0) return 0;
+  if (C == 64 || C == 96 || C == 128 || C == 192 || C == 256 || C == 384) return 1;
+  return (C == 512 || C == 768) && 32 % T == 0;
 }

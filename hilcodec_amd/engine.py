@@ -39,11 +39,13 @@ class ExecOptions:
     DECODER (offline and streaming: up-sampling, wide depthwise-separable layers, the GEMM phases of the fused residual
     blocks) run on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32
     accumulation).  The encoder and the RVQ — hence every index — are never touched by it.
-    side_stream: set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves."""
+    side_stream: set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves.
+    stream_wide_blocks: same arithmetic either way (tests pin one launch against two, bit for bit)."""
     decoder_gemm: str = "fp32"
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     side_stream: Optional[object] = None
+    stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
 
 
 _DEFAULT_OPTIONS = ExecOptions()
@@ -74,7 +76,7 @@ class ResBlockSpec:
     dw2_b: Optional[Tensor]
     pre_scale: float        # (1 + idx*res_scale^2)^-1/2  (seanet.py:84), 1.0 in the streaming decoder
     out_scale: float        # res_scale * res_scale_param (seanet.py:144-148); 1.0 when merged into dw2
-    pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec), C <= 192 only
+    pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec): C <= 192, streaming plans also 256 ... 768
     pw2_packed: Optional[Tensor] = None
 
 
@@ -153,16 +155,20 @@ class RvqSpec:
         return self.codebooks.shape[0]
 
 
-def finalize_block(rb: "ResBlockSpec") -> "ResBlockSpec":
+STREAM_WIDE_C = (256, 384, 512, 768)     # widths only the streaming form of the fused block takes (csrc/resblock.hip: NARROW shapes)
+
+
+def finalize_block(rb: "ResBlockSpec", streaming: bool = False) -> "ResBlockSpec":
     c = rb.pw1_wt.shape[0]
-    if (rb.pw1_packed is None and rb.pw1_wt.device.type in ("cuda", "meta") and rb.pw1_wt.shape[1] == c and c <= FUSE_RESBLOCK_MAX_C
-            and ops.resblock_supported(c, 4)):
+    narrow = c <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(c, 4)
+    if (rb.pw1_packed is None and rb.pw1_wt.device.type in ("cuda", "meta") and rb.pw1_wt.shape[1] == c
+            and (narrow or (streaming and c in STREAM_WIDE_C))):
         rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
         rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
     return rb
 
 
-def finalize_spec(spec):
+def finalize_spec(spec, streaming: bool = False):
     """Device-side, one-off derived tables of an Encoder/DecoderSpec whose tensors already live on the GPU: packed
     pointwise weights of the fused residual blocks, expanded up-sampling taps.  (They used to be hidden caches keyed
     by data_ptr inside the op wrappers; as part of the spec they are plain graph inputs for torch.compile.)"""
@@ -172,7 +178,7 @@ def finalize_spec(spec):
                 and sb.n_fft in (64, 128, 256) and sb.wt.shape[1] == sb.n_fft):
             sb.fused = ops.spec_block_tables(sb.basis_t, sb.wt, sb.n_fft)
         for rb in st.blocks:
-            finalize_block(rb)
+            finalize_block(rb, streaming)
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
     return spec
@@ -197,9 +203,10 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
-def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False) -> bool:
+def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False, wide: bool = True) -> bool:
     return (FUSE_RESBLOCK and rb.pw1_packed is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-            and rb.dw1_b is not None and rb.dw2_b is not None and x.shape[1] <= FUSE_RESBLOCK_MAX_C
+            and rb.dw1_b is not None and rb.dw2_b is not None
+            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or (streaming and wide))
             and ops.resblock_supported(x.shape[1], x.shape[2], x.shape[0], streaming))
 
 
@@ -228,8 +235,10 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
                                 hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
         return y
-    if caches is not None and x.shape[2] >= 4 and _fusable(rb, x, True):
-        # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns
+    if (caches is not None and x.shape[2] >= 4 and not (x3 and x.shape[1] > FUSE_RESBLOCK_MAX_C)
+            and _fusable(rb, x, True, opts.stream_wide_blocks)):
+        # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns; the wide blocks of a hop
+        # (C = 256 ... 768) take its narrow-tile shapes (in bf16x3 mode they stay two bf16x3 launches, below)
         y, cs = ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                              rb.pre_scale, rb.out_scale, hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)

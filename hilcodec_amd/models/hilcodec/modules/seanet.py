@@ -178,6 +178,7 @@ class SpecBlock(nn.Module):
 
 class _PlanModule(nn.Module):
     """Mixin: folded plan cached per (device, parameter versions); per-model execution options."""
+    _stream_plan = False      # streaming Encoder / Decoder: the plan also holds packed weights for the wide fused blocks
 
     @property
     def exec_options(self) -> engine.ExecOptions:
@@ -214,7 +215,7 @@ class _PlanModule(nn.Module):
             return cached
         key = self._plan_key(dev)
         if getattr(self, "_plan_cache_key", None) != key:
-            self._plan_cache = engine.finalize_spec(self.build_spec(dev))
+            self._plan_cache = engine.finalize_spec(self.build_spec(dev), streaming=self._stream_plan)
             self._plan_cache_key = key
         return self._plan_cache
 

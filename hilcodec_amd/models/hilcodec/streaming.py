@@ -178,7 +178,7 @@ class ResBlock(nn.Module):
 
     def forward(self, x: Tensor, cache: tp.List[Tensor]) -> tp.Tuple[Tensor, tp.List[Tensor]]:
         new_cache: tp.List[Tensor] = []
-        y = engine._resblock(engine.finalize_block(self.spec(x.device)), x.contiguous().float(), cache, new_cache)
+        y = engine._resblock(engine.finalize_block(self.spec(x.device), streaming=True), x.contiguous().float(), cache, new_cache)
         return y, new_cache
 
 
@@ -259,6 +259,8 @@ def _check_stream_options(activation, activation_params, dilation_base, compress
 
 class Encoder(_PlanModule):
     """`streaming.py:368-517`: forward(x [B,1,320m], *cache_in) -> (z [B,m,dimension], cache_out list[22])."""
+
+    _stream_plan = True
 
     def __init__(self, channels: int = 1, dimension: int = 128, n_filters: int = 32, n_fft_base: int = 64,
                  n_residual_layers: int = 2, ratios: tp.List[int] = [8, 5, 4, 2], activation: str = "ELU",
@@ -360,6 +362,8 @@ class Encoder(_PlanModule):
 
 class Decoder(_PlanModule):
     """`streaming.py:520-648`: forward(q [B,m,dimension], *cache_in) -> (wav [B,1,320m], cache_out list[30])."""
+
+    _stream_plan = True
 
     def __init__(self, channels: int = 1, dimension: int = 128, n_filters: int = 32, n_residual_layers: int = 1,
                  ratios: tp.List[int] = [8, 5, 4, 2], activation: str = "ELU", activation_params: dict = {"alpha": 1.0},

@@ -780,9 +780,17 @@ def up_conv(x: Tensor, tr_w: Tensor, wt: Tensor, bias: Optional[Tensor], stride:
 
 
 def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> bool:
-    """mirror of hilc_resblock_supported (plain Python so that a tracing compiler can evaluate it; the C entry point
-    is checked against this in tests/test_api_cpu.py); the streaming form walks a flat 32-bit column space"""
-    return C in (64, 96, 128, 192) and T % 4 == 0 and (not streaming or B * C * T * 4 < (1 << 32))
+    """mirror of hilc_resblock_supported / hilc_resblock_stream_supported (plain Python so that a tracing compiler can
+    evaluate it; the C entry points are checked against this in tests/test_api_cpu.py); the streaming form walks a flat
+    32-bit column space and also takes the wide blocks of a hop (C = 256 / 384; C = 512 / 768 where whole streams tile 32
+    columns)"""
+    if T <= 0 or T % 4 != 0:
+        return False
+    if not streaming:
+        return C in (64, 96, 128, 192)
+    if B * C * T * 4 >= (1 << 32):
+        return False
+    return C in (64, 96, 128, 192, 256, 384) or (C in (512, 768) and 32 % T == 0)
 
 
 def resblock_pack(wt: Tensor) -> Tensor:

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 8   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row */
+#define HILC_ABI_VERSION 9   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream) */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -148,13 +148,19 @@ int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const 
 /* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv
  * takes) into "MFMA lane order": the operands one lane feeds to the matrix pipe for a 16-deep K slice become
  * consecutive 16-B words, so the fused block streams its weights with a quarter of the load instructions.
- * packed: `C*C` floats, must not alias wt.  C in {64, 96, 128, 192}. */
+ * packed: `C*C` floats, must not alias wt.  C in {64, 96, 128, 192}, and {256, 384, 512, 768} for the streaming form. */
 int hilc_resblock_pack_weights(const float* wt, float* packed, int C, void* stream);
 
 /* Streaming form of the same block (`streaming.py:195-276` ResBlock with two DWSBlock caches,
  * `causal_layers.py:147-167`): hist1 / hist2 `[B][C][4]` = the last 4 samples of the two depthwise convs'
  * inputs (the pointwise outputs) from the previous hop, hist*_out receive the new caches.  All four are
- * optional (NULL = zero history / no cache written); outputs must not alias inputs. */
+ * optional (NULL = zero history / no cache written); outputs must not alias inputs.
+ * Besides the offline widths the streaming form takes the WIDE blocks of a hop, where a stream contributes 8 or 40
+ * frames: C = 256 / 384 (64-column tiles over the flat stream-major column space) and C = 512 / 768 (32-column tiles of
+ * whole streams, T in {4, 8, 16, 32}: no halo) — both GEMMs and the activation between them in one launch instead of two
+ * hilc_dws_conv_stream launches; same products in the same order, bit-identical.  hilc_resblock_stream_supported(C, T)
+ * tells the caller whether the specialisation exists (else HILC_ERR_UNSUPPORTED: fall back to two launches). */
+int hilc_resblock_stream_supported(int C, int T);
 int hilc_resblock_stream(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                          const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
                          const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C, int T,

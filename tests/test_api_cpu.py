@@ -42,6 +42,10 @@ def test_error_codes_without_gpu():
     for c in (32, 64, 80, 96, 128, 160, 192, 256, 768):          # the traceable Python mirror agrees with the library
         for t in (4, 75, 120, 600, 24000):
             assert ops.resblock_supported(c, t) == bool(lib.hilc_resblock_supported(c, t))
+    for c in (32, 64, 96, 128, 192, 256, 320, 384, 512, 640, 768, 1024):       # ... and so does its streaming half
+        for t in (1, 4, 8, 12, 16, 32, 40, 64, 160, 320):
+            assert ops.resblock_supported(c, t, 4, streaming=True) == bool(lib.hilc_resblock_stream_supported(c, t)), (c, t)
+    assert not ops.resblock_supported(768, 8, 1 << 18, streaming=True)          # flat 32-bit column space
     assert lib.hilc_resblock(one, one, one, one, one, one, one, one, 1, 96, 16, 1.0, 1.0, None) == -4  # y aliases x
 
 

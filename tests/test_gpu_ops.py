@@ -330,6 +330,54 @@ def test_fused_resblock_streaming_equals_offline(env, C, hop, hops, B):
     close(caches[1], h2[:, :, -4:].cpu(), 2e-5, "cache 2")
 
 
+@pytest.mark.parametrize("C,T,B", [(768, 8, 37), (768, 8, 4), (512, 8, 21), (768, 4, 9), (512, 32, 3), (384, 40, 19), (384, 40, 1),
+                                   (256, 40, 23), (256, 8, 50), (384, 4, 7), (256, 64, 5), (384, 128, 2)])
+def test_wide_stream_block_equals_two_launches(env, C, T, B):
+    """The wide blocks of a streaming hop as ONE launch (hilc_resblock_stream, NARROW shapes: 32-column tiles of whole streams
+    for C = 512 / 768, 64-column tiles on the flat column space for C = 256 / 384) against the two hilc_dws_conv_stream
+    launches they replace (`streaming.py:195-276`): output and both new caches bit for bit, over three hops, with ragged
+    stream counts."""
+    ops, fold, O, dev = env
+    assert ops.resblock_supported(C, T, B, streaming=True)
+    w1, w2 = (rnd(1, C, C) / C ** 0.5).to(dev), (rnd(4, C, C) / C ** 0.5).to(dev)
+    d1, b1 = (rnd(2, C, 5) * 0.5).to(dev), (rnd(3, C) * 0.2).to(dev)
+    d2, b2 = (rnd(5, C, 5) * 0.5).to(dev), (rnd(6, C) * 0.2).to(dev)
+    w1p, w2p = ops.resblock_pack(w1), ops.resblock_pack(w2)
+    ca = [(rnd(7, B, C, 4) * 0.7).to(dev), (rnd(8, B, C, 4) * 0.7).to(dev)]
+    cb = [c.clone() for c in ca]
+    for h in range(3):
+        x = rnd(C + T + h, B, C, T).to(dev)
+        y, ca = ops.resblock(x, w1p, d1, b1, w2p, d2, b2, 0.9, 0.4, hist=ca)
+        g, c0 = ops.dws_conv_stream(x, w1, d1, b1, cb[0], in_scale=0.9, in_elu=True, out_elu=True)
+        y2, c1 = ops.dws_conv_stream(g, w2, d2, b2, cb[1], res=x, out_scale=0.4)
+        cb = [c0, c1]
+        assert torch.equal(y, y2), (h, float((y - y2).abs().max()))
+        assert torch.equal(ca[0], cb[0]) and torch.equal(ca[1], cb[1]), h
+    # zero history (NULL caches) and caller-provided cache outputs
+    x = rnd(99, B, C, T).to(dev)
+    o = [torch.empty(B, C, 4, device=dev), torch.empty(B, C, 4, device=dev)]
+    z = [torch.zeros(B, C, 4, device=dev), torch.zeros(B, C, 4, device=dev)]
+    y, cs = ops.resblock(x, w1p, d1, b1, w2p, d2, b2, 0.9, 0.4, hist=z, hist_out=o)
+    g, c0 = ops.dws_conv_stream(x, w1, d1, b1, z[0], in_scale=0.9, in_elu=True, out_elu=True)
+    y2, c1 = ops.dws_conv_stream(g, w2, d2, b2, z[1], res=x, out_scale=0.4)
+    assert torch.equal(y, y2) and torch.equal(o[0], c0) and torch.equal(o[1], c1)
+
+
+def test_wide_stream_block_shapes_it_does_not_take(env):
+    """C = 512 / 768 need whole streams per 32-column tile: other hop lengths are refused (the engine then runs two launches)"""
+    ops, fold, O, dev = env
+    from hilcodec_amd._lib import lib
+    assert lib.hilc_resblock_stream_supported(768, 8) == 1 and lib.hilc_resblock_stream_supported(768, 40) == 0
+    assert lib.hilc_resblock_stream_supported(384, 40) == 1 and lib.hilc_resblock_stream_supported(640, 8) == 0
+    assert not ops.resblock_supported(768, 40, 4, streaming=True) and not ops.resblock_supported(768, 8, 4, streaming=False)
+    C, T, B = 768, 40, 2
+    w = (rnd(1, C, C) / C ** 0.5).to(dev)
+    d, b = (rnd(2, C, 5) * 0.5).to(dev), (rnd(3, C) * 0.2).to(dev)
+    z = [torch.zeros(B, C, 4, device=dev), torch.zeros(B, C, 4, device=dev)]
+    with pytest.raises(Exception):
+        ops.resblock(rnd(5, B, C, T).to(dev), ops.resblock_pack(w), d, b, ops.resblock_pack(w), d, b, 0.9, 0.4, hist=z)
+
+
 def test_elu_fast_error(env):
     """The hot-path ELU (2^(x log2 e) - 1 via v_exp_f32) against expm1 in fp64 on a dense grid:
     absolute error bounded by one fp32 ulp of an O(1) activation."""
