@@ -96,7 +96,7 @@ struct Cfg {
   static constexpr int DEPTH = HILC_RES_DEPTH;
 #else
   static constexpr int KP = C >= 128 ? 4 : 8;
-  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? 3 : 2);
+  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
 #endif
 #ifndef HILC_RES_MINW
 #define HILC_RES_MINW 2
@@ -547,17 +547,56 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
       return reinterpret_cast<f32x4*>(a.y + s.b * (long)C * T + (long)m * T + s.t);
   };
 
+  // The 4 samples in front of this lane's column group: the tile's own columns, or — STREAM, at a stream's t = 0 — that
+  // stream's cache.  Branch-free (address / value selects): a per-row `if (head)` is an exec-mask region per row that splits a
+  // batch's loads — by the stamps P3 took 31.8 k cycles per tile at C = 128 against 7.5 k offline.
+  [[maybe_unused]] const float* const hbase[2] = {a.hist1 != nullptr ? a.hist1 : a.x, a.hist2 != nullptr ? a.hist2 : a.x};
+  [[maybe_unused]] const bool hvalid[2] = {a.hist1 != nullptr, a.hist2 != nullptr};
+  Cols cs;
+  // prev[i] for the RB rows of a batch that starts at row pointer xp (rows m0 + RSTEP * i)
+  auto prevs_of = [&](lptr_t xp, int m0, int which, f32x4 (&prev)[K::RB]) {
+    if constexpr (!STREAM) {
+#pragma unroll
+      for (int i = 0; i < K::RB; ++i) prev[i] = *(lvec_t)(xp + i * RSTEP * XS - 4);   // c4 == 0: discarded columns (pad / previous row)
+    } else {
+      bool staged = false;
+      if constexpr (!K::NARROW) staged = one_head;      // wave-uniform: ONE branch per batch
+      if (staged) {      // T >= tile width: the one cache block of the tile sits in HS, staged during P0
+#pragma unroll
+        for (int i = 0; i < K::RB; ++i) {
+          const lptr_t own = xp + i * RSTEP * XS - 4;
+          const lptr_t pa = cs.head ? (lptr_t)(HS + (which * C + m0 + RSTEP * i) * 4) : own;
+          prev[i] = *(lvec_t)pa;
+        }
+      } else {
+        // every lane reads ITS stream's cache words (a valid address for every lane: hoff = 0 outside the tensor), heads keep them
+        f32x4 hv[K::RB];
+#pragma unroll
+        for (int i = 0; i < K::RB; ++i)
+          hv[i] = *reinterpret_cast<const f32x4*>(hbase[which] + (hvalid[which] ? cs.hoff + (unsigned)(m0 + RSTEP * i) * 4u : 0u));
+#pragma unroll
+        for (int i = 0; i < K::RB; ++i) {
+          const f32x4 own = *(lvec_t)(xp + i * RSTEP * XS - 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) prev[i][e] = cs.head ? (hvalid[which] ? hv[i][e] : 0.f) : own[e];
+        }
+      }
+    }
+  };
+
   // persistent: this workgroup walks tiles (static stride or tickets).  x registers: the tile's rows of this
   // lane, loaded one tile ahead; they are the GEMM input (through P0) AND the shortcut of P6.
   float touch = 0.f;
   constexpr int LPR = K::NCOL / 32;                 // 128-B lines per tile row
-  constexpr int NTOUCH = (C * LPR + NT - 1) / NT;
+  // (STREAM: no touch loads — a hop's activations were written by the previous launch a few hundred microseconds ago, and the
+  // registers of the address arithmetic are what the cache handling needs)
+  constexpr int NTOUCH = STREAM ? 1 : (C * LPR + NT - 1) / NT;
   float tv[NTOUCH];                                 // L2 touch loads in flight across the tile boundary
 #pragma unroll
   for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
   __shared__ long s_next;
   long tile = blockIdx.x;
-  Cols cs = columns_of(tile < a.total_tiles ? tile : 0);
+  cs = columns_of(tile < a.total_tiles ? tile : 0);
   f32x4 xr[RW];
   if (tile < a.total_tiles) {
 #pragma unroll
@@ -578,21 +617,26 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     const float* w1t = a.w1t + (long)wclass * (C * C / K::RH);
     const float* w2t = a.w2t + (long)wclass * (C * C / K::RH);
     asm volatile("" : "+s"(w1t), "+s"(w2t));
-    if constexpr (STREAM) {
-      if (one_head && __builtin_amdgcn_ballot_w64(cs.head) != 0) {   // wave-uniform
-        if (cs.head) {
+    // STREAM, T >= tile width: the ONE stream start a tile can hold.  Its two [C][4] cache blocks are contiguous: one coalesced
+    // 16-B load per thread, requested here and written to HS at the end of P0 (the round trip hides behind the prologue; P3 / P6
+    // read HS barriers later).  (Round 3 until here: the few lanes that sit on t = 0 loaded their 2 * RW words themselves,
+    // 32 masked loads in a row and their latency in front of P0 — 3-12 k cycles per tile by the stamps.)
+    [[maybe_unused]] f32x4 hstage[(STREAM && !K::NARROW) ? (2 * C + NT - 1) / NT : 1];
+    [[maybe_unused]] bool stage_hs = false;
+    if constexpr (STREAM && !K::NARROW) {
+      if (one_head) {
+        const int first = (int)tile * TO - HALO, last = first + K::NCOL - 1;
+        const unsigned bh = __umulhi((unsigned)last, a.div_magic) >> a.div_shift;      // stream of the tile's last column
+        const int hcol = (int)bh * T;
+        stage_hs = hcol >= first && (int)bh < a.B;                                     // uniform: its t = 0 lies in this tile
+        if (stage_hs) {
 #pragma unroll
-          for (int which = 0; which < 2; ++which) {
-            const float* hp = which == 0 ? a.hist1 : a.hist2;
-            f32x4 h[RW];
-#pragma unroll
-            for (int i = 0; i < RW; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (hp != nullptr) {
-#pragma unroll
-              for (int i = 0; i < RW; ++i) h[i] = *reinterpret_cast<const f32x4*>(hp + cs.hoff + (rsub + RSTEP * i) * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < RW; ++i) *reinterpret_cast<f32x4*>(&HS[(which * C + rsub + RSTEP * i) * 4]) = h[i];
+          for (int q = 0; q < (2 * C + NT - 1) / NT; ++q) {
+            const int e = tid + q * NT;
+            const int which = e >= C ? 1 : 0, m = e - which * C;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < 2 * C && hvalid[which]) v = *reinterpret_cast<const f32x4*>(hbase[which] + bh * (unsigned)(C * 4) + (unsigned)m * 4u);
+            hstage[q] = v;
           }
         }
       }
@@ -615,6 +659,15 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     // the end of P6 it drained the queue, i.e. waited for the freshly issued x loads of the next tile)
 #pragma unroll
     for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
+    if constexpr (STREAM && !K::NARROW) {
+      if (stage_hs) {
+#pragma unroll
+        for (int q = 0; q < (2 * C + NT - 1) / NT; ++q) {
+          const int e = tid + q * NT;
+          if (e < 2 * C) *reinterpret_cast<f32x4*>(&HS[e * 4]) = hstage[q];
+        }
+      }
+    }
     lds_barrier();
     STAMP(1);
     const long next = (TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x;
@@ -642,19 +695,15 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
         const int m = rsub + RSTEP * (i0 + i);
         const lptr_t row = xp3 + i * RSTEP * XS;
         cur[i] = *(lvec_t)(row);
-        prev[i] = *(lvec_t)(row - 4);          // c4 == 0: discarded columns (pad / previous row)
         wa[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS]);
         wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 4]);
-        if constexpr (STREAM) {
-          if (cs.head) {
-            if (one_head) {
-              prev[i] = *reinterpret_cast<const f32x4*>(&HS[m * 4]);   // written by this same lane before P0
-            } else {
-              prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (a.hist1 != nullptr) prev[i] = *reinterpret_cast<const f32x4*>(a.hist1 + cs.hoff + m * 4);
-            }
-          }
-          if (cs.tail && a.hist1_out != nullptr) *reinterpret_cast<f32x4*>(a.hist1_out + cs.hoff + m * 4) = cur[i];
+      }
+      prevs_of(xp3, rsub + RSTEP * i0, 0, prev);
+      if constexpr (STREAM) {
+        if (cs.tail && a.hist1_out != nullptr) {      // one exec-mask region per batch, not per row
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<f32x4*>(a.hist1_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
         }
       }
       f32x4 o[RB];
@@ -700,7 +749,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     const bool have_next = next < a.total_tiles;
     const Cols cn = columns_of(have_next ? next : tile);
-    {
+    if constexpr (!STREAM) {
       long nb;
       int nt0;
       if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
@@ -743,19 +792,15 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
         const int m = rsub + RSTEP * (i0 + i);
         const lptr_t row = xp6 + i * RSTEP * XS;
         cur[i] = *(lvec_t)(row);
-        prev[i] = *(lvec_t)(row - 4);
         wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 6]);   // w2_0, w2_1
         wc[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS + 8]);   // w2_2, w2_3, w2_4, b2
-        if constexpr (STREAM) {
-          if (cs.head) {
-            if (one_head) {
-              prev[i] = *reinterpret_cast<const f32x4*>(&HS[(C + m) * 4]);
-            } else {
-              prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (a.hist2 != nullptr) prev[i] = *reinterpret_cast<const f32x4*>(a.hist2 + cs.hoff + m * 4);
-            }
-          }
-          if (cs.tail && a.hist2_out != nullptr) *reinterpret_cast<f32x4*>(a.hist2_out + cs.hoff + m * 4) = cur[i];
+      }
+      prevs_of(xp6, rsub + RSTEP * i0, 1, prev);
+      if constexpr (STREAM) {
+        if (cs.tail && a.hist2_out != nullptr) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<f32x4*>(a.hist2_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
         }
       }
 #pragma unroll

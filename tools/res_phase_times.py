@@ -19,18 +19,23 @@ from hilcodec_amd import ops
 from hilcodec_amd._lib import lib
 dev = torch.device("cuda:0")
 B = 256
-for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
+STREAMING = os.environ.get("HILC_STAMP_STREAM") == "1"      # the hop shapes of 1024 streams instead of the offline layers
+SHAPES = [(64, 320), (96, 320), (128, 160), (192, 160)] if STREAMING else [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]
+if STREAMING:
+    B = 1024
+for C, T in SHAPES:
     x = torch.randn(B, C, T, device=dev)
+    hist = [torch.randn(B, C, 4, device=dev), torch.randn(B, C, 4, device=dev)] if STREAMING else None
     w1 = torch.randn(C, C, device=dev) / C ** 0.5; w2 = torch.randn(C, C, device=dev) / C ** 0.5
     d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
     d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
     TO = 120
-    nblk = B * ((T + TO - 1) // TO)
+    nblk = (B * T + TO - 1) // TO if STREAMING else B * ((T + TO - 1) // TO)
     w1, w2 = ops.resblock_pack(w1), ops.resblock_pack(w2)
-    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); torch.cuda.synchronize()
+    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5, hist=hist); torch.cuda.synchronize()
     buf = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
     lib.hilc_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
-    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); torch.cuda.synchronize()
+    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5, hist=hist); torch.cuda.synchronize()
     lib.hilc_debug_set_stamp_buffer(None)
     d = (buf[:, 1:] - buf[:, :-1]).double()
     med = d.median(dim=0).values.tolist()
@@ -39,7 +44,7 @@ for C, T in [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]:
     tt = (buf[live, 7] - buf[live, 0]).double()
     qs = torch.quantile(tt[:200000], torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95, 0.99], dtype=torch.float64, device=dev)).tolist()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5); e1.record(); torch.cuda.synchronize()
+    e0.record(); ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5, hist=hist); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print(f"C={C}: {int(live.sum())} tiles stamped, mean {tt.mean().item():.0f}, quantiles 5/25/50/75/95/99 % = "
           + "/".join(f"{q:.0f}" for q in qs) + f"; kernel {ms:.3f} ms -> sum(ticks)/ms = {tt.sum().item() / ms / 1e6:.2f} G tile-ticks per second"
