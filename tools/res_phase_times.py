@@ -19,8 +19,10 @@ from hilcodec_amd import ops
 from hilcodec_amd._lib import lib
 dev = torch.device("cuda:0")
 B = 256
-STREAMING = os.environ.get("HILC_STAMP_STREAM") == "1"      # the hop shapes of 1024 streams instead of the offline layers
+STREAMING = os.environ.get("HILC_STAMP_STREAM") in ("1", "2")      # the hop shapes of 1024 streams instead of the offline layers
 SHAPES = [(64, 320), (96, 320), (128, 160), (192, 160)] if STREAMING else [(64, 24000), (96, 24000), (128, 12000), (192, 12000)]
+if os.environ.get("HILC_STAMP_STREAM") == "2":              # ... the wide blocks of a hop (narrow-tile shapes)
+    SHAPES = [(256, 40), (384, 40), (512, 8), (768, 8)]
 if STREAMING:
     B = 1024
 for C, T in SHAPES:
@@ -29,7 +31,7 @@ for C, T in SHAPES:
     w1 = torch.randn(C, C, device=dev) / C ** 0.5; w2 = torch.randn(C, C, device=dev) / C ** 0.5
     d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
     d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
-    TO = 120
+    TO = 120 if C <= 192 else (56 if C < 512 else 32)
     nblk = (B * T + TO - 1) // TO if STREAMING else B * ((T + TO - 1) // TO)
     w1, w2 = ops.resblock_pack(w1), ops.resblock_pack(w2)
     ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5, hist=hist); torch.cuda.synchronize()
@@ -52,5 +54,5 @@ for C, T in SHAPES:
     names = ["P0 ELU(regs)", "G1", "P2 acc->lds", "P3 dw+ELU", "G2", "P5 acc->lds", "P6 dw+store+prefetch"]
     if os.environ.get("HILC_STAMP_NAMES") == "wave":     # resblock_wave_kernel's stamps
         names = ["P0 ELU->LDS", "G1", "reorder+halo out+barrier", "E1 dw1+ELU->LDS", "G2", "reorder+halo out+barrier", "E2 dw2->LDS->rows+x->HBM, next x"]
-    mf = (C // 2) * (C // 32) * 64
+    mf = (C // 2) * (C // 32) * 64 if C <= 192 else (C // 2) * (C // 32) * 64 * (64 if C < 512 else 32) // 128
     print(f"C={C}: total {tot:.0f} ticks; ideal MFMA per GEMM {mf} cyc; " + ", ".join(f"{n}={v:.0f}" for n, v in zip(names, med)))
