@@ -506,6 +506,13 @@ struct DwSegEpilogue {
 
   template <int MB>
   __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    if (k == 16 && stride == 8) body<MB, 16>(acc, smem, m0, ntile, wave, lane, tid);        // uniform
+    else if (k == 10 && stride == 5) body<MB, 10>(acc, smem, m0, ntile, wave, lane, tid);
+    else body<MB, 0>(acc, smem, m0, ntile, wave, lane, tid);
+  }
+
+  template <int MB, int KS>
+  __device__ void body(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
 #pragma unroll
     for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
       const int nblk = acc_chunk_to_lds<MB>(acc, smem, ch, wave, lane);
@@ -522,10 +529,42 @@ struct DwSegEpilogue {
         const float* hp = hist != nullptr ? hist + (b * M + m) * (long)pad + pad : nullptr;   // hp[tt], tt < 0
         const float* w = dw_w + (long)m * k;
         float a = 0.f;
-        for (int j = 0; j < k; ++j) {
-          const int tt = o * stride - pad + j;
-          const float v = tt >= 0 ? h[tt] : (hp != nullptr ? hp[tt] : 0.f);
-          a = fmaf(w[j], v, a);
+        if (KS > 0) {
+          // the codec's down-sampling layers (k = 2 * stride = 16 or 10): taps and operands requested before the chain (same
+          // chain, j ascending); only output 0 of a clip reaches into the cache, with its first k - stride taps
+          constexpr int KK = KS > 0 ? KS : 2, PAD = KK / 2;
+          float wv[KK], v[KK];
+          if (KK % 4 == 0) {
+#pragma unroll
+            for (int j4 = 0; j4 < KK / 4; ++j4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(w + 4 * j4);
+              wv[4 * j4] = t.x; wv[4 * j4 + 1] = t.y; wv[4 * j4 + 2] = t.z; wv[4 * j4 + 3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int j2 = 0; j2 < KK / 2; ++j2) {
+              const f32x2 t = *reinterpret_cast<const f32x2*>(w + 2 * j2);
+              wv[2 * j2] = t.x; wv[2 * j2 + 1] = t.y;
+            }
+          }
+          const float* hs = h + o * PAD - PAD;          // stride == PAD
+          if (o == 0) {
+#pragma unroll
+            for (int j = 0; j < PAD; ++j) v[j] = hp != nullptr ? hp[j - PAD] : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < PAD; ++j) v[j] = hs[j];
+          }
+#pragma unroll
+          for (int j = PAD; j < KK; ++j) v[j] = hs[j];
+#pragma unroll
+          for (int j = 0; j < KK; ++j) a = fmaf(wv[j], v[j], a);
+        } else {
+          for (int j = 0; j < k; ++j) {
+            const int tt = o * stride - pad + j;
+            const float v = tt >= 0 ? h[tt] : (hp != nullptr ? hp[tt] : 0.f);
+            a = fmaf(w[j], v, a);
+          }
         }
         if (dw_b != nullptr) a = __fadd_rn(a, dw_b[m]);
         a = __fmul_rn(a, out_scale);
