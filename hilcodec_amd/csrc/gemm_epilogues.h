@@ -456,6 +456,18 @@ struct DwStrideEpilogue {
             const bool from_cache = lane == 0;
             const float* hc = hist + (b * M + m) * (long)r;
             for (int j = 0; j < k; ++j) a = fmaf(w[j], (from_cache && j < r) ? hc[j] : h[j], a);
+          } else if (KR == 8 && H == 4) {
+            // stride 4: a lane's 8 operands are two aligned 16-B words, consecutive lanes are consecutive words — two conflict-free
+            // ds_read_b128 instead of four ds_read2_b32 whose lanes sit 4 dwords apart (8 lanes per bank)
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(h), v1 = *reinterpret_cast<const f32x4*>(h + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(wv[g][j < KR ? j : 0], v[j], a);
+          } else if (KR == 4 && H == 4) {
+            const f32x2 v0 = *reinterpret_cast<const f32x2*>(h), v1 = *reinterpret_cast<const f32x2*>(h + 2);
+            const float v[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a = fmaf(wv[g][j < KR ? j : 0], v[j], a);
           } else if (KR > 0) {
 #pragma unroll
             for (int j = 0; j < (KR > 0 ? KR : 1); ++j) a = fmaf(wv[g][j], h[j], a);
