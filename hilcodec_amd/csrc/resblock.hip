@@ -5,13 +5,16 @@
 // For C in {64, 96} the un-fused block is HBM-bound (1x1 conv intensity = C/4 flop/B): this kernel reads x ONCE and
 // writes y once; everything between lives in registers and one LDS tile.
 //
-// Workgroup = NW waves, one clip, NCOL-8 output samples: the tile spans NCOL columns (see Cfg),
-// column c <-> time t0 + c with t0 = (NCOL-8)*tile - 8 (8 = left halo of two causal k=5 convs).
+// Workgroup = NW waves walking a CONTIGUOUS run of tiles; a tile = NCOL columns of one clip (see Cfg), column c <-> time
+// t0 + c with t0 = NCOL * (tile within the clip).  The two causal k = 5 convs need the 4 columns in front of a tile of H1 and
+// of H2: the previous tile of the run leaves them in LDS (CARRY), a clip's first tile takes zeros (streaming: the caches).  A run
+// that starts inside a clip walks the tile in front of it once without storing anything (warm-up).  No column is computed twice
+// (rounds 1-3 recomputed an 8-column halo per tile: 6.25 % of the GEMM work).
 //   P0  a1 = ELU(pre*x) from the x REGISTERS (loaded during the previous tile's P6)  -> LDS  X[k][c]
 //   P1  GEMM1  H1 = W1 * a1   (fp32 MFMA 32x32x2; a wave owns one 32-column block and CBW row blocks)
 //   P2  accumulators -> LDS  X[m][c]
 //   P3  a2 = ELU(dw1(H1)+b1) in place (a row is handled by one wave instruction, so read-before-write holds
-//       without a barrier); columns with t < 0 are forced to 0 (the second conv's zero padding)
+//       without a barrier, for the tile and for the carry)
 //   P4  GEMM2  H2 = W2 * a2
 //   P5  accumulators -> LDS
 //   P6  y = (dw2(H2)+b2)*out_scale + x (the shortcut comes from the x registers: no re-read) -> HBM; as soon as a
@@ -75,8 +78,14 @@ struct Cfg {
   // there is no halo to recompute.
   static constexpr bool NARROW = STREAM && C >= 256;
   static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL;
-  static constexpr int HALO = (NARROW && C >= 512) ? 0 : 8;   // left halo of two causal k=5 convs, recomputed per tile
+  static constexpr int XS = NCOL + (!STREAM ? 8 : 0);   // LDS row stride: the tile's columns (+ offline: two 4-float carry slots, H1 and H2)
+  // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
+  // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
+  // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
+  // strided / ticketed tile order: a hop is 2.5-5 tiles per workgroup, runs would rarely start on a stream's t = 0 and each start
+  // inside a stream costs a warm-up tile (measured: 5.34 -> 6.26 ms per hop with two stream groups).
+  static constexpr bool CARRYMODE = !STREAM;
+  static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
   static constexpr int NW = (WIDE || C >= 192) ? 8 : 4;           // waves per workgroup
   static constexpr int NT = 64 * NW;
@@ -511,14 +520,13 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   const int rsub = wave * K::RPI + (K::RPI > 1 ? lane / (K::NCOL / 4) : 0);
   const int c4 = (lane & (K::NCOL / 4 - 1)) * 4;
   [[maybe_unused]] const unsigned row_b = (unsigned)T * 4u;
-  [[maybe_unused]] const bool one_head = STREAM && !K::NARROW && T >= XS;
-  constexpr int HALO = K::HALO;
+  [[maybe_unused]] const bool one_head = STREAM && !K::NARROW && T >= K::NCOL;
 
   auto columns_of = [&](long tile) -> Cols {
     Cols s;
     s.boff = 0; s.hoff = 0; s.head = false; s.tail = false;
     if constexpr (STREAM) {
-      const int flat = (int)tile * TO - HALO + c4;
+      const int flat = (int)tile * TO - K::HALO + c4;
       s.t_in = flat >= 0 && flat < a.B * T;
       const unsigned ub = s.t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
       s.b = ub;
@@ -526,10 +534,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
       s.boff = (ub * (unsigned)(C * T) + (unsigned)s.t) * 4u;
       s.hoff = ub * (unsigned)(C * 4);
       s.head = s.t_in && s.t == 0;
-      s.tail = s.t_in && c4 >= HALO && s.t == T - 4;
+      s.tail = s.t_in && c4 >= K::HALO && s.t == T - 4;
     } else {
       s.b = tile / a.tiles;
-      s.t = (int)(tile - s.b * a.tiles) * TO - 8 + c4;
+      s.t = (int)(tile - s.b * a.tiles) * TO + c4;
       s.t_in = s.t >= 0 && s.t < T;
     }
     return s;
@@ -553,19 +561,28 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   [[maybe_unused]] const float* const hbase[2] = {a.hist1 != nullptr ? a.hist1 : a.x, a.hist2 != nullptr ? a.hist2 : a.x};
   [[maybe_unused]] const bool hvalid[2] = {a.hist1 != nullptr, a.hist2 != nullptr};
   Cols cs;
-  // prev[i] for the RB rows of a batch that starts at row pointer xp (rows m0 + RSTEP * i)
-  auto prevs_of = [&](lptr_t xp, int m0, int which, f32x4 (&prev)[K::RB]) {
+  // The 4 columns in front of a lane's column group are its left neighbour's — except for column group 0, whose "previous columns"
+  // are the last 4 of the run's previous tile.  They live in two 4-float slots behind each row of the tile (H1 at X[m][NCOL..],
+  // H2 at X[m][NCOL + 4..]): the lane of group 0 reads them through ONE base pointer chosen per phase (same row stride, same
+  // immediate offsets as everybody else), the lane of the last group leaves them at a constant offset from its own pointer.
+  // A clip's first tile finds zeros there (the convs' zero padding); STREAM: at a stream's t = 0 the cache overrides.
+  const bool lane0 = c4 == 0, lane_last = c4 == K::NCOL - 4;
+  auto prev_base = [&](int which) -> lptr_t {        // + i * RSTEP * XS = the 16-B word in front of row (rsub + RSTEP * i)'s group
+    if constexpr (!K::CARRYMODE) return (lptr_t)(X + rsub * XS + c4 - 4);       // STREAM: group 0 = discarded halo columns, or a head
+    else return lane0 ? (lptr_t)(X + rsub * XS + K::NCOL + which * 4) : (lptr_t)(X + rsub * XS + c4 - 4);
+  };
+  // prev[i] for the RB rows of the batch whose first row sits RW0 rows (in units of RSTEP) below rsub; pb = prev_base(which)
+  auto prevs_of = [&](lptr_t pb, int m0, int which, f32x4 (&prev)[K::RB]) {
     if constexpr (!STREAM) {
 #pragma unroll
-      for (int i = 0; i < K::RB; ++i) prev[i] = *(lvec_t)(xp + i * RSTEP * XS - 4);   // c4 == 0: discarded columns (pad / previous row)
+      for (int i = 0; i < K::RB; ++i) prev[i] = *(lvec_t)(pb + i * RSTEP * XS);
     } else {
       bool staged = false;
       if constexpr (!K::NARROW) staged = one_head;      // wave-uniform: ONE branch per batch
       if (staged) {      // T >= tile width: the one cache block of the tile sits in HS, staged during P0
 #pragma unroll
         for (int i = 0; i < K::RB; ++i) {
-          const lptr_t own = xp + i * RSTEP * XS - 4;
-          const lptr_t pa = cs.head ? (lptr_t)(HS + (which * C + m0 + RSTEP * i) * 4) : own;
+          const lptr_t pa = cs.head ? (lptr_t)(HS + (which * C + m0 + RSTEP * i) * 4) : pb + i * RSTEP * XS;
           prev[i] = *(lvec_t)pa;
         }
       } else {
@@ -576,10 +593,19 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
           hv[i] = *reinterpret_cast<const f32x4*>(hbase[which] + (hvalid[which] ? cs.hoff + (unsigned)(m0 + RSTEP * i) * 4u : 0u));
 #pragma unroll
         for (int i = 0; i < K::RB; ++i) {
-          const f32x4 own = *(lvec_t)(xp + i * RSTEP * XS - 4);
+          const f32x4 own = *(lvec_t)(pb + i * RSTEP * XS);
 #pragma unroll
           for (int e = 0; e < 4; ++e) prev[i][e] = cs.head ? (hvalid[which] ? hv[i][e] : 0.f) : own[e];
         }
+      }
+    }
+  };
+  // xp = this lane's pointer to its group in the batch's first row: the last group's lane leaves the batch's carry words
+  auto carry_out = [&](lptr_t xp, int which, const f32x4 (&cur)[K::RB]) {
+    if constexpr (K::CARRYMODE) {
+      if (lane_last) {
+#pragma unroll
+        for (int i = 0; i < K::RB; ++i) *(lvec_t)(xp + i * RSTEP * XS + 4 + which * 4) = cur[i];
       }
     }
   };
@@ -594,24 +620,44 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   float tv[NTOUCH];                                 // L2 touch loads in flight across the tile boundary
 #pragma unroll
   for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
+  // Offline: this workgroup's run = tiles [run0, run1) of the launch, in order.  A run that starts inside a clip first walks the
+  // tile in front of it as a WARM-UP (everything computed, nothing stored): its last 4 columns of H1 and H2 depend only on its own
+  // columns 116..127, so the carry it leaves is exact whatever it was handed itself.
+  // STREAM: tiles by static stride or by ticket (where several workgroups share a CU), every tile with its own halo.
   __shared__ long s_next;
+  long run0 = blockIdx.x, run1 = a.total_tiles;
   long tile = blockIdx.x;
-  cs = columns_of(tile < a.total_tiles ? tile : 0);
+  if constexpr (K::CARRYMODE) {
+    run0 = (long)blockIdx.x * a.total_tiles / gridDim.x;
+    run1 = ((long)blockIdx.x + 1) * a.total_tiles / gridDim.x;
+    tile = (run0 % a.tiles != 0 && run0 < run1) ? run0 - 1 : run0;
+  }
+  cs = columns_of(tile < run1 ? tile : 0);
   f32x4 xr[RW];
-  if (tile < a.total_tiles) {
+  if (tile < run1) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, rsub + RSTEP * i);
   }
   lds_barrier();   // DW / pad visible
-  while (tile < a.total_tiles) {
+  while (tile < run1) {
+    const bool warm = K::CARRYMODE && tile < run0;           // uniform
+    constexpr bool TICKETS = !K::CARRYMODE && K::NW == 4;
+    if constexpr (K::CARRYMODE) {
+      // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
+      // it two barriers from here)
+      if (tile % a.tiles == 0) {
+        for (int e = tid; e < 2 * C; e += NT)
+          *reinterpret_cast<f32x4*>(X + (e >> 1) * XS + K::NCOL + (e & 1) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      // tickets only where several workgroups share a CU (one per CU progresses evenly: static stride, no atomic round trip on
+      // the critical path)
+      if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
+    }
 #ifdef HILC_DEBUG_STAMPS
     stamp_tile = tile;
 #endif
     STAMP(0);
-    // tickets only where several workgroups share a CU (one per CU progresses evenly: static stride, no atomic round
-    // trip on the critical path)
-    constexpr bool TICKETS = K::NW == 4;
-    if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
     // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
     // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
     const float* w1t = a.w1t + (long)wclass * (C * C / K::RH);
@@ -625,7 +671,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     [[maybe_unused]] bool stage_hs = false;
     if constexpr (STREAM && !K::NARROW) {
       if (one_head) {
-        const int first = (int)tile * TO - HALO, last = first + K::NCOL - 1;
+        const int first = (int)tile * TO - K::HALO, last = first + K::NCOL - 1;
         const unsigned bh = __umulhi((unsigned)last, a.div_magic) >> a.div_shift;      // stream of the tile's last column
         const int hcol = (int)bh * T;
         stage_hs = hcol >= first && (int)bh < a.B;                                     // uniform: its t = 0 lies in this tile
@@ -670,7 +716,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     }
     lds_barrier();
     STAMP(1);
-    const long next = (TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x;
+    const long next = K::CARRYMODE ? tile + 1 : ((TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x);
 
     f32x16 acc[CBW];
     // ---- P1, P2
@@ -686,6 +732,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place, RB rows at a time
     wp.prefetch(w2t, lane);                  // GEMM2's first weight slices travel while P3 runs
     lptr_t xp3 = (lptr_t)(X + rsub * XS + c4);
+    lptr_t pb3 = prev_base(0);
 #pragma unroll
     for (int i0 = 0; i0 < RW; i0 += RB) {
       f32x4 cur[RB], prev[RB], wa[RB];
@@ -698,9 +745,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
         wa[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS]);
         wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 4]);
       }
-      prevs_of(xp3, rsub + RSTEP * i0, 0, prev);
+      prevs_of(pb3, rsub + RSTEP * i0, 0, prev);
+      carry_out(xp3, 0, cur);                          // H1's last 4 columns, before the row is overwritten in place
       if constexpr (STREAM) {
-        if (cs.tail && a.hist1_out != nullptr) {      // one exec-mask region per batch, not per row
+        if (cs.tail && !warm && a.hist1_out != nullptr) {      // one exec-mask region per batch, not per row
 #pragma unroll
           for (int i = 0; i < RB; ++i)
             *reinterpret_cast<f32x4*>(a.hist1_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
@@ -723,20 +771,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
       for (int i = 0; i < RB; ++i)
         *(lvec_t)(xp3 + i * RSTEP * XS) = o[i];
       xp3 += RB * RSTEP * XS;
-      asm volatile("" : "+v"(xp3));
+      pb3 += RB * RSTEP * XS;
+      asm volatile("" : "+v"(xp3), "+v"(pb3));
       __builtin_amdgcn_sched_barrier(0);   // batches stay batches: hoisting every row's reads costs RW * 14 registers
-    }
-    if constexpr (!STREAM) {
-      // columns with t < 0 are the second conv's zero padding: only a clip's first tile has them (t0 = -8: column
-      // groups 0 and 1), so instead of a select per element in every tile those two lanes of a row overwrite their
-      // own outputs — same lane, program order, no hazard.  (STREAM: a clip's first samples take the cache instead.)
-      if (__builtin_amdgcn_readfirstlane(cs.t - c4) < 0) {       // uniform
-        if (c4 < 8) {
-          lptr_t xz = (lptr_t)(X + rsub * XS + c4);
-#pragma unroll
-          for (int i = 0; i < RW; ++i) *(lvec_t)(xz + i * RSTEP * XS) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
     }
     lds_barrier();
     STAMP(4);
@@ -747,20 +784,20 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
-    const bool have_next = next < a.total_tiles;
+    const bool have_next = next < run1;
     const Cols cn = columns_of(have_next ? next : tile);
     if constexpr (!STREAM) {
       long nb;
       int nt0;
       if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
-        const int nf0 = (int)(have_next ? next : tile) * TO - HALO;
+        const int nf0 = (int)(have_next ? next : tile) * TO - K::HALO;
         const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
         nb = q;
         nt0 = nf0 - (int)q * T;
       } else {
         const long nt = have_next ? next : tile;
         nb = nt / a.tiles;
-        nt0 = (int)(nt - nb * a.tiles) * TO - 8;
+        nt0 = (int)(nt - nb * a.tiles) * TO;
       }
       const float* nx = a.x + nb * (long)C * T;
 #pragma unroll
@@ -779,10 +816,11 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     lds_barrier();
     STAMP(6);
 
-    // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for columns >= 8, t < T; then this batch's x registers take the
+    // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for t < T (not in a warm-up tile); then this batch's x registers take the
     //      next tile's rows
-    const bool out_ok = STREAM ? (c4 >= HALO && cs.t_in) : (c4 >= 8 && cs.t < T);
+    const bool out_ok = !warm && (STREAM ? (c4 >= K::HALO && cs.t_in) : cs.t < T);
     lptr_t xp6 = (lptr_t)(X + rsub * XS + c4);
+    lptr_t pb6 = prev_base(1);
 #pragma unroll
     for (int i0 = 0; i0 < RW; i0 += RB) {
       f32x4 cur[RB], prev[RB], wc[RB];
@@ -795,9 +833,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
         wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 6]);   // w2_0, w2_1
         wc[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS + 8]);   // w2_2, w2_3, w2_4, b2
       }
-      prevs_of(xp6, rsub + RSTEP * i0, 1, prev);
+      prevs_of(pb6, rsub + RSTEP * i0, 1, prev);
+      carry_out(xp6, 1, cur);
       if constexpr (STREAM) {
-        if (cs.tail && a.hist2_out != nullptr) {
+        if (cs.tail && !warm && a.hist2_out != nullptr) {
 #pragma unroll
           for (int i = 0; i < RB; ++i)
             *reinterpret_cast<f32x4*>(a.hist2_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
@@ -824,7 +863,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
         for (int i = 0; i < RB; ++i) xr[i0 + i] = *xrow(cn, rsub + RSTEP * (i0 + i));
       }
       xp6 += RB * RSTEP * XS;
-      asm volatile("" : "+v"(xp6));
+      pb6 += RB * RSTEP * XS;
+      asm volatile("" : "+v"(xp6), "+v"(pb6));
       __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(7);
@@ -832,7 +872,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
     tile = next;
     cs = cn;
   }
-  if (K::NW == 4 && a.sched != nullptr && tid == 0) {          // last workgroup out re-arms the scheduler for the next launch
+  if (!K::CARRYMODE && K::NW == 4 && a.sched != nullptr && tid == 0) {   // last workgroup out re-arms the scheduler for the next launch
     if (atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) {
       a.sched[0] = 0;
       a.sched[1] = 0;

@@ -31,7 +31,7 @@ for C, T in SHAPES:
     w1 = torch.randn(C, C, device=dev) / C ** 0.5; w2 = torch.randn(C, C, device=dev) / C ** 0.5
     d1 = torch.randn(C, 5, device=dev); b1 = torch.randn(C, device=dev)
     d2 = torch.randn(C, 5, device=dev); b2 = torch.randn(C, device=dev)
-    TO = 120 if C <= 192 else (56 if C < 512 else 32)
+    TO = (120 if STREAMING else 128) if C <= 192 else (56 if C < 512 else 32)
     nblk = (B * T + TO - 1) // TO if STREAMING else B * ((T + TO - 1) // TO)
     w1, w2 = ops.resblock_pack(w1), ops.resblock_pack(w2)
     ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5, hist=hist); torch.cuda.synchronize()
