@@ -66,7 +66,7 @@ constexpr bool wide_shape() {
   return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
 }
 
-template <int C, bool STREAM, bool X3_ = false>
+template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false>
 struct Cfg {
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
@@ -78,13 +78,15 @@ struct Cfg {
   // there is no halo to recompute.
   static constexpr bool NARROW = STREAM && C >= 256;
   static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + (!STREAM ? 8 : 0);   // LDS row stride: the tile's columns (+ offline: two 4-float carry slots, H1 and H2)
+  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
   // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
   // strided / ticketed tile order: a hop is 2.5-5 tiles per workgroup, runs would rarely start on a stream's t = 0 and each start
   // inside a stream costs a warm-up tile (measured: 5.34 -> 6.26 ms per hop with two stream groups).
-  static constexpr bool CARRYMODE = !STREAM;
+  // SCARRY: the carry form for a STREAMING launch whose geometry lets every run start on a stream's t = 0 (launch_res decides:
+  // 1024 streams x 160 samples = 256 runs of exactly 5 tiles = 4 whole streams each, five rounds of tiles instead of six).
+  static constexpr bool CARRYMODE = !STREAM || SCARRY_;
   static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
   static constexpr int NW = (WIDE || C >= 192) ? 8 : 4;           // waves per workgroup
@@ -477,9 +479,9 @@ struct Cols {
   bool head, tail;     // STREAM: t == 0 (previous 4 samples live in the cache) / t == T-4 on an output column
 };
 
-template <int C, bool STREAM, bool X3 = false>
-__global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, X3>;
+template <int C, bool STREAM, bool X3 = false, bool SCARRY = false>
+__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY>::NT), (Cfg<C, STREAM, X3, SCARRY>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, X3, SCARRY>;
   using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
@@ -630,7 +632,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   if constexpr (K::CARRYMODE) {
     run0 = (long)blockIdx.x * a.total_tiles / gridDim.x;
     run1 = ((long)blockIdx.x + 1) * a.total_tiles / gridDim.x;
-    tile = (run0 % a.tiles != 0 && run0 < run1) ? run0 - 1 : run0;
+    const bool mid = STREAM ? (run0 * TO) % T != 0 : run0 % a.tiles != 0;     // does the run start inside a clip / stream?
+    tile = (mid && run0 < run1) ? run0 - 1 : run0;
   }
   cs = columns_of(tile < run1 ? tile : 0);
   f32x4 xr[RW];
@@ -642,14 +645,15 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
   while (tile < run1) {
     const bool warm = K::CARRYMODE && tile < run0;           // uniform
     constexpr bool TICKETS = !K::CARRYMODE && K::NW == 4;
-    if constexpr (K::CARRYMODE) {
+    if constexpr (K::CARRYMODE && !STREAM) {
       // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
-      // it two barriers from here)
+      // it two barriers from here).  (STREAM: column group 0 of a stream's first tile is a head and takes the cache.)
       if (tile % a.tiles == 0) {
         for (int e = tid; e < 2 * C; e += NT)
           *reinterpret_cast<f32x4*>(X + (e >> 1) * XS + K::NCOL + (e & 1) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    } else {
+    }
+    if constexpr (!K::CARRYMODE) {
       // tickets only where several workgroups share a CU (one per CU progresses evenly: static stride, no atomic round trip on
       // the critical path)
       if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
@@ -882,8 +886,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3>::NT), (Cfg<C, STREAM, X3>::MINW
 #undef STAMP
 }
 
-template <int C, bool STREAM, bool X3 = false>
-int launch_res(ResArgs a, int B, hipStream_t s) {
+template <int C, bool STREAM, bool X3 = false, bool SCARRY = false>
+int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
   a.B = B;
   {  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
     int l = 0;
@@ -893,7 +897,7 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
     a.div_shift = (unsigned)(l - 1);
   }
-  using K = Cfg<C, STREAM, X3>;
+  using K = Cfg<C, STREAM, X3, SCARRY>;
   constexpr int TO = K::TO;
   a.tiles = (a.T + TO - 1) / TO;
   a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
@@ -908,15 +912,31 @@ int launch_res(ResArgs a, int B, hipStream_t s) {
     int n_cu = 0, occ = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
       return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, X3>, K::NT, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, X3, SCARRY>, K::NT, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
     cached = n_cu * occ;
     if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
   }
   const long resident = cached;
+  if constexpr (STREAM && !SCARRY && !X3 && (C == 96 || C == 192)) {
+    // The carry form for this hop?  Only where every run is the same whole number of streams (so that no run starts inside a
+    // stream and pays a warm-up tile) and the runs are fewer tile-times than the rounds of the halo form.
+    constexpr int NC = K::NCOL;
+    long g = a.T, h = NC;
+    while (h != 0) { const long t = g % h; g = h; h = t; }                      // gcd(T, NCOL)
+    const long unit = (long)a.T / g;                                              // tiles of the shortest aligned run
+    const long cols = (long)B * a.T;
+    if (cols % (unit * NC) == 0) {
+      const long units = cols / (unit * NC);
+      const long k = (units + resident - 1) / resident;                          // aligned runs per workgroup (same residency: 8 KB of LDS more)
+      const long halo_rounds = (a.total_tiles + resident - 1) / resident;
+      if (units % k == 0 && k * unit < halo_rounds) return launch_res<C, STREAM, X3, true>(a, B, s, units / k);
+    }
+  }
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
+  if (SCARRY && carry_grid > 0 && carry_grid <= resident) blocks = carry_grid;
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

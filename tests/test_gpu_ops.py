@@ -305,7 +305,10 @@ def test_fused_resblock_vs_oracle(env, C, Tn, B):
 
 
 @pytest.mark.parametrize("C,hop,hops,B", [(64, 320, 3, 2), (96, 320, 2, 1), (128, 160, 3, 2), (192, 160, 2, 3), (64, 8, 5, 2),
-                                          (96, 4, 4, 1)])
+                                          (96, 4, 4, 1),
+                                          # stream counts whose hop splits into equal whole-stream runs: the carry form of the
+                                          # streaming block (runs of 5 tiles = 4 / 2 streams, no halo), one run and several
+                                          (192, 160, 2, 4), (192, 160, 2, 1100), (96, 320, 2, 2), (96, 320, 2, 1028), (192, 32, 3, 12)])
 def test_fused_resblock_streaming_equals_offline(env, C, hop, hops, B):
     """hilc_resblock_stream hop by hop (caches = last 4 pointwise outputs of each depthwise conv,
     causal_layers.py:147-167) must reproduce the offline block on the concatenated signal bit for bit, and its
