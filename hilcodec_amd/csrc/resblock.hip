@@ -61,6 +61,16 @@ constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1
 #ifndef HILC_RES_WIDE_MASK
 #define HILC_RES_WIDE_MASK 0   // bit 0: C = 64, bit 1: C = 96, bit 2: C = 128 use the wide lockstep shape (tuning: tools/res_bench.py)
 #endif
+// run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
+// (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
+// 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
+#ifndef HILC_RES_SHARE2_0
+#define HILC_RES_SHARE2_0 0.64
+#endif
+#ifndef HILC_RES_SHARE3_0
+#define HILC_RES_SHARE3_0 0.44
+#define HILC_RES_SHARE3_1 0.31
+#endif
 template <int C>
 constexpr bool wide_shape() {
   return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
@@ -126,6 +136,8 @@ struct ResArgs {
   const float* dw2_b;
   float* y;
   int T, tiles;
+  int classes;        // carry form: workgroups per CU (0 = equal runs) and the cumulative run shares of the dispatch classes, 16-bit fractions
+  unsigned cum[5];
   long total_tiles;
   float pre_scale, out_scale;
   int B;
@@ -630,8 +642,19 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY>::NT), (Cfg<C, STREAM, X
   long run0 = blockIdx.x, run1 = a.total_tiles;
   long tile = blockIdx.x;
   if constexpr (K::CARRYMODE) {
-    run0 = (long)blockIdx.x * a.total_tiles / gridDim.x;
-    run1 = ((long)blockIdx.x + 1) * a.total_tiles / gridDim.x;
+    if (a.classes > 1) {
+      // Workgroups that share a CU are not served equally: the one dispatched first (lower blockIdx: the grid is classes x CUs, a CU
+      // holds one workgroup of every class) wins issue arbitration until it is done — with equal runs the first class finished at
+      // 0.76 of the kernel and the last ran on alone (tools/res_wg_times.py).  Runs in proportion to the classes' speeds: a
+      // "slot" u owns a contiguous range of tiles, its classes split it in dispatch order.
+      const unsigned P = gridDim.x / (unsigned)a.classes, u = blockIdx.x % P, c = blockIdx.x / P;
+      const long s0 = (long)u * a.total_tiles / P, len = (long)(u + 1) * a.total_tiles / P - s0;
+      run0 = s0 + ((len * (long)a.cum[c]) >> 16);
+      run1 = s0 + ((len * (long)a.cum[c + 1]) >> 16);
+    } else {
+      run0 = (long)blockIdx.x * a.total_tiles / gridDim.x;
+      run1 = ((long)blockIdx.x + 1) * a.total_tiles / gridDim.x;
+    }
     const bool mid = STREAM ? (run0 * TO) % T != 0 : run0 % a.tiles != 0;     // does the run start inside a clip / stream?
     tile = (mid && run0 < run1) ? run0 - 1 : run0;
   }
@@ -935,6 +958,32 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
   }
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
   if (SCARRY && carry_grid > 0 && carry_grid <= resident) blocks = carry_grid;
+  a.classes = 0;
+  if constexpr (!STREAM) {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0 && blocks == resident &&
+        resident % n_cu == 0 && resident / n_cu >= 2 && resident / n_cu <= 4 && a.total_tiles >= 8 * resident) {
+      const int cls = (int)(resident / n_cu);
+      // shares of the dispatch classes (first-dispatched first), measured: see tools/res_wg_times.py and profiles/r03_experiments.md
+      double share[4] = {0, 0, 0, 0};
+      if (cls == 2) { share[0] = HILC_RES_SHARE2_0; share[1] = 1.0 - share[0]; }
+      else if (cls == 3) { share[0] = HILC_RES_SHARE3_0; share[1] = HILC_RES_SHARE3_1; share[2] = 1.0 - share[0] - share[1]; }
+      else { for (int i = 0; i < cls; ++i) share[i] = 1.0 / cls; }
+#ifdef HILC_RES_SHARE_ENV      // tuning builds only
+      if (cls == 2) { if (const char* e = getenv("HILC_SHARE2_0")) { share[0] = atof(e); share[1] = 1.0 - share[0]; } }
+      if (cls == 3) {
+        if (const char* e = getenv("HILC_SHARE3_0")) share[0] = atof(e);
+        if (const char* e = getenv("HILC_SHARE3_1")) share[1] = atof(e);
+        share[2] = 1.0 - share[0] - share[1];
+      }
+#endif
+      double acc = 0;
+      a.cum[0] = 0;
+      for (int i = 0; i < cls; ++i) { acc += share[i]; a.cum[i + 1] = (unsigned)(acc * 65536.0 + 0.5); }
+      a.cum[cls] = 65536u;
+      a.classes = cls;
+    }
+  }
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
