@@ -452,6 +452,25 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
   if (ld.vec && lin_ok(B, K, T)) {
     TileCols cols;
     cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
+#ifndef HILC_NO_WAVE_ROW
+    // stride 4 (the second encoder stage): taps on the accumulator registers (wave-row form), as for k5 / stride 1 — 2.22 -> 2.05 ms
+    // at K = 128 -> 256, T = 12000.  (Stride 2, K = 64 -> 128: 1.68 -> 1.71 ms — a lane's 32 outputs leave as sixteen 8-B stores
+    // into 64 different rows per instruction; it keeps the LDS epilogue, whose stores are whole rows.)
+    if (stride == 4 && ep.H == 4 && wr_shape(M, (long)B * ep.tiles)) {
+      auto go = [&](auto er) {
+        er.y = y; er.dw_w = dw_w; er.dw_b = dw_b; er.M = M; er.To = ep.To; er.tiles = ep.tiles; er.n_out = ep.n_out;
+        if (in_elu) {
+          RowsB<TileCols, true> bo;
+          bo.x = x; bo.T = T; bo.in_scale = in_scale; bo.cols = cols;
+          return launch_lin_wr(wt, M, K, M, (long)B * ep.tiles, bo, er, (hipStream_t)stream);
+        }
+        RowsB<TileCols, false> bo;
+        bo.x = x; bo.T = T; bo.in_scale = in_scale; bo.cols = cols;
+        return launch_lin_wr(wt, M, K, M, (long)B * ep.tiles, bo, er, (hipStream_t)stream);
+      };
+      return go(DwStrideRegEpilogue<4>{});
+    }
+#endif
     return launch_gemm_lin(wt, x, M, K, M, T, (long)B * ep.tiles, in_scale, in_elu != 0, cols, ep, (hipStream_t)stream);
   }
   return launch_gemm(wt, M, K, M, (long)B * ep.tiles, true, ld, ep, (hipStream_t)stream);

@@ -391,6 +391,67 @@ struct Dw5RegEpilogue {
   }
 };
 
+// Down-sampling layers (depthwise k = 2r, stride r, r = 2 or 4) on the wave-row form of the GEMM tile: a lane holds one channel and
+// 64 contiguous columns of it (lanes 32-63: columns 64-127), so output k of a half is
+//     sum_j w[j] * U[-r + r*k + j],   j = 0 .. 2r-1 (in order),   U[q >= 0] = the lane's column q, U[q < 0] = the other half's last r
+// for BOTH halves (the lower half's first H/r values of k are the tile's halo and are not stored): tile output i = k - H/r in the
+// lower half, 64/r - H/r + k in the upper one.  Same products in the same order as DwStrideEpilogue, no LDS round trip.
+// Offline only (no cache), M % 128 == 0, T % 4 == 0.  The launcher uses R = 4 (R = 2 measured slower than the LDS form: gemm.hip).
+template <int R>
+struct DwStrideRegEpilogue {
+  float* y;
+  const float* dw_w;   // [M][2R]
+  const float* dw_b;
+  int M, To, tiles, n_out;
+  static constexpr int H = 4;
+  static_assert(R == 2 || R == 4, "strides of the first two encoder stages");
+
+  __device__ void run_wr(f32x16 (&acc)[4], int mrow0, long ntile, int lane) const {
+    constexpr int NK = 64 / R, SH = H / R;
+    const long b = ntile / tiles;
+    const int o0 = (int)(ntile - b * tiles) * n_out;
+    const int h = lane >> 5;
+    const int m = mrow0 + (lane & 31);
+    float w[2 * R];
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) w[j] = dw_w[(long)m * (2 * R) + j];
+    const float bias = dw_b ? dw_b[m] : 0.f;
+    wr_time_order(acc);
+    float u[R + 64];                     // U[-R .. 63] at u[0 .. R+63]
+#pragma unroll
+    for (int j = 0; j < R; ++j) {        // upper half: the lower half's columns 64-R .. 63 (lower half: zeros, its first outputs are halo)
+      const float src = HILC_WR_V(acc, 64 - R + j);
+      const auto p = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(src), false, false);
+      const unsigned p0 = p[0];
+      u[j] = __uint_as_float(p0);
+    }
+#pragma unroll
+    for (int q = 0; q < 64; ++q) u[R + q] = HILC_WR_V(acc, q);
+    const int i0 = h ? NK - SH : -SH;    // tile output of k = 0
+    float* const yrow = y + (b * M + m) * (long)To + o0 + i0;
+#pragma unroll
+    for (int k = 0; k < NK; k += 2) {
+      float o[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) a = fmaf(w[j], u[R * (k + e) + j], a);
+        o[e] = dw_b ? __fadd_rn(a, bias) : a;
+      }
+      // (R = 2: o0 and i0 are even, the pair is 8-B aligned; R = 4: scalar stores)
+      const int i = i0 + k;
+      if (R == 2) {
+        if (i >= 0 && i < n_out && o0 + i + 1 < To) *reinterpret_cast<f32x2*>(yrow + k) = f32x2{o[0], o[1]};
+        else if (i >= 0 && i < n_out && o0 + i < To) yrow[k] = o[0];
+      } else {
+        if (i >= 0 && i < n_out && o0 + i < To) yrow[k] = o[0];
+        if (i + 1 >= 0 && i + 1 < n_out && o0 + i + 1 < To) yrow[k + 1] = o[1];
+      }
+    }
+  }
+};
+
 // depthwise causal conv k = 2r, stride r (down-sampling): tile covers times [o0*r - H, +128) with
 // H = round_up(r, 4); output o0 + i reads columns H - r + i*r + j, j < 2r.
 struct DwStrideEpilogue {
