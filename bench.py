@@ -471,11 +471,19 @@ def main():
                             "fp32-EQUIVALENT flops against the fp32 peak, not a utilisation")
         out["roofline"] = roof
         if world == 1 and not args.no_other_configs and (args.is_default or (args.other_configs and args.mode == "offline")):
-            out["other_configs"] = other_config_lines(dev, D, B, 4 * B)
+            # auxiliary lines: a failure here (it would be a bug) must not cost the headline line its measurement — it is reported
+            # in place of the lines, and tests/test_gpu_bench.py fails on it
+            try:
+                out["other_configs"] = other_config_lines(dev, D, B, 4 * B)
+            except Exception as e:                                     # noqa: BLE001
+                out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)
-            if args.mode == "offline" and lo == 0 and hi - lo >= args.cpu_clips:
-                out["parity_census"] = parity_census(model, sd, nq, ctx["last"]["z"], idx, wav, oracle_out)
+            try:
+                out["cpu_baseline"], oracle_out = cpu_baseline(name, mk, sd, args.cpu_clips, T)
+                if args.mode == "offline" and lo == 0 and hi - lo >= args.cpu_clips:
+                    out["parity_census"] = parity_census(model, sd, nq, ctx["last"]["z"], idx, wav, oracle_out)
+            except Exception as e:                                     # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     D.shutdown()
 
