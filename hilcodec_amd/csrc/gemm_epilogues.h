@@ -7,7 +7,8 @@
 namespace hilc {
 
 // the linear-addressing cores use 32-bit byte offsets into x
-static inline bool lin_ok(int B, int K, int T) { return (long)B * K * T * 4 < (1L << 32); }
+// 32-bit byte offsets per thread, and `tc` of gemm_lin.h clamps a column group to [0, T - 4]: needs T >= 4
+static inline bool lin_ok(int B, int K, int T) { return T >= 4 && (long)B * K * T * 4 < (1L << 32); }
 
 // n / d for n < 2^31 as __umulhi(n, magic) >> shift (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l)/d); d >= 2
 static inline void div_magic(int d, unsigned& m, unsigned& sh) {

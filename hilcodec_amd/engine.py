@@ -11,6 +11,8 @@ behaviours of the reference's two decoders are data in the spe
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -39,16 +41,28 @@ class ExecOptions:
     DECODER (offline and streaming: up-sampling, wide depthwise-separable layers, the GEMM phases of the fused residual
     blocks) run on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32
     accumulation).  The encoder and the RVQ — hence every index — are never touched by it.
-    side_stream: set by graph_step while it warms up / captures a hop: second HIP stream for the STFT front halves.
     stream_wide_blocks: same arithmetic either way (tests pin one launch against two, bit for bit)."""
     decoder_gemm: str = "fp32"
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
-    side_stream: Optional[object] = None
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
 
 
 _DEFAULT_OPTIONS = ExecOptions()
+
+# The HIP stream that takes the STFT front halves of the un-fused SpecBlocks while a hop is warmed up / captured
+# (graph_step).  A context variable like ops._TIMER / ops._SCHED_WS: it belongs to the schedule being built on THIS thread,
+# not to the model — two schedules built concurrently on one model from different threads do not see each other's stream.
+_SIDE_STREAM: contextvars.ContextVar = contextvars.ContextVar("hilcodec_side_stream", default=None)
+
+
+@contextlib.contextmanager
+def spectra_side_stream(stream):
+    token = _SIDE_STREAM.set(stream)
+    try:
+        yield
+    finally:
+        _SIDE_STREAM.reset(token)
 _X3_SPLIT = {}            # id(weight tensor) -> (weak reference, version, split form); built on first use, dies with the weight
 
 
@@ -298,7 +312,7 @@ def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Te
 
 def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor], side, skip=()) -> Optional[dict]:
     """Streaming hop inside a captured graph: the log-magnitude spectra of the un-fused SpecBlocks depend on the
-    waveform only, so they are computed on `side` (ExecOptions.side_stream) beside the first encoder stages (their small launches fill
+    waveform only, so they are computed on `side` (`spectra_side_stream`) beside the first encoder stages (their small launches fill
     idle CUs instead of standing in the chain); `_spec_block` waits for each one's event.  Same launches, same
     results."""
     if side is None or torch.compiler.is_compiling() or not wav.is_cuda:
@@ -326,6 +340,42 @@ def _contig(caches: Optional[Sequence[Tensor]]):
     return None if caches is None else [c.contiguous() for c in caches]
 
 
+# The linear-addressing GEMM cores and the fused residual block address an activation tensor with 32-bit byte offsets
+# (csrc/gemm_epilogues.h: lin_ok, csrc/resblock.hip): a tensor of 4 GiB or more silently took the generic core / two
+# launches (10-20 % slower).  Clips are independent and results batch-invariant bit for bit (tests/test_gpu_fullsize.py),
+# so an offline batch whose LARGEST activation would reach the limit is run as equal clip chunks that each stay below it.
+OFFSET_LIMIT_BYTES = 1 << 32
+
+
+def _clip_chunks(batch: int, per_clip_elems: int) -> List[Tuple[int, int]]:
+    """[(lo, hi)] — one range if the whole batch fits 32-bit byte offsets, else the fewest equal chunks that do"""
+    most = max(1, (OFFSET_LIMIT_BYTES - 1) // (4 * max(1, per_clip_elems)))
+    if batch <= most:
+        return [(0, batch)]
+    n = -(-batch // most)
+    size = -(-batch // n)
+    return [(lo, min(batch, lo + size)) for lo in range(0, batch, size)]
+
+
+def _encoder_clip_elems(es: "EncoderSpec", T: int) -> int:
+    """largest [C, T_s] activation of one clip that a launch of the offline encoder reads or writes"""
+    best, t = es.pre_w.shape[0] * T, T
+    for st in es.stages:
+        best = max(best, st.down_pw_wt.shape[0] * t)
+        t = -(-t // st.ratio)
+        best = max(best, st.down_dw_w.shape[0] * t)
+    return best
+
+
+def _decoder_clip_elems(ds: "DecoderSpec", F: int) -> int:
+    best, t = ds.pre_dw_w.shape[0] * F, F
+    for st in ds.stages:
+        best = max(best, st.tr_w.shape[0] * t)
+        t *= st.ratio
+        best = max(best, st.pw_wt.shape[1] * t)
+    return best
+
+
 def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]] = None,
                 channel_last_out: bool = False, caches_out: Optional[Sequence[Tensor]] = None,
                 opts: ExecOptions = _DEFAULT_OPTIONS):
@@ -337,6 +387,10 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         raise RuntimeError(f"expected [B,1,T] waveform, got {tuple(wav.shape)}")
     wav = wav.contiguous().float()
     streaming = caches is not None
+    if not streaming and not torch.compiler.is_compiling():
+        chunks = _clip_chunks(wav.shape[0], _encoder_clip_elems(es, wav.shape[2]))
+        if len(chunks) > 1:
+            return torch.cat([run_encoder(es, wav[lo:hi], None, channel_last_out, None, opts) for lo, hi in chunks], dim=0)
     caches = _contig(caches)
     new_caches: Optional[list] = [] if streaming else None
 
@@ -359,13 +413,13 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
-    early = _early_spectra(es, wav, wav_hist, opts.side_stream, skip=(sb0,) if fuse_pre else ()) if streaming else None
+    early = _early_spectra(es, wav, wav_hist, _SIDE_STREAM.get(), skip=(sb0,) if fuse_pre else ()) if streaming else None
     for si, st in enumerate(es.stages):
         if not (fuse_pre and si == 0):
             x = _spec_block(st.spec, x, wav, wav_hist, early)
         for rb in st.blocks:
             x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
-                          caches_out[ci:ci + 2] if caches_out is not None else None)
+                          caches_out[ci:ci + 2] if caches_out is not None else None, opts=opts)
             ci += 2
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
             x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci],
@@ -409,6 +463,10 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         return caches_out[i] if caches_out is not None else None
 
     q = q.contiguous().float()
+    if not streaming and not torch.compiler.is_compiling():
+        chunks = _clip_chunks(q.shape[0], _decoder_clip_elems(ds, q.shape[2]))
+        if len(chunks) > 1:
+            return torch.cat([run_decoder(ds, q[lo:hi], None, None, opts) for lo, hi in chunks], dim=0)
     if opts.decoder_gemm not in ("fp32", "bf16x3"):
         raise RuntimeError(f"ExecOptions.decoder_gemm must be 'fp32' or 'bf16x3', got {opts.decoder_gemm!r}")
     if opts.decoder_gemm != "fp32" and torch.compiler.is_compiling():

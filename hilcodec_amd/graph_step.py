@@ -16,7 +16,6 @@ log-magnitude spectra of the un-fused SpecBlocks (n_fft 256 / 512 / 1024 at one 
 waveform only) sit on a second branch beside the first encoder stages (`engine._early_spectra`)."""
 from __future__ import annotations
 
-import contextlib
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -25,16 +24,11 @@ from torch import Tensor
 from . import engine, ops
 
 
-@contextlib.contextmanager
 def _spectra_on(encoder, stream: Optional[torch.cuda.Stream]):
-    """while a hop of THIS model's encoder is warmed up / captured: the STFT front halves of its un-fused SpecBlocks go
-    to `stream` (engine._early_spectra), a branch of the graph beside the first encoder stages"""
-    opts = encoder.exec_options
-    prev, opts.side_stream = opts.side_stream, stream
-    try:
-        yield
-    finally:
-        opts.side_stream = prev
+    """while a hop is warmed up / captured on this thread: the STFT front halves of the un-fused SpecBlocks go to `stream`
+    (engine._early_spectra), a branch of the graph beside the first encoder stages.  Context-local (engine._SIDE_STREAM),
+    nothing is written into the model."""
+    return engine.spectra_side_stream(stream)
 
 
 class StateBlock:
@@ -156,13 +150,21 @@ class GraphedHop:
             main.wait_stream(self.chain[g])
         return torch.cat([o[0] for o in outs], dim=1), torch.cat([o[1] for o in outs], dim=0)
 
+    def _current(self, which: str) -> List[Tensor]:
+        per_group = [getattr(blocks[self.parity], which) for blocks in self.gstate]
+        if len(per_group) == 1:
+            return per_group[0]                                        # views of the state block itself
+        return [torch.cat(cs, dim=0) for cs in zip(*per_group)]      # groups are contiguous stream ranges: copies, full batch
+
     @property
     def cache_enc(self) -> List[Tensor]:
-        return self.state[self.parity].enc
+        """the CURRENT encoder caches of all streams, in the reference's order (`streaming.py:458-470`) — what
+        `wire.save_cache` / `reset(...)` take; with groups > 1 concatenated over the groups (copies)"""
+        return self._current("enc")
 
     @property
     def cache_dec(self) -> List[Tensor]:
-        return self.state[self.parity].dec
+        return self._current("dec")
 
     def reset(self, cache_enc: Optional[Sequence[Tensor]] = None, cache_dec: Optional[Sequence[Tensor]] = None) -> None:
         """zero history, or resume from caches saved earlier (`wire.save_cache` / `e_in*`, `d_in*`)"""
@@ -281,11 +283,27 @@ class PipelinedHop:
         self.idx[p].copy_(idxs[0] if G == 1 else torch.cat(idxs, dim=1))
         return wavs[0] if G == 1 else torch.cat(wavs, dim=0)
 
-    def reset(self) -> None:
+    @property
+    def cache_enc(self) -> List[Tensor]:
+        """CURRENT encoder caches of all streams (after the hop last given to `step`), concatenated over the groups"""
+        per_group = [blocks[self.parity].enc for blocks in self.gstate]
+        return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
+
+    @property
+    def cache_dec(self) -> List[Tensor]:
+        """CURRENT decoder caches: the decoder is one hop behind while a hop is pending (they then describe the streams
+        after the hop BEFORE the last `step`); after `flush()` both cache lists describe the same instant"""
+        p = self.parity ^ 1 if self.pending else self.parity
+        per_group = [blocks[p].dec for blocks in self.gstate]
+        return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
+
+    def reset(self, cache_enc: Optional[Sequence[Tensor]] = None, cache_dec: Optional[Sequence[Tensor]] = None) -> None:
+        """zero history, or resume from caches exported earlier (`cache_enc` / `cache_dec` after a `flush()`)"""
         with torch.no_grad():
             self.parity, self.pending = 0, False
-            for a, _b in self.gstate:
-                a.zero_()
+            for (lo, hi), (a, _b) in zip(self.bounds, self.gstate):
+                a.load_(None if cache_enc is None else [c[lo:hi] for c in cache_enc],
+                        None if cache_dec is None else [c[lo:hi] for c in cache_dec])
 
     def step(self, x: Tensor) -> Tuple[Tensor, Optional[Tensor]]:
         """x `[B,1,hop]` -> (indices of THIS hop `[n,B,T]`, wav `[B,1,hop]` of the PREVIOUS hop or None on the first

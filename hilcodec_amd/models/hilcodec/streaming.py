@@ -514,14 +514,39 @@ class HILCodec(nn.Module):
             if hasattr(module, "merge_scaling"):
                 module.merge_scaling()
 
-    def load_offline_state_dict(self, sd: tp.Dict[str, Tensor]) -> None:
+    def load_offline_state_dict(self, sd: tp.Dict[str, Tensor], norm: str = "weight_norm",
+                                norm_kwargs: tp.Optional[dict] = None) -> None:
         """Fill this streaming model from an OFFLINE checkpoint (`checkpoint['model']` of the reference)
         with the correspondence of `scripts/HILCodec Onnx.ipynb` cell 1.  Call
-        `remove_weight_reparameterizations()` afterwards, as the notebook does."""
+        `remove_weight_reparameterizations()` afterwards, as the notebook does.
+
+        `norm` = the re-parameterisation the OFFLINE model was built with.  The reference's streaming classes know
+        weight_norm only (`causal_layers.py:200-204,216-220` raise ValueError otherwise), so a checkpoint of an offline
+        `HILCodec(norm="weight_standardization", norm_kwargs=...)` (`conv.py:36-37`) has one way into the streaming
+        model: every conv folded to a plain weight with `modules/weight_standardization.py:30-41`'s expression
+        (`fold.weight_standardization_fold`; `norm_kwargs`: `eps`, `scale`, as given to the offline constructor) — this
+        model's convs then hold plain `weight`s, as after `remove_weight_norm`."""
+        if norm not in ("weight_norm", "weight_standardization"):
+            raise ValueError(f"Unknown norm: {norm}")
+        ws = norm == "weight_standardization"
+        if ws:
+            kw = dict(norm_kwargs or {})
+            ws_eps = float(kw.get("eps", 1e-7))
+            ws_scale = None if kw.get("scale") is None else torch.ones(1) * float(kw["scale"])
+            for module in self.modules():
+                if isinstance(module, ConvParams):
+                    module.remove_reparameterization()
         own = self.state_dict()
         new: tp.Dict[str, Tensor] = {}
 
         def conv(dst: str, src: str):
+            if ws and f"{src}.weight_v" in sd:
+                scale = sd.get(f"{src}.weight_scale", ws_scale)
+                new[f"{dst}.weight"] = fold.weight_standardization_fold(sd[f"{src}.weight_v"], sd.get(f"{src}.weight_g"),
+                                                                         scale, ws_eps)
+                if f"{src}.bias" in sd:
+                    new[f"{dst}.bias"] = sd[f"{src}.bias"]
+                return
             for suffix in ("weight_g", "weight_v", "bias", "weight"):
                 if f"{src}.{suffix}" in sd:
                     new[f"{dst}.{suffix}"] = sd[f"{src}.{suffix}"]

@@ -83,6 +83,19 @@ def conv_weight(sd: SD, prefix: str) -> Tuple[Tensor, Optional[Tensor]]:
     return fold_weight_norm(v, g), bias
 
 
+def with_weight_standardization(sd: SD, scale: Optional[float] = None) -> SD:
+    """Copy of a `weight_g/_v` state dict marked as belonging to `HILCodec(norm="weight_standardization",
+    norm_kwargs={"scale": scale})` (`conv.py:36-37`): the marker `conv_weight` reads, plus the `weight_scale` buffer the
+    reference's constructor would have registered for every conv (`modules/weight_standardization.py:88-92`)."""
+    out = dict(sd)
+    out["__norm__"] = "weight_standardization"
+    if scale is not None:
+        for k in sd:
+            if k.endswith(".weight_v"):
+                out[k[:-len("weight_v")] + "weight_scale"] = torch.ones(1) * scale
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # primitive layers (offline, `conv.py`)
 # --------------------------------------------------------------------------------------

@@ -273,6 +273,8 @@ def main():
     trained_codebook_golden(ref)
     rvq_train_golden(ref)
     realistic_golden(ref)
+    shard_golden(ref)
+    ws_golden(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot)
 
@@ -328,6 +330,94 @@ def realistic_golden(ref):
           "bytes", os.path.getsize(os.path.join(OUT, "realistic.npz")))
 
 
+def shard_golden(ref):
+    """BASELINE configs[4] (hil_music, 2048 clips over 8 GPUs = 256 per rank) has no reference-side multi-GPU inference to
+    compare with (`train.py:51-61` is the reference's only NCCL setup); what CAN be pinned is that the clips a rank != 0
+    owns — other seeds than any other golden — come out of the real reference's offline model as they do out of the HIP path
+    when they sit inside that rank's full 256-clip shard.  Here: the first 8 clips of rank 7's shard (clips 1792..1799 of
+    `synth_clips(first=1792)`, 1 s each) through the REAL reference; stored: all indices, z / wav probes."""
+    name, first, n_clips = "hil_music", 1792, 8
+    mk = synth.model_kwargs(name)
+    sd = synth.synth_state_dict(name, seed=WEIGHT_SEED)
+    model = R.build_offline(ref, mk, sd)
+    x = synth.synth_clips(n_clips, 24000, seed=CLIP_SEED, first=first)
+    zs, ids, ws = [], [], []
+    with torch.no_grad():
+        for i in range(0, n_clips, 4):
+            z = model.encoder(x[i:i + 4].clone())
+            q, _, _, idx = model.quantizer(z, None, return_indices=True)
+            zs.append(z); ids.append(idx); ws.append(model.decoder(q))
+    z, idx, wav = torch.cat(zs), torch.cat(ids), torch.cat(ws)
+    np.savez_compressed(os.path.join(OUT, "shard_rank7_hil_music.npz"),
+                        indices=t2n(idx).astype(np.int16), z_probe=t2n(z[:, :, ::5]), wav_probe=t2n(wav[:, :, ::25]),
+                        z_abs_sum=np.float64(z.double().abs().sum()), wav_abs_sum=np.float64(wav.double().abs().sum()),
+                        first=np.int64(first), rank=np.int64(7), world=np.int64(8), shard_clips=np.int64(256),
+                        weight_seed=np.int64(WEIGHT_SEED), clip_seed=np.int64(CLIP_SEED))
+    print("shard rank 7: idx", idx.shape, "checksum of the 8 clips", int(idx.sum()))
+
+
+WS_KWARGS = {"eps": 1e-7, "scale": 1.25}
+
+
+def ws_golden(ref):
+    """Whole-model weight standardisation (`conv.py:36-37`, `modules/weight_standardization.py:30-41`): the reference's
+    offline `HILCodec(norm="weight_standardization", norm_kwargs=...)` on the seeded state dict (same keys as weight_norm:
+    `weight_g/_v`; `weight_scale` is a buffer the constructor fills from `norm_kwargs['scale']`), 2 clips x 0.2 s.
+
+    Streaming: the reference's streaming classes accept weight_norm only (`causal_layers.py:200-204` raises ValueError for
+    anything else), so the only streaming flow a weight-standardised checkpoint has is fold -> plain weights -> streaming
+    model (what `remove_weight_reparameterizations` + the notebook's mapping do for weight_norm).  The golden is the
+    REFERENCE streaming model (built with weight_norm, hooks removed) carrying the plain weights that the reference's own
+    `WeightStandardization.compute_weight` produced, 1 stream x 5 hops with every cache."""
+    import copy
+    name = "hil_speech"
+    mk = dict(synth.model_kwargs(name), norm="weight_standardization", norm_kwargs=dict(WS_KWARGS))
+    sd = synth.synth_state_dict(name, seed=WEIGHT_SEED)
+    model = R.build_offline(ref, mk, sd)
+    x = synth.synth_clips(2, 4800, seed=CLIP_SEED + 900)
+    out = dict(weight_seed=np.int64(WEIGHT_SEED), clip_seed=np.int64(CLIP_SEED + 900), samples=np.int64(4800),
+               ws_eps=np.float64(WS_KWARGS["eps"]), ws_scale=np.float64(WS_KWARGS["scale"]))
+    with torch.no_grad():
+        z = model.encoder(x.clone())
+        q, _, loss, idx = model.quantizer(z, None, return_indices=True)
+        wav = model.decoder(q)
+    out.update(z=t2n(z), indices=t2n(idx).astype(np.int16), wav=t2n(wav), loss=t2n(loss))
+    # one folded weight as a known answer of the fold itself (transposed conv: dim 0 = in_channels)
+    out["fold_probe_convtr"] = t2n(model.decoder.model[4].convtr.convtr.weight)
+    out["fold_probe_pw"] = t2n(model.encoder.blocks[1][0].block[1].conv.conv.weight)
+
+    # streaming: plain (folded) weights into the reference's streaming model
+    mk_wn = synth.model_kwargs(name)
+    plain = R.build_offline(ref, mk_wn, sd)            # weight_norm twin: only its structure is used
+    model(x[:1, :, :640].clone(), None)                # make sure every pre-hook has produced .weight
+    src = dict(model.named_modules())
+    with torch.no_grad():
+        for mod_name, mod in plain.named_modules():
+            if isinstance(mod, (torch.nn.Conv1d, torch.nn.ConvTranspose1d)) and hasattr(mod, "weight_g"):
+                torch.nn.utils.remove_weight_norm(mod)
+                mod.weight.copy_(src[mod_name].weight)          # the reference's own compute_weight output
+    sm = R.build_streaming(ref, mk_wn, plain, plain_weights=True)
+    hops = 5
+    xs = synth.synth_clips(1, 320 * hops, seed=CLIP_SEED + 901)
+    ce, cd = sm.initialize_cache(xs)
+    zs, idxs, wavs = [], [], []
+    with torch.no_grad():
+        for h in range(hops):
+            zz, ce = sm.encoder(xs[:, :, 320 * h: 320 * (h + 1)], *ce)
+            ii = sm.quantizer(zz, 8)
+            w, cd = sm.decoder(sm.dequantizer(ii, 8), *cd)
+            zs.append(zz); idxs.append(ii); wavs.append(w)
+    out.update(s_z=t2n(torch.cat(zs, 1)), s_indices=t2n(torch.cat(idxs, 2)).astype(np.int16), s_wav=t2n(torch.cat(wavs, 2)),
+               s_hops=np.int64(hops), s_clip_seed=np.int64(CLIP_SEED + 901))
+    for i, c in enumerate(ce):
+        out[f"e_out{i}"] = t2n(c)
+    for i, c in enumerate(cd):
+        out[f"d_out{i}"] = t2n(c)
+    np.savez_compressed(os.path.join(OUT, "ws_hil_speech.npz"), **out)
+    print("ws: offline z", z.shape, "idx", idx.shape, "stream z", out["s_z"].shape, "bytes",
+          os.path.getsize(os.path.join(OUT, "ws_hil_speech.npz")))
+
+
 def trained_codebook_golden(ref):
     """Dequantizer known-answer test on the reference's SHIPPED data: trained codebooks
     (`onnx/hil_speech_deq{i}.onnx`) + the first frames of `onnx/hil_speech_quantized.npy`, run through the
@@ -360,6 +450,12 @@ if __name__ == "__main__":
     elif "--realistic" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         realistic_golden(R.load_reference())
+    elif "--shard" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        shard_golden(R.load_reference())
+    elif "--ws" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        ws_golden(R.load_reference())
     elif "--rvq-train" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         rvq_train_golden(R.load_reference())

@@ -75,21 +75,25 @@ def build_offline(ref, mk: dict, sd: dict):
     import copy
     model = ref.OfflineHILCodec(sample_rate=24000, channels_audio=1, **copy.deepcopy(mk)).eval()
     missing, unexpected = model.load_state_dict(sd, strict=False)
-    missing = [k for k in missing if not k.endswith("_extra_state")]
+    # `weight_scale` (weight standardisation) is a buffer the constructor fills from norm_kwargs['scale']
+    missing = [k for k in missing if not k.endswith("_extra_state") and not k.endswith(".weight_scale")]
     assert not missing and not unexpected, (missing, unexpected)
     for layer in model.quantizer.layers:
         layer.initted = True
     return model
 
 
-def build_streaming(ref, mk: dict, offline_model):
+def build_streaming(ref, mk: dict, offline_model, plain_weights: bool = False):
     """Reference streaming model (`models/hilcodec/streaming.py:651`) filled from an offline model
     with the offline->streaming correspondence that `scripts/HILCodec Onnx.ipynb` cell 1
     establishes, then `remove_weight_reparameterizations()` (`streaming.py:740-747`).
 
     The correspondence is expressed as (streaming module, offline module) pairs:
     streaming convs are bare (weight-normed) `nn.Conv1d`, offline ones sit two wrappers deep
-    (`SConv1d.conv.conv` / `SConvTranspose1d.convtr.convtr`)."""
+    (`SConv1d.conv.conv` / `SConvTranspose1d.convtr.convtr`).
+
+    `plain_weights`: the offline model's convs already carry plain `weight`s (re-parameterisation removed or folded by
+    the caller): the streaming model's weight_norm hooks are removed FIRST and the plain weights copied in."""
     import copy
     mk2 = copy.deepcopy(mk)
     for k in ("spec_learnable", "causal", "pad_mode"):
@@ -135,6 +139,12 @@ def build_streaming(ref, mk: dict, offline_model):
             pos += 1
     pairs.append((sdec.conv_post, seq[pos + 2]))
 
+    if plain_weights:
+        from torch.nn.utils import remove_weight_norm
+        import torch.nn as nn
+        for module in model.modules():
+            if isinstance(module, (nn.Conv1d, nn.ConvTranspose1d)) and hasattr(module, "weight_g"):
+                remove_weight_norm(module)
     for dst, src in pairs:
         dst.load_state_dict(inner(src).state_dict())
     for dst, src in scalars:
@@ -144,5 +154,7 @@ def build_streaming(ref, mk: dict, offline_model):
             tgt.embed.data.copy_(src.embed.data)
             tgt.ema_num.data.copy_(src.ema_num.data)
     model.eval()
+    if plain_weights:
+        model.norm = "none"                       # hooks are gone already; merge_scaling still has to run
     model.remove_weight_reparameterizations()
     return model

@@ -68,6 +68,35 @@ def oracle_clips(name, sd, mk, x, chunk=8, threads=None):
     return torch.cat(zs), torch.cat(ids), torch.cat(ws), dt, threads
 
 
+def cpu_worker(name: str, clips: int, samples: int, first: int, rendezvous: str, wid: int) -> None:
+    """One single-threaded CPU worker of the multi-process baseline (bench.py: cpu_baseline): builds the model's state
+    dict, warms up on one clip, waits at a file rendezvous until every worker is ready, runs its `clips` clips one at a
+    time through the oracle and prints its own wall-clock interval.  Never touches the GPU."""
+    import torch
+    from hilcodec_amd import synth
+    from oracle import hilcodec_oracle as O
+    torch.set_num_threads(1)
+    mk = synth.model_kwargs(name)
+    sd = synth.synth_state_dict(name, seed=7)
+    x = synth.synth_clips(clips, samples, seed=1234, first=first)
+    with torch.no_grad():
+        O.codec_forward(sd, x[:1, :, :min(samples, 4800)], mk)           # warm-up
+        open(os.path.join(rendezvous, f"ready{wid}"), "w").close()
+        go = os.path.join(rendezvous, "go")
+        deadline = time.time() + 600
+        while not os.path.exists(go):
+            if time.time() > deadline:
+                raise SystemExit("rendezvous timed out")
+            time.sleep(0.01)
+        t0 = time.time()
+        chk = 0
+        for i in range(clips):
+            _, _, _, aux = O.codec_forward(sd, x[i:i + 1], mk)
+            chk += int(aux["indices"].sum())
+        t1 = time.time()
+    print(json.dumps({"worker": wid, "t0": t0, "t1": t1, "clips": clips, "index_checksum": chk}), flush=True)
+
+
 def gpu_forward(model, x_dev):
     import torch
     with torch.no_grad():
@@ -116,7 +145,12 @@ if __name__ == "__main__":
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--cpu-worker", nargs=5, default=None, metavar=("CLIPS", "SAMPLES", "FIRST", "RENDEZVOUS", "ID"))
     a = ap.parse_args()
+    if a.cpu_worker:
+        c, smp, first, rdv, wid = a.cpu_worker
+        cpu_worker(a.model, int(c), int(smp), int(first), rdv, int(wid))
+        sys.exit(0)
     if a.lib:
         os.environ["HILC_LIB"] = os.path.abspath(a.lib)
     print(json.dumps(run_census(a.model, a.clips, a.batch)), flush=True)

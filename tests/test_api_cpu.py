@@ -237,3 +237,40 @@ def test_x3_weight_cache_follows_the_weight(monkeypatch):
     assert len(engine._X3_SPLIT) == 0
     assert engine.ExecOptions().decoder_gemm == "fp32"            # the default arithmetic is the reference's
     assert not hasattr(engine, "DECODER_GEMM") and not hasattr(engine, "SIDE_STREAM")     # no process-global switches
+
+
+def test_clip_chunks_keep_activations_below_32bit_offsets():
+    """engine: an offline batch whose largest activation would reach 4 GiB runs as the fewest equal clip chunks below it"""
+    from hilcodec_amd import engine
+    per_clip = 96 * 24000
+    assert engine._clip_chunks(256, per_clip) == [(0, 256)]
+    assert engine._clip_chunks(512, per_clip) == [(0, 256), (256, 512)]
+    for b in (467, 1000, 2048):
+        ch = engine._clip_chunks(b, per_clip)
+        assert ch[0][0] == 0 and ch[-1][1] == b and all(a[1] == c[0] for a, c in zip(ch, ch[1:]))
+        assert all((hi - lo) * per_clip * 4 < 2 ** 32 for lo, hi in ch) and max(hi - lo for lo, hi in ch) - min(hi - lo for lo, hi in ch) <= len(ch)
+    assert engine._clip_chunks(4, 2 ** 31) == [(0, 1), (1, 2), (2, 3), (3, 4)]          # a single clip above the limit still runs (generic cores)
+
+
+def test_streaming_model_takes_a_weight_standardised_checkpoint(golden):
+    """`load_offline_state_dict(sd, norm="weight_standardization", norm_kwargs=...)`: every conv folded to a plain weight
+    with the reference's expression (`modules/weight_standardization.py:30-41`) — the streaming classes themselves know
+    weight_norm only, like the reference's (`causal_layers.py:200-204`)."""
+    import torch
+    from hilcodec_amd import synth
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec as S
+    g = golden("ws_hil_speech")
+    mk = {k: v for k, v in synth.model_kwargs("hil_speech").items() if k not in ("spec_learnable", "causal", "pad_mode")}
+    sd = synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"]))
+    with pytest.raises(ValueError):
+        S(24000, norm="weight_standardization", **mk)
+    m = S(24000, **mk).eval()
+    with pytest.raises(ValueError):
+        m.load_offline_state_dict(sd, norm="spectral_norm")
+    m.load_offline_state_dict(sd, norm="weight_standardization", norm_kwargs={"eps": float(g["ws_eps"]), "scale": float(g["ws_scale"])})
+    keys = m.state_dict()
+    assert "decoder.upsample_depthwise.0.weight" in keys and "decoder.upsample_depthwise.0.weight_g" not in keys
+    assert torch.equal(keys["decoder.upsample_depthwise.0.weight"], torch.from_numpy(g["fold_probe_convtr"]))
+    assert torch.equal(keys["encoder.blocks.1.0.block.0.pointwise.1.weight"], torch.from_numpy(g["fold_probe_pw"]))
+    m.remove_weight_reparameterizations()               # hooks are gone already; merge_scaling still runs
+    assert "encoder.spec_post.layer.bias" in m.state_dict()

@@ -99,3 +99,73 @@ def test_streaming_equals_offline_encoder_on_zero_caches():
         zs, _ = sm.encoder(x, *ce)
         zo = model.encoder(x)
     assert (zs.transpose(1, 2) - zo).abs().max() < 2e-5
+
+
+def test_rank7_shard_of_configs4_full_size(golden):
+    """BASELINE configs[4] (hil_music, 2048 clips over 8 GPUs = 256 per rank) at its REAL per-GPU size for a rank != 0:
+    rank 7's full 256-clip shard (clips 1792..2047 of the global batch — other seeds than any other golden) through the
+    HIP path exactly as `bench.py` builds it; the shard's first 8 clips are pinned by the REAL reference
+    (tests/golden/shard_rank7_hil_music.npz), three picks are batch-invariant bit for bit, and `bench.py --emulate-rank 7
+    --emulate-world 8` at full size prints the same index checksum.  (The reference has no multi-GPU inference to compare
+    with: `/root/reference/train.py:51-61` is its only NCCL setup.)"""
+    import bench
+    from hilcodec_amd import distributed as D
+    from tests.test_gpu_bench import run_bench
+    g = golden("shard_rank7_hil_music")
+    dev = torch.device("cuda:0")
+    lo, hi = D.shard_range(256 * 8, 7, 8)
+    assert (lo, hi) == (int(g["first"]), int(g["first"]) + int(g["shard_clips"])) == (1792, 2048)
+    step, audio_s, ctx = bench.offline_workload("hil_music", hi - lo, lo, 24000, dev)
+    assert audio_s == 256.0
+    with torch.no_grad():
+        idx, wav = step(0)
+    z = ctx["last"]["z"]
+    assert idx.shape == (256, 12, 75) and wav.shape == (256, 1, 24000) and torch.isfinite(wav).all()
+    n = g["indices"].shape[0]
+    flips = int((idx[:n].cpu() != T(g["indices"]).long()).sum())
+    print(f"rank-7 shard: {n * 12 * 75} argmins against the real reference, flips = {flips}")
+    assert flips == 0
+    assert (z[:n, :, ::5].cpu() - T(g["z_probe"])).abs().max() < 2e-5
+    assert (wav[:n, :, ::25].cpu() - T(g["wav_probe"])).abs().max() < 1e-4
+    # batch invariance inside the shard, bit for bit
+    model = ctx["model"]
+    pick = [5, 131, 255]
+    x = synth.synth_clips(256, 24000, seed=1234, first=lo)[pick].to(dev)
+    z1, _, idx1, wav1, _ = run(model, x)
+    assert torch.equal(z1, z[pick]) and torch.equal(idx1, idx[pick]) and torch.equal(wav1, wav[pick])
+    # the bench line of the emulated rank at FULL size carries the same checksum
+    d = run_bench("--emulate-rank", "7", "--emulate-world", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                  "--no-clock-probe", "--no-launch-timing")
+    assert d["config"]["shard"] == [1792, 2048] and d["config"]["global_batch"] == 2048
+    assert "configs[4]" in d["config"]["workload"] and "hil_music" in d["config"]["workload"]
+    assert d["index_checksum"] == int(idx.sum().item())
+
+
+def test_batch_beyond_4gib_activations_keeps_the_fast_kernels():
+    """B = 512 x 1 s: the decoder's [512, 96, 24000] activations are 4.7 GB, beyond the 32-bit byte offsets of the linear GEMM
+    cores and the fused block (csrc/gemm_epilogues.h: lin_ok, csrc/resblock.hip) — the engine runs equal clip chunks instead
+    of letting every launch fall back to the generic core: bit-identical to two B = 256 runs, and as fast as those."""
+    import time
+    from hilcodec_amd import engine
+    dev = torch.device("cuda:0")
+    model, mk = build("hil_speech")
+    x = synth.synth_clips(512, 24000, seed=4000).to(dev)
+    assert len(engine._clip_chunks(512, 96 * 24000)) == 2 and len(engine._clip_chunks(256, 96 * 24000)) == 1
+
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return out, sorted(ts)[reps // 2]
+
+    run(model, x[:256].contiguous())                      # warm-up (folds, tables)
+    (z, q, idx, wav, _), t512 = timed(lambda: run(model, x))
+    halves, t256 = timed(lambda: [run(model, x[:256].contiguous()), run(model, x[256:].contiguous())])
+    (za, _, ia, wa, _), (zb, _, ib, wb, _) = halves
+    assert torch.equal(torch.cat([za, zb]), z) and torch.equal(torch.cat([ia, ib]), idx) and torch.equal(torch.cat([wa, wb]), wav)
+    print(f"B=512: {t512 * 1e3:.1f} ms, two B=256 runs: {t256 * 1e3:.1f} ms")
+    assert t512 < 1.05 * t256

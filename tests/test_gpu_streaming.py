@@ -342,6 +342,114 @@ def test_streaming_1024_streams_full_size(golden):
     assert torch.equal(idx_g, idx) and torch.equal(wav_g, wav)
     for a, b in zip(caches_g, caches):
         assert torch.equal(a, b)
+    # (5) every schedule bench.py reports, at full size, against the eager loop bit for bit: indices, wav (the pipelined
+    # schedules deliver it one replay later), all 22 + 30 caches.  The reference's protocol is the plain loop
+    # (`scripts/HILCodec Onnx.ipynb` cell 3, `test_onnx.py:75-135`).
+    from hilcodec_amd.graph_step import PipelinedHop
+    for make, pipelined in ((lambda: GraphedHop(model, B, 320, 8, dev, groups=2), False),
+                            (lambda: PipelinedHop(model, B, 320, 8, dev, groups=1), True),
+                            (lambda: PipelinedHop(model, B, 320, 8, dev, groups=2), True)):
+        hopper = make()
+        ids, ws = [], []
+        with torch.no_grad():
+            for h in range(hops):
+                i_h, w_h = hopper.step(x[:, :, 320 * h: 320 * (h + 1)])
+                ids.append(i_h.clone())
+                if pipelined:
+                    assert (w_h is None) == (h == 0)
+                if w_h is not None:
+                    ws.append(w_h.clone())
+            if pipelined:
+                ws.append(hopper.flush().clone())
+        assert torch.equal(torch.cat(ids, 2), idx), type(hopper).__name__
+        assert torch.equal(torch.cat(ws, 2), wav), type(hopper).__name__
+        got = list(hopper.cache_enc) + list(hopper.cache_dec)
+        assert len(got) == 52
+        for i, (a, b) in enumerate(zip(got, caches)):
+            assert torch.equal(a, b), f"{type(hopper).__name__} cache {i}"
+        del hopper
+        torch.cuda.empty_cache()
+
+
+def test_grouped_schedules_export_and_resume():
+    """A grouped schedule exports its caches in the reference's order (`cache_enc` / `cache_dec`, concatenated over the
+    groups) and resumes from them: run 2 hops, export, build a NEW hopper, `reset(exported)`, the remaining hops equal the
+    uninterrupted run bit for bit — GraphedHop(groups=2), and PipelinedHop(groups=2) after a flush()."""
+    from hilcodec_amd.graph_step import GraphedHop, PipelinedHop
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming()
+    B, hops = 6, 5
+    x = synth.synth_clips(B, 320 * hops, seed=79).to(dev)
+    ce, cd = model.initialize_cache(x)
+    eager = []
+    with torch.no_grad():
+        for h in range(hops):
+            z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)].contiguous(), *ce)
+            idx = model.quantizer(z, 8)
+            wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+            eager.append((idx.clone(), wav.clone()))
+    g = GraphedHop(model, B, 320, 8, dev, groups=2)
+    for h in range(2):
+        g.step(x[:, :, 320 * h: 320 * (h + 1)])
+    saved = ([c.clone() for c in g.cache_enc], [c.clone() for c in g.cache_dec])
+    assert len(saved[0]) == 22 and len(saved[1]) == 30 and all(c.shape[0] == B for c in saved[0] + saved[1])
+    g2 = GraphedHop(model, B, 320, 8, dev, groups=3)             # another grouping resumes from the same export
+    g2.reset(*saved)
+    for h in range(2, hops):
+        idx, wav = g2.step(x[:, :, 320 * h: 320 * (h + 1)])
+        assert torch.equal(idx, eager[h][0]) and torch.equal(wav, eager[h][1])
+    p = PipelinedHop(model, B, 320, 8, dev, groups=2)
+    for h in range(2):
+        p.step(x[:, :, 320 * h: 320 * (h + 1)])
+    assert torch.equal(p.flush(), eager[1][1])
+    for a, b in zip(list(p.cache_enc) + list(p.cache_dec), saved[0] + saved[1]):
+        assert torch.equal(a, b)
+    p2 = PipelinedHop(model, B, 320, 8, dev, groups=1)
+    p2.reset(p.cache_enc, p.cache_dec)
+    for h in range(2, hops):
+        idx, wav = p2.step(x[:, :, 320 * h: 320 * (h + 1)])
+        assert torch.equal(idx, eager[h][0])
+        assert wav is None if h == 2 else torch.equal(wav, eager[h - 1][1])
+    assert torch.equal(p2.flush(), eager[hops - 1][1])
+
+
+def test_stream_wide_blocks_option_reaches_both_halves():
+    """`exec_options.stream_wide_blocks` (one launch per wide residual block of a hop, or two as in round 2) is honoured by
+    the ENCODER's and the DECODER's blocks and changes no bit (model level; the op-level pin is in test_gpu_ops.py)."""
+    from hilcodec_amd import ops
+    dev = torch.device("cuda:0")
+    model, mk, sd = build_streaming()
+    B, hops = 8, 3
+    x = synth.synth_clips(B, 320 * hops, seed=80).to(dev)
+
+    def run(flag):
+        model.encoder.exec_options.stream_wide_blocks = flag
+        model.decoder.exec_options.stream_wide_blocks = flag
+        ce, cd = model.initialize_cache(x)
+        outs, kinds = [], []
+        with torch.no_grad():
+            for h in range(hops):
+                with ops.timed_launches() as t:
+                    z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)].contiguous(), *ce)
+                    n_enc = len(t.records)
+                    idx = model.quantizer(z, 8)
+                    wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+                kinds.append((sum(r[0] == "resblock" for r in t.records[:n_enc]), sum(r[0] == "resblock" for r in t.records[n_enc:])))
+                outs.append((z.clone(), idx.clone(), wav.clone()))
+        return outs, kinds, list(ce) + list(cd)
+
+    try:
+        one, k_one, c_one = run(True)
+        two, k_two, c_two = run(False)
+    finally:
+        model.encoder.exec_options.stream_wide_blocks = True
+        model.decoder.exec_options.stream_wide_blocks = True
+    # the encoder has 4 wide blocks (C = 256, 512 x 2 each), the decoder 6 (C = 768, 384 x 3 each) that leave the fused kernel
+    assert k_one[0][0] - k_two[0][0] == 4 and k_one[0][1] - k_two[0][1] == 6, (k_one[0], k_two[0])
+    for (z1, i1, w1), (z2, i2, w2) in zip(one, two):
+        assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
+    for a, b in zip(c_one, c_two):
+        assert torch.equal(a, b)
 
 
 def test_captured_resblock_needs_its_own_scheduler_words():
@@ -375,3 +483,35 @@ def test_captured_resblock_needs_its_own_scheduler_words():
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ref) and int(ws.words.abs().sum()) == 0          # the kernel re-armed its ticket words
+
+
+def test_streaming_weight_standardised_checkpoint(golden):
+    """A checkpoint of the offline `HILCodec(norm="weight_standardization")` through the streaming model, hop by hop, against
+    the REAL reference's streaming model carrying the weights its own `WeightStandardization.compute_weight` produced
+    (tests/golden/ws_hil_speech.npz; the reference's streaming classes know weight_norm only, so folded plain weights are
+    the only way in — `oracle/make_golden.py: ws_golden`): z, indices, wav and all 52 caches after 5 hops."""
+    from hilcodec_amd.models.hilcodec.streaming import HILCodec
+    g = golden("ws_hil_speech")
+    dev = torch.device("cuda:0")
+    mk = {k: v for k, v in synth.model_kwargs("hil_speech").items() if k not in ("spec_learnable", "causal", "pad_mode")}
+    sd = synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"]))
+    model = HILCodec(24000, **mk).eval()
+    model.load_offline_state_dict(sd, norm="weight_standardization",
+                                  norm_kwargs={"eps": float(g["ws_eps"]), "scale": float(g["ws_scale"])})
+    model.remove_weight_reparameterizations()
+    hops = int(g["s_hops"])
+    x = synth.synth_clips(1, 320 * hops, seed=int(g["s_clip_seed"])).to(dev)
+    ce, cd = model.initialize_cache(x)
+    zs, ids, ws = [], [], []
+    with torch.no_grad():
+        for h in range(hops):
+            z, ce = model.encoder(x[:, :, 320 * h: 320 * (h + 1)], *ce)
+            idx = model.quantizer(z, 8)
+            w, cd = model.decoder(model.dequantizer(idx, 8), *cd)
+            zs.append(z); ids.append(idx); ws.append(w)
+    assert (torch.cat(zs, 1).cpu() - T(g["s_z"])).abs().max() < 2e-5
+    assert torch.equal(torch.cat(ids, 2).cpu(), T(g["s_indices"]).long())
+    assert (torch.cat(ws, 2).cpu() - T(g["s_wav"])).abs().max() < 1e-4
+    for i, c in enumerate(list(ce) + list(cd)):
+        ref = T(g[f"e_out{i}"] if i < 22 else g[f"d_out{i - 22}"])
+        assert c.shape == ref.shape and (c.cpu() - ref).abs().max() < 5e-5, i

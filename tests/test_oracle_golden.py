@@ -224,3 +224,51 @@ def test_realistic_and_adversarial_inputs(golden):
         assert torch.isfinite(wav_a).all() and float(loss_a) == float(g["adv_loss"])
         q, _, _, idx = O.rvq_forward(sd, T(g["near_z"]), None, 8)
         assert torch.equal(idx, T(g["near_indices"]).long()) and torch.equal(q[:, :, ::7], T(g["near_q_probe"]))
+
+
+def test_shard_rank7_prefix(golden):
+    """BASELINE configs[4]: the first 8 clips of rank 7's 256-clip shard (hil_music, clips 1792..1799), from the REAL reference."""
+    g = golden("shard_rank7_hil_music")
+    mk = synth.model_kwargs("hil_music")
+    sd = synth.synth_state_dict("hil_music", seed=int(g["weight_seed"]))
+    x = synth.synth_clips(2, 24000, seed=int(g["clip_seed"]), first=int(g["first"]) + 3)       # clips 1795, 1796: the oracle is pinned on two
+    with torch.no_grad():
+        wav, _, _, aux = O.codec_forward(sd, x, mk)
+    assert torch.equal(aux["indices"], T(g["indices"]).long()[3:5])
+    assert torch.equal(aux["z"][:, :, ::5], T(g["z_probe"])[3:5])
+    assert torch.equal(wav[:, :, ::25], T(g["wav_probe"])[3:5])
+
+
+def test_weight_standardization_whole_model(golden):
+    """`HILCodec(norm="weight_standardization")` (`conv.py:36-37`, `modules/weight_standardization.py:30-41`), offline and —
+    through folded plain weights, the only way the reference's weight_norm-only streaming classes can carry such a
+    checkpoint — streaming with every cache."""
+    g = golden("ws_hil_speech")
+    mk = synth.model_kwargs("hil_speech")
+    sd = O.with_weight_standardization(synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"])), float(g["ws_scale"]))
+    x = synth.synth_clips(2, int(g["samples"]), seed=int(g["clip_seed"]))
+    with torch.no_grad():
+        wav, _, loss, aux = O.codec_forward(sd, x, mk)
+        assert torch.equal(aux["z"], T(g["z"])) and torch.equal(aux["indices"], T(g["indices"]).long())
+        assert torch.equal(wav, T(g["wav"])) and float(loss) == float(g["loss"])
+        w, _ = O.conv_weight(sd, "decoder.model.4.convtr.convtr")
+        assert torch.equal(w, T(g["fold_probe_convtr"]))
+        w, _ = O.conv_weight(sd, "encoder.blocks.1.0.block.1.conv.conv")
+        assert torch.equal(w, T(g["fold_probe_pw"]))
+        p = O.stream_prepare(sd, mk)
+        hops = int(g["s_hops"])
+        xs = synth.synth_clips(1, 320 * hops, seed=int(g["s_clip_seed"]))
+        ce, cd = O.stream_init_cache(mk, 1)
+        zs, ids, ws = [], [], []
+        for h in range(hops):
+            z, ce = O.stream_encoder(p, mk, xs[:, :, 320 * h: 320 * (h + 1)], ce)
+            idx = O.stream_quantize(p, z, 8)
+            w, cd = O.stream_decoder(p, mk, O.stream_dequantize(p, idx, 8), cd)
+            zs.append(z); ids.append(idx); ws.append(w)
+        assert torch.equal(torch.cat(zs, 1), T(g["s_z"]))
+        assert torch.equal(torch.cat(ids, 2), T(g["s_indices"]).long())
+        assert torch.equal(torch.cat(ws, 2), T(g["s_wav"]))
+        for i, c in enumerate(ce):
+            assert torch.equal(c, T(g[f"e_out{i}"])), i
+        for i, c in enumerate(cd):
+            assert torch.equal(c, T(g[f"d_out{i}"])), i
