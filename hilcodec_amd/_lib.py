@@ -41,6 +41,10 @@ SIGNATURES = {
     "hilc_up_conv_expanded": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "hilc_resblock_chain_supported": [_i, _i, _i, _i],
+    "hilc_resblock_chain_row_classes": [_i],
+    "hilc_resblock_pack_weights_rc": [_p, _p, _i, _i, _p],
+    "hilc_resblock_chain": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
@@ -63,7 +67,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def source_hash() -> str:
@@ -79,6 +83,12 @@ def source_hash() -> str:
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+class ResblockParams(C.Structure):
+    """`hilc_resblock_params` of include/hilcodec_amd.h: one residual block of a chain launch"""
+    _fields_ = [("w1t", _p), ("dw1_w", _p), ("dw1_b", _p), ("w2t", _p), ("dw2_w", _p), ("dw2_b", _p),
+                ("hist1", _p), ("hist2", _p), ("hist1_out", _p), ("hist2_out", _p), ("pre_scale", _f), ("out_scale", _f)]
 
 
 class HilcodecLibraryError(RuntimeError):

@@ -1,442 +1,7 @@
-// Fully fused SEANet residual block for the narrow, long layers (C <= 192), gfx950.
-//
-//   y = x + out_scale * dw2( pw2( ELU( dw1( pw1( ELU(pre_scale * x) ) ) + b1 ) ) ) + b2 )      (seanet.py:129-148)
-//
-// For C in {64, 96} the un-fused block is HBM-bound (1x1 conv intensity = C/4 flop/B): this kernel reads x ONCE and
-// writes y once; everything between lives in registers and one LDS tile.
-//
-// Workgroup = NW waves walking a CONTIGUOUS run of tiles; a tile = NCOL columns of one clip (see Cfg), column c <-> time
-// t0 + c with t0 = NCOL * (tile within the clip).  The two causal k = 5 convs need the 4 columns in front of a tile of H1 and
-// of H2: the previous tile of the run leaves them in LDS (CARRY), a clip's first tile takes zeros (streaming: the caches).  A run
-// that starts inside a clip walks the tile in front of it once without storing anything (warm-up).  No column is computed twice
-// (rounds 1-3 recomputed an 8-column halo per tile: 6.25 % of the GEMM work).
-//   P0  a1 = ELU(pre*x) from the x REGISTERS (loaded during the previous tile's P6)  -> LDS  X[k][c]
-//   P1  GEMM1  H1 = W1 * a1   (fp32 MFMA 32x32x2; a wave owns one 32-column block and CBW row blocks)
-//   P2  accumulators -> LDS  X[m][c]
-//   P3  a2 = ELU(dw1(H1)+b1) in place (a row is handled by one wave instruction, so read-before-write holds
-//       without a barrier, for the tile and for the carry)
-//   P4  GEMM2  H2 = W2 * a2
-//   P5  accumulators -> LDS
-//   P6  y = (dw2(H2)+b2)*out_scale + x (the shortcut comes from the x registers: no re-read) -> HBM; as soon as a
-//       row batch is stored its x registers are re-loaded with the NEXT tile's rows, so the loads travel under the
-//       rest of P6 / the barrier and P0 never waits for HBM (the next tile's lines were touched into this XCD's L2
-//       during GEMM2).
-// Cost model behind this shape (profiles/r02_mfma_shadow_microbench.txt): next to fp32 MFMAs (64 cycles each) LDS
-// traffic and sparse global loads are free, a VALU instruction costs ~2.8 cycles of the same pipe (4.9 when a SIMD
-// hosts a single wave: one wave cannot issue VALU back to back), v_exp_f32 8.4.  Hence: (i) the element-wise phases
-// process rows in BATCHES — all LDS reads of a batch, then the arithmetic, then the writes; the in-place row
-// update used to serialise on one exposed LDS round trip per row (P3 / P6 ran at a third of their VALU rate);
-// (ii) every LDS address is base + compile-time constant (a select in an address hides the no-alias fact from the
-// scheduler); (iii) C = 192, whose 96 KB tile allows one workgroup per CU, runs 8 waves (two per SIMD, each owning
-// half of the row blocks) so that the VALU phases issue at full rate.
-// A operands (weights) are read straight from global memory (L1/L2 resident, a few tens of KB) into VGPRs one
-// 16-deep K slice ahead — no LDS staging, no barrier in the K loop.
-// Summation order: k ascending (an fmaf chain), taps j = 0..4 — the same as the un-fused kernels.
-//
-// STREAM instantiation (hilc_resblock_stream; streaming.py:195-276 with causal_layers.py:147-167 caches): the
-// tile walks the FLAT column space (clip-major, b*T + t) so short hops (T = 160 / 320 per stream) still fill
-// 120 of 128 columns; the 4 samples before a clip's t = 0 come from the caches hist1 / hist2 (= last 4
-// pointwise outputs of the previous hop) instead of the LDS neighbours, and the lanes holding t = T-4..T-1
-// store the new caches.  Per-column arithmetic is identical, so hop-by-hop output == offline output bit for bit.
-#include <stdlib.h>
-
-#include <atomic>
-#include <type_traits>
-
-#include "gemm_core.h"
-
-using namespace hilc;
+// Entry points of the fused residual block, one block per launch (kernel: resblock_kernel.h).
+#include "resblock_kernel.h"
 
 namespace {
-
-constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1, w2_0, w2_1 | w2_2..4, b2]
-
-// Shape of a workgroup.  Offline: ONE 8-wave workgroup per CU (two waves per SIMD) that moves through the phases in
-// lockstep — co-resident workgroups in different phases do not help each other here: beside another wave's MFMA
-// stream a VALU phase gets a fraction of its stand-alone issue rate while the matrix wave gains nothing (fp32 MFMA and
-// VALU share the pipe), and 4-wave workgroups leave SIMDs idle at every barrier.  Tile width 256 columns where the
-// tile fits LDS (C <= 128: 248 of 256 columns useful instead of 120 of 128; a wave owns one 32-column block and all
-// row blocks), 128 columns for C = 192 (a wave owns a column block and HALF of the row blocks).
-// STREAM: 128-column tiles over the flat clip-major column space (hops are short), 4 waves (8 for C = 192).
-#ifndef HILC_RES_WIDE_MASK
-#define HILC_RES_WIDE_MASK 0   // bit 0: C = 64, bit 1: C = 96, bit 2: C = 128 use the wide lockstep shape (tuning: tools/res_bench.py)
-#endif
-// run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
-// (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
-// 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
-#ifndef HILC_RES_SHARE2_0
-#define HILC_RES_SHARE2_0 0.64
-#endif
-#ifndef HILC_RES_SHARE3_0
-#define HILC_RES_SHARE3_0 0.44
-#define HILC_RES_SHARE3_1 0.31
-#endif
-template <int C>
-constexpr bool wide_shape() {
-  return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
-}
-
-template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false>
-struct Cfg {
-  static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
-  static constexpr int CH = C;
-  static constexpr int CB = C / 32;
-  static constexpr bool WIDE = !STREAM && wide_shape<C>();
-  // NARROW (STREAM, C >= 256: the wide blocks of a streaming hop, 8 or 40 frames per stream): the whole channel range of a
-  // 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).  At 32 columns a tile is
-  // whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the previous samples, so
-  // there is no halo to recompute.
-  static constexpr bool NARROW = STREAM && C >= 256;
-  static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
-  // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
-  // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
-  // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
-  // strided / ticketed tile order: a hop is 2.5-5 tiles per workgroup, runs would rarely start on a stream's t = 0 and each start
-  // inside a stream costs a warm-up tile (measured: 5.34 -> 6.26 ms per hop with two stream groups).
-  // SCARRY: the carry form for a STREAMING launch whose geometry lets every run start on a stream's t = 0 (launch_res decides:
-  // 1024 streams x 160 samples = 256 runs of exactly 5 tiles = 4 whole streams each, five rounds of tiles instead of six).
-  static constexpr bool CARRYMODE = !STREAM || SCARRY_;
-  static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
-  static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = (WIDE || C >= 192) ? 8 : 4;           // waves per workgroup
-  static constexpr int NT = 64 * NW;
-  static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
-  static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
-  static constexpr int RPI = 256 / NCOL;             // rows covered by one wave instruction of the element-wise phases
-  static constexpr int RSTEP = RPI * NW;
-  static constexpr int RW = C / RSTEP;               // rows per lane there
-#ifndef HILC_RES_RB
-#define HILC_RES_RB 4
-#endif
-  static constexpr int RB = HILC_RES_RB;             // rows per batch there
-  // weight stream: DEPTH register sets of KP k-pairs each; the loads run DEPTH-1 sets (= (DEPTH-1)*KP*CBW MFMAs per
-  // wave, twice that in wall time with two waves per SIMD) ahead of their use
-#ifdef HILC_RES_KP
-  static constexpr int KP = HILC_RES_KP;
-  static constexpr int DEPTH = HILC_RES_DEPTH;
-#else
-  static constexpr int KP = C >= 128 ? 4 : 8;
-  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
-#endif
-#ifndef HILC_RES_MINW
-#define HILC_RES_MINW 2
-#endif
-  static constexpr int MINW = NW == 8 ? 2 : HILC_RES_MINW;   // waves per SIMD the register budget must allow
-  static_assert(NW % (NCOL / 32) == 0 && CB % RH == 0 && RW % RB == 0 && C % RSTEP == 0, "tile split");
-};
-
-struct ResArgs {
-  const float* x;
-  const float* w1t;   // packed, see WeightPipe
-  const float* dw1_w; // [C][5]
-  const float* dw1_b; // [C]
-  const float* w2t;
-  const float* dw2_w;
-  const float* dw2_b;
-  float* y;
-  int T, tiles;
-  int classes;        // carry form: workgroups per CU (0 = equal runs) and the cumulative run shares of the dispatch classes, 16-bit fractions
-  unsigned cum[5];
-  long total_tiles;
-  float pre_scale, out_scale;
-  int B;
-  unsigned div_magic, div_shift;   // STREAM: n / T == __umulhi(n, div_magic) >> div_shift for n < 2^31
-  const float* hist1;   // STREAM: [B][C][4] caches of the two depthwise convs (NULL = zeros), and their successors
-  const float* hist2;
-  float* hist1_out;
-  float* hist2_out;
-  // optional dynamic tile scheduler: two ints, zero at launch and zero again at exit.  Co-resident workgroups do
-  // not share a CU fairly (the older one wins issue arbitration), so with static tile lists part of the kernel runs
-  // at reduced occupancy; with tickets the faster workgroup simply takes more tiles.
-  int* sched;
-  unsigned long long* dbg;   // optional [tiles][8] s_memtime stamps (HILC_DEBUG_STAMPS builds, tools/res_phase_times.py)
-};
-
-#ifdef HILC_DEBUG_STAMPS
-unsigned long long* g_dbg = nullptr;   // tools/res_phase_times.py builds its own copy of the library with this
-#endif
-
-// The weight pointers go through an empty asm (LICM fence, see resblock_kernel) and come back without their
-// address space: loads through them would be FLAT instructions (LDS-or-global check, both wait counters).  This
-// type puts them back into the global address space -> global_load.
-typedef const __attribute__((address_space(1))) float* gptr_t;
-// the same for the laundered LDS row pointers: keep them 32-bit LDS pointers (ds_read / ds_write, not flat_load)
-typedef __attribute__((address_space(3))) float* lptr_t;
-typedef __attribute__((address_space(3))) f32x4* lvec_t;
-typedef __attribute__((address_space(3))) f32x2* lvec2_t;
-
-// Packed ("MFMA lane order") weights, produced by hilc_resblock_pack_weights from the k-major [K][C] matrix.  For
-// the wave class h (row half, RH of them) and K slice kt the 8*CBW operands a lane feeds to the MFMAs sit in
-// NQ = 2*CBW consecutive 16-B words per lane and a wave's 64 lanes read 1 KiB contiguous per load:
-//   packed[(((h * C/16 + kt) * NQ + q) * 64 + lane) * 4 + e] = W[kt*16 + 2j + (lane >> 5)][32*(h*CBW + i) + (lane & 31)]
-//   with q*4 + e = j*CBW + i   (j = k-pair of the slice, i = row block of the wave).
-// DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the shadow of the MFMAs of slice kt; the
-// first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise phase that precedes the GEMM.
-template <class K>
-struct WeightPipe {
-  static constexpr int CBW = K::CBW;
-  static constexpr int DEPTH = K::DEPTH;
-  static constexpr int KP = K::KP;              // k-pairs per register set (8 = one 16-deep slice, 4 = half of one)
-  static constexpr int WPS = KP * CBW / 4;      // 16-B words per lane and set (consecutive in the packed array)
-  static_assert(KP * CBW % 4 == 0 && 8 % KP == 0, "register set = whole 16-B words");
-  float a[DEPTH][KP][CBW];
-  // wset: UNIFORM pointer to the set's first word (scalar base + lane offset + immediate: no per-lane 64-bit adds)
-  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
-    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
-    const f32x4 v = *(gvec_t)(wset + q * 256 + lane * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CBW][(q * 4 + e) % CBW] = v[e];
-  }
-  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
-  }
-};
-
-// wt: this wave class's part of the packed matrix;  X: LDS tile;  colblk: the wave's 32-column block
-template <class K>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                           WeightPipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS;
-  constexpr int CBW = K::CBW;
-  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
-  constexpr int NSETS = C / 2 / KP;
-  const int kh = lane >> 5, l31 = lane & 31;
-  // this lane's B column: X[(2p+kh)][32*colblk + l31], p = k-pair.  `xn` walks ahead of the MFMAs one register set at a
-  // time and is laundered after every step: a DS instruction reaches 64 KB past its base register, the tile is up to
-  // 136 KB, and left alone hipcc materialises one base register per far row and keeps them all alive (spilling them).
-  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
-  float b[DEPTH][KP];
-#pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d) {
-#pragma unroll
-    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
-    xn += KP * 2 * XS;
-    asm volatile("" : "+v"(xn));
-  }
-  // Issue order, pinned: the weight words of set s+DEPTH-1 are spread over the MFMAs of set s (one every fourth),
-  // its LDS operand reads one per k-pair.
-  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
-#pragma unroll
-  for (int s = 0; s < NSETS; ++s) {
-    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
-    const int sn = s + DEPTH - 1;
-    const bool more = sn < NSETS;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      if (more) b[nxt][j] = xn[j * 2 * XS];
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int n = j * CBW + i;                   // MFMA index inside the set
-        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        // The pure MFMA intrinsic is free to move at IR level and hipcc sinks a whole GEMM phase's MFMAs below all of
-        // its operand loads (every operand then spills).  Default: builtins pinned per register set (end of this loop);
-        // -DHILC_RES_ASM_MFMA: the former form, a volatile asm per MFMA (keeps its place among the loads, but hides the
-        // instruction's hazards from the compiler).
-#ifndef HILC_RES_ASM_MFMA        // builtin MFMAs, pinned per register set (below); HILC_RES_ASM_MFMA = the former asm form, for A/B
-        if (s == 0 && j == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        }
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-#else
-        if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
-        else
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
-#endif
-      }
-    }
-    if (more) {
-      xn += KP * 2 * XS;
-      wn += WPS * 256;
-      asm volatile("" : "+v"(xn), "+s"(wn));
-    }
-#ifndef HILC_RES_ASM_MFMA
-    // pin the set: an empty asm that "updates" the accumulators and clobbers memory keeps this set's MFMAs above it and
-    // the later sets' loads below it.  The builtins are pure, and left alone hipcc sinks a whole phase's MFMAs under all of
-    // its operand loads (~300 spilled registers); pinned, they schedule as written, need fewer registers than the asm form
-    // (C = 192: 202 instead of 219) and — unlike asm — carry their hazard information: the bf16x3 phases, first written
-    // with asm MFMAs fed by VALU conversions, produced rare garbage tiles that no manual wait state fixed.
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
-#endif
-  }
-#ifndef HILC_RES_ASM_MFMA
-  return;
-#endif
-  // the accumulators are read next by non-MFMA instructions (ds_write after a barrier): the compiler cannot see
-  // into the asm, so the 16-pass MFMA -> VALU/DS read hazard (18 wait states) is covered by hand
-  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-}
-
-// The same phase ROLLED, for the wide channel counts of the NARROW stream shapes (C = 768: 96 register sets of 12 MFMAs —
-// fully unrolled that is 25 KB of code per phase): a loop over groups of DEPTH sets, so that the register-set indices stay
-// compile-time; issue order, products and k order are those of gemm_phase.
-template <class K>
-__device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                                  WeightPipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS;
-  constexpr int CBW = K::CBW;
-  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
-  constexpr int NSETS = C / 2 / KP;
-  static_assert(NSETS % DEPTH == 0 && NSETS >= 2 * DEPTH, "whole groups of register sets");
-  constexpr int NG = NSETS / DEPTH;
-  const int kh = lane >> 5, l31 = lane & 31;
-  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
-  float b[DEPTH][KP];
-#pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d) {
-#pragma unroll
-    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
-    xn += KP * 2 * XS;
-    asm volatile("" : "+v"(xn));
-  }
-  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
-#pragma unroll
-  for (int i = 0; i < CBW; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  auto one_set = [&](auto dc, bool more) {
-    constexpr int cur = decltype(dc)::value, nxt = (cur + DEPTH - 1) % DEPTH;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      if (more) b[nxt][j] = xn[j * 2 * XS];
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int n = j * CBW + i;
-        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-      }
-    }
-    if (more) {
-      xn += KP * 2 * XS;
-      wn += WPS * 256;
-      asm volatile("" : "+v"(xn), "+s"(wn));
-    }
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");      // pin the set (see gemm_phase)
-  };
-  auto group = [&](bool last) {
-    one_set(std::integral_constant<int, 0>{}, true);       // set s = g*DEPTH fetches set s + DEPTH - 1: inside this group
-    if constexpr (DEPTH > 1) one_set(std::integral_constant<int, 1>{}, !last);
-    if constexpr (DEPTH > 2) one_set(std::integral_constant<int, 2>{}, !last);
-    if constexpr (DEPTH > 3) one_set(std::integral_constant<int, 3>{}, !last);
-    static_assert(DEPTH <= 4, "group body");
-  };
-#pragma nounroll
-  for (int g = 0; g < NG - 1; ++g) group(false);
-  group(true);
-}
-
-// ---- EXPERIMENTAL bf16x3 GEMM phases (hilc_resblock_x3; opt-in, offline decoder only; see gemm_x3.h for the arithmetic) ----
-// Only the two GEMM phases change: the tile in LDS stays fp32 (the depthwise / ELU phases are untouched).  A wave reads
-// the 8 consecutive k of its column for a 16-deep step with eight ds_read_b32, splits them in registers (2.5 VALU per
-// value) and feeds three v_mfma_f32_32x32x16_bf16 per row block; the weights arrive pre-split and packed in lane order
-//   packed16[((((h * C/16 + ks) * CBW + i) * 2 + part) * 64 + lane) * 8 + e] = part(W[ks*16 + 8*(lane >> 5) + e][32*(h*CBW + i) + (lane & 31)])
-// (one 16-B word per lane, row block and part: hilc_resblock_pack_weights_x3; same byte size as the fp32 packing).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-
-template <class K>
-struct X3Pipe {
-  static constexpr int CBW = K::CBW;
-  static constexpr int DEPTH = 3;                 // 16-deep steps between a weight load and its use
-  static constexpr int WPS = 2 * CBW;             // 16-B words per lane and step
-  f32x4 a[DEPTH][CBW][2];
-  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
-    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
-    a[slot][q >> 1][q & 1] = *(gvec_t)(wset + q * 256 + lane * 4);
-  }
-  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
-  }
-};
-
-// 8 fp32 -> bf16 heads and bf16 heads of the remainders, as two 4-register MFMA operands
-__device__ __forceinline__ void split8(const float (&v)[8], f32x4& hi, f32x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const f32x2 x = {v[2 * p], v[2 * p + 1]};
-    const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
-    const f32x2 r = x - __builtin_convertvector(h, f32x2);
-    const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
-    hi[p] = __builtin_bit_cast(float, h);
-    lo[p] = __builtin_bit_cast(float, l);
-  }
-}
-
-template <class K>
-__device__ __forceinline__ void gemm_phase_x3(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                              X3Pipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS, CBW = K::CBW;
-  constexpr int DEPTH = X3Pipe<K>::DEPTH, WPS = X3Pipe<K>::WPS;
-  constexpr int KS = C / 16;
-  const int kh = lane >> 5, l31 = lane & 31;
-  lptr_t xn = (lptr_t)(X + 8 * kh * XS + colblk * 32 + l31);   // this lane's column, rows 8 kh .. 8 kh + 7 of step 0
-  float br[2][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) br[0][j] = xn[j * XS];
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;
-#pragma unroll
-  for (int i = 0; i < CBW; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
-    const bool more = s + DEPTH - 1 < KS;
-    if (s + 1 < KS) {
-      xn += 16 * XS;
-      asm volatile("" : "+v"(xn));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) br[(s + 1) & 1][j] = xn[j * XS];
-    }
-    f32x4 b1, b2;
-    split8(br[s & 1], b1, b2);
-    // Three passes over the row blocks (small terms first).  Builtins, not asm (unlike gemm_phase): with asm MFMAs fed by
-    // VALU conversions this phase produced rare garbage tiles (more often with two workgroups per CU) that neither
-    // early-clobber outputs nor spacing the dependent MFMAs removed — the compiler cannot place hazard wait states or
-    // protect operand registers around an instruction it cannot see into.  A 16-deep step is only 9 MFMAs, and the
-    // scheduling barrier per step keeps the builtin MFMAs from being sunk below the next steps' loads.
-    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-    const bf16x8_t vb1 = __builtin_bit_cast(bf16x8_t, b1), vb2 = __builtin_bit_cast(bf16x8_t, b2);
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) {
-      if (more) {
-        wp.load_word((gptr_t)wn, nxt, 2 * i, lane);
-        wp.load_word((gptr_t)wn, nxt, 2 * i + 1, lane);
-      }
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][1]), vb1, acc[i], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < CBW; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb2, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < CBW; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb1, acc[i], 0, 0, 0);
-    if (more) {
-      wn += WPS * 256;
-      asm volatile("" : "+s"(wn));
-    }
-    // pin the step: an empty asm that "updates" the accumulators and clobbers memory keeps this step's MFMAs above it and
-    // the next steps' loads below it (the builtins are pure: without it hipcc sinks them under every later load and
-    // spills ~120 registers at C = 192)
-    if constexpr (CBW == 3) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) :: "memory");
-    else {
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* wt, unsigned short* packed, int C, int RH) {
   const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed` (bf16 elements)
   if (idx >= 2 * C * C) return;
@@ -462,534 +27,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, floa
   packed[idx] = wt[(long)k * C + m];
 }
 
-template <class K>
-__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[K::CBW], float* X, int rowblk0, int colblk, int lane) {
-  constexpr int XS = K::XS;
-  lptr_t xb = (lptr_t)(X + (rowblk0 * 32 + 4 * (lane >> 5)) * XS + colblk * 32 + (lane & 31));
-#pragma unroll
-  for (int i = 0; i < K::CBW; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xb[((r & 3) + 8 * (r >> 2)) * XS] = acc[i][r];     // acc_row(r, lane) without its lane term
-    xb += 32 * XS;
-    asm volatile("" : "+v"(xb));      // one base register per row block (see gemm_phase)
-  }
-}
-
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() drains vmcnt as well (it is a memory fence for global
-// memory too), i.e. every barrier would wait for the weight words and the next tile's x rows that are deliberately
-// kept in flight across it — measured as a 3-7 k cycle hole at the end of every tile.  All data exchanged between
-// the waves here lives in LDS, and a wave's LDS operations complete in order: lgkmcnt(0) + s_barrier is sufficient.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// this lane's 4 columns of a tile: clip, time (a multiple of 4; T % 4 == 0: the group is entirely inside or outside)
-struct Cols {
-  long b;              // offline: clip
-  int t;
-  bool t_in;
-  unsigned boff;       // STREAM: byte offset of (clip, row 0, t) against the tensor base (B*C*T*4 < 2^32, launcher-checked)
-  unsigned hoff;       // STREAM: element offset of this clip's [C][4] cache block
-  bool head, tail;     // STREAM: t == 0 (previous 4 samples live in the cache) / t == T-4 on an output column
-};
-
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false>
-__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY>::NT), (Cfg<C, STREAM, X3, SCARRY>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, X3, SCARRY>;
-  using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
-  constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
-  // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
-  // plain base + constant address instead of a select
-  __shared__ __attribute__((aligned(16))) float Xbuf[4 + C * XS];
-  __shared__ __attribute__((aligned(16))) float DW[C * DWS];
-  // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
-  // do not pay one exposed global-load latency per row for the single lane that needs them
-  __shared__ __attribute__((aligned(16))) float HS[(STREAM && !K::NARROW) ? 2 * C * 4 : 4];
-  float* const X = Xbuf + 4;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
-  constexpr int NCB = K::NCOL / 32;                      // column blocks of the tile
-  const int colblk = wave % NCB;
-  const int wclass = wave / NCB;                         // row class (0 unless RH == 2)
-  const int rowblk0 = wclass * CBW;
-#ifdef HILC_DEBUG_STAMPS
-#define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-  long stamp_tile = blockIdx.x;
-#else
-#define STAMP(i) do { } while (0)
-#endif
-  const int T = a.T;
-  // depthwise taps / biases -> LDS once per workgroup (read back as half-wave broadcasts in P3 / P6)
-  for (int e = tid; e < C * DWS; e += NT) {
-    const int m = e / DWS, j = e - m * DWS;
-    float v;
-    if (j < 5) v = a.dw1_w[m * 5 + j];
-    else if (j == 5) v = a.dw1_b[m];
-    else if (j < 11) v = a.dw2_w[m * 5 + (j - 6)];
-    else v = a.dw2_b[m];
-    DW[e] = v;
-  }
-  if (tid < 4) Xbuf[tid] = 0.f;
-  // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 2*NW*i), lane = 4 adjacent
-  // columns: 16-B global accesses, 512 B contiguous per half-wave; a row is read and written by one
-  // wave instruction, so the in-place update of P3 needs no barrier.
-  const int rsub = wave * K::RPI + (K::RPI > 1 ? lane / (K::NCOL / 4) : 0);
-  const int c4 = (lane & (K::NCOL / 4 - 1)) * 4;
-  [[maybe_unused]] const unsigned row_b = (unsigned)T * 4u;
-  [[maybe_unused]] const bool one_head = STREAM && !K::NARROW && T >= K::NCOL;
-
-  auto columns_of = [&](long tile) -> Cols {
-    Cols s;
-    s.boff = 0; s.hoff = 0; s.head = false; s.tail = false;
-    if constexpr (STREAM) {
-      const int flat = (int)tile * TO - K::HALO + c4;
-      s.t_in = flat >= 0 && flat < a.B * T;
-      const unsigned ub = s.t_in ? __umulhi((unsigned)flat, a.div_magic) >> a.div_shift : 0u;   // flat / T
-      s.b = ub;
-      s.t = s.t_in ? flat - (int)ub * T : 0;
-      s.boff = (ub * (unsigned)(C * T) + (unsigned)s.t) * 4u;
-      s.hoff = ub * (unsigned)(C * 4);
-      s.head = s.t_in && s.t == 0;
-      s.tail = s.t_in && c4 >= K::HALO && s.t == T - 4;
-    } else {
-      s.b = tile / a.tiles;
-      s.t = (int)(tile - s.b * a.tiles) * TO + c4;
-      s.t_in = s.t >= 0 && s.t < T;
-    }
-    return s;
-  };
-  auto xrow = [&](const Cols& s, int m) -> const f32x4* {     // rows outside [0, T) read a mapped dummy (zeroed in P0)
-    if constexpr (STREAM)
-      return reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x) + (s.boff + (unsigned)m * row_b));
-    else
-      return reinterpret_cast<const f32x4*>(a.x + s.b * (long)C * T + (long)m * T + (s.t_in ? s.t : 0));
-  };
-  auto yrow = [&](const Cols& s, int m) -> f32x4* {
-    if constexpr (STREAM)
-      return reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + (s.boff + (unsigned)m * row_b));
-    else
-      return reinterpret_cast<f32x4*>(a.y + s.b * (long)C * T + (long)m * T + s.t);
-  };
-
-  // The 4 samples in front of this lane's column group: the tile's own columns, or — STREAM, at a stream's t = 0 — that
-  // stream's cache.  Branch-free (address / value selects): a per-row `if (head)` is an exec-mask region per row that splits a
-  // batch's loads — by the stamps P3 took 31.8 k cycles per tile at C = 128 against 7.5 k offline.
-  [[maybe_unused]] const float* const hbase[2] = {a.hist1 != nullptr ? a.hist1 : a.x, a.hist2 != nullptr ? a.hist2 : a.x};
-  [[maybe_unused]] const bool hvalid[2] = {a.hist1 != nullptr, a.hist2 != nullptr};
-  Cols cs;
-  // The 4 columns in front of a lane's column group are its left neighbour's — except for column group 0, whose "previous columns"
-  // are the last 4 of the run's previous tile.  They live in two 4-float slots behind each row of the tile (H1 at X[m][NCOL..],
-  // H2 at X[m][NCOL + 4..]): the lane of group 0 reads them through ONE base pointer chosen per phase (same row stride, same
-  // immediate offsets as everybody else), the lane of the last group leaves them at a constant offset from its own pointer.
-  // A clip's first tile finds zeros there (the convs' zero padding); STREAM: at a stream's t = 0 the cache overrides.
-  const bool lane0 = c4 == 0, lane_last = c4 == K::NCOL - 4;
-  auto prev_base = [&](int which) -> lptr_t {        // + i * RSTEP * XS = the 16-B word in front of row (rsub + RSTEP * i)'s group
-    if constexpr (!K::CARRYMODE) return (lptr_t)(X + rsub * XS + c4 - 4);       // STREAM: group 0 = discarded halo columns, or a head
-    else return lane0 ? (lptr_t)(X + rsub * XS + K::NCOL + which * 4) : (lptr_t)(X + rsub * XS + c4 - 4);
-  };
-  // prev[i] for the RB rows of the batch whose first row sits RW0 rows (in units of RSTEP) below rsub; pb = prev_base(which)
-  auto prevs_of = [&](lptr_t pb, int m0, int which, f32x4 (&prev)[K::RB]) {
-    if constexpr (!STREAM) {
-#pragma unroll
-      for (int i = 0; i < K::RB; ++i) prev[i] = *(lvec_t)(pb + i * RSTEP * XS);
-    } else {
-      bool staged = false;
-      if constexpr (!K::NARROW) staged = one_head;      // wave-uniform: ONE branch per batch
-      if (staged) {      // T >= tile width: the one cache block of the tile sits in HS, staged during P0
-#pragma unroll
-        for (int i = 0; i < K::RB; ++i) {
-          const lptr_t pa = cs.head ? (lptr_t)(HS + (which * C + m0 + RSTEP * i) * 4) : pb + i * RSTEP * XS;
-          prev[i] = *(lvec_t)pa;
-        }
-      } else {
-        // every lane reads ITS stream's cache words (a valid address for every lane: hoff = 0 outside the tensor), heads keep them
-        f32x4 hv[K::RB];
-#pragma unroll
-        for (int i = 0; i < K::RB; ++i)
-          hv[i] = *reinterpret_cast<const f32x4*>(hbase[which] + (hvalid[which] ? cs.hoff + (unsigned)(m0 + RSTEP * i) * 4u : 0u));
-#pragma unroll
-        for (int i = 0; i < K::RB; ++i) {
-          const f32x4 own = *(lvec_t)(pb + i * RSTEP * XS);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) prev[i][e] = cs.head ? (hvalid[which] ? hv[i][e] : 0.f) : own[e];
-        }
-      }
-    }
-  };
-  // xp = this lane's pointer to its group in the batch's first row: the last group's lane leaves the batch's carry words
-  auto carry_out = [&](lptr_t xp, int which, const f32x4 (&cur)[K::RB]) {
-    if constexpr (K::CARRYMODE) {
-      if (lane_last) {
-#pragma unroll
-        for (int i = 0; i < K::RB; ++i) *(lvec_t)(xp + i * RSTEP * XS + 4 + which * 4) = cur[i];
-      }
-    }
-  };
-
-  // persistent: this workgroup walks tiles (static stride or tickets).  x registers: the tile's rows of this
-  // lane, loaded one tile ahead; they are the GEMM input (through P0) AND the shortcut of P6.
-  float touch = 0.f;
-  constexpr int LPR = K::NCOL / 32;                 // 128-B lines per tile row
-  // (STREAM: no touch loads — a hop's activations were written by the previous launch a few hundred microseconds ago, and the
-  // registers of the address arithmetic are what the cache handling needs)
-  constexpr int NTOUCH = STREAM ? 1 : (C * LPR + NT - 1) / NT;
-  float tv[NTOUCH];                                 // L2 touch loads in flight across the tile boundary
-#pragma unroll
-  for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
-  // Offline: this workgroup's run = tiles [run0, run1) of the launch, in order.  A run that starts inside a clip first walks the
-  // tile in front of it as a WARM-UP (everything computed, nothing stored): its last 4 columns of H1 and H2 depend only on its own
-  // columns 116..127, so the carry it leaves is exact whatever it was handed itself.
-  // STREAM: tiles by static stride or by ticket (where several workgroups share a CU), every tile with its own halo.
-  __shared__ long s_next;
-  long run0 = blockIdx.x, run1 = a.total_tiles;
-  long tile = blockIdx.x;
-  if constexpr (K::CARRYMODE) {
-    if (a.classes > 1) {
-      // Workgroups that share a CU are not served equally: the one dispatched first (lower blockIdx: the grid is classes x CUs, a CU
-      // holds one workgroup of every class) wins issue arbitration until it is done — with equal runs the first class finished at
-      // 0.76 of the kernel and the last ran on alone (tools/res_wg_times.py).  Runs in proportion to the classes' speeds: a
-      // "slot" u owns a contiguous range of tiles, its classes split it in dispatch order.
-      const unsigned P = gridDim.x / (unsigned)a.classes, u = blockIdx.x % P, c = blockIdx.x / P;
-      const long s0 = (long)u * a.total_tiles / P, len = (long)(u + 1) * a.total_tiles / P - s0;
-      run0 = s0 + ((len * (long)a.cum[c]) >> 16);
-      run1 = s0 + ((len * (long)a.cum[c + 1]) >> 16);
-    } else {
-      run0 = (long)blockIdx.x * a.total_tiles / gridDim.x;
-      run1 = ((long)blockIdx.x + 1) * a.total_tiles / gridDim.x;
-    }
-    const bool mid = STREAM ? (run0 * TO) % T != 0 : run0 % a.tiles != 0;     // does the run start inside a clip / stream?
-    tile = (mid && run0 < run1) ? run0 - 1 : run0;
-  }
-  cs = columns_of(tile < run1 ? tile : 0);
-  f32x4 xr[RW];
-  if (tile < run1) {
-#pragma unroll
-    for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, rsub + RSTEP * i);
-  }
-  lds_barrier();   // DW / pad visible
-  while (tile < run1) {
-    const bool warm = K::CARRYMODE && tile < run0;           // uniform
-    constexpr bool TICKETS = !K::CARRYMODE && K::NW == 4;
-    if constexpr (K::CARRYMODE && !STREAM) {
-      // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
-      // it two barriers from here).  (STREAM: column group 0 of a stream's first tile is a head and takes the cache.)
-      if (tile % a.tiles == 0) {
-        for (int e = tid; e < 2 * C; e += NT)
-          *reinterpret_cast<f32x4*>(X + (e >> 1) * XS + K::NCOL + (e & 1) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    if constexpr (!K::CARRYMODE) {
-      // tickets only where several workgroups share a CU (one per CU progresses evenly: static stride, no atomic round trip on
-      // the critical path)
-      if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
-    }
-#ifdef HILC_DEBUG_STAMPS
-    stamp_tile = tile;
-#endif
-    STAMP(0);
-    // the weight loads are invariant across tiles; launder the pointers so LICM does not try to keep
-    // every weight of both matrices in registers across the tile loop (it spills 8 KB/lane if it does)
-    const float* w1t = a.w1t + (long)wclass * (C * C / K::RH);
-    const float* w2t = a.w2t + (long)wclass * (C * C / K::RH);
-    asm volatile("" : "+s"(w1t), "+s"(w2t));
-    // STREAM, T >= tile width: the ONE stream start a tile can hold.  Its two [C][4] cache blocks are contiguous: one coalesced
-    // 16-B load per thread, requested here and written to HS at the end of P0 (the round trip hides behind the prologue; P3 / P6
-    // read HS barriers later).  (Round 3 until here: the few lanes that sit on t = 0 loaded their 2 * RW words themselves,
-    // 32 masked loads in a row and their latency in front of P0 — 3-12 k cycles per tile by the stamps.)
-    [[maybe_unused]] f32x4 hstage[(STREAM && !K::NARROW) ? (2 * C + NT - 1) / NT : 1];
-    [[maybe_unused]] bool stage_hs = false;
-    if constexpr (STREAM && !K::NARROW) {
-      if (one_head) {
-        const int first = (int)tile * TO - K::HALO, last = first + K::NCOL - 1;
-        const unsigned bh = __umulhi((unsigned)last, a.div_magic) >> a.div_shift;      // stream of the tile's last column
-        const int hcol = (int)bh * T;
-        stage_hs = hcol >= first && (int)bh < a.B;                                     // uniform: its t = 0 lies in this tile
-        if (stage_hs) {
-#pragma unroll
-          for (int q = 0; q < (2 * C + NT - 1) / NT; ++q) {
-            const int e = tid + q * NT;
-            const int which = e >= C ? 1 : 0, m = e - which * C;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < 2 * C && hvalid[which]) v = *reinterpret_cast<const f32x4*>(hbase[which] + bh * (unsigned)(C * 4) + (unsigned)m * 4u);
-            hstage[q] = v;
-          }
-        }
-      }
-    }
-    Pipe wp;
-    wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
-    // ---- P0: the prologue on the x registers (they stay live: shortcut of P6)
-    {
-      lptr_t xp = (lptr_t)(X + rsub * XS + c4);   // walks down the tile RB rows at a time (laundered: see gemm_phase)
-#pragma unroll
-      for (int i0 = 0; i0 < RW; i0 += RB) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-          *(lvec_t)(xp + i * RSTEP * XS) = prologue4v(zero_unless(cs.t_in, xr[i0 + i]), a.pre_scale, 1);
-        xp += RB * RSTEP * XS;
-        asm volatile("" : "+v"(xp));
-      }
-    }
-    // last tile's touch loads are older than the x loads P0 just waited for: consuming them here costs no wait (at
-    // the end of P6 it drained the queue, i.e. waited for the freshly issued x loads of the next tile)
-#pragma unroll
-    for (int i = 0; i < NTOUCH; ++i) touch += tv[i];
-    if constexpr (STREAM && !K::NARROW) {
-      if (stage_hs) {
-#pragma unroll
-        for (int q = 0; q < (2 * C + NT - 1) / NT; ++q) {
-          const int e = tid + q * NT;
-          if (e < 2 * C) *reinterpret_cast<f32x4*>(&HS[e * 4]) = hstage[q];
-        }
-      }
-    }
-    lds_barrier();
-    STAMP(1);
-    const long next = K::CARRYMODE ? tile + 1 : ((TICKETS && a.sched != nullptr) ? s_next : tile + gridDim.x);
-
-    f32x16 acc[CBW];
-    // ---- P1, P2
-    if constexpr (X3) gemm_phase_x3<K>(w1t, X, acc, wp, colblk, lane);
-    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
-    else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
-    lds_barrier();
-    STAMP(2);
-    acc_to_x<K>(acc, X, rowblk0, colblk, lane);
-    lds_barrier();
-    STAMP(3);
-
-    // ---- P3: a2 = ELU(dw1(H1) + b1), zero for t < 0, in place, RB rows at a time
-    wp.prefetch(w2t, lane);                  // GEMM2's first weight slices travel while P3 runs
-    lptr_t xp3 = (lptr_t)(X + rsub * XS + c4);
-    lptr_t pb3 = prev_base(0);
-#pragma unroll
-    for (int i0 = 0; i0 < RW; i0 += RB) {
-      f32x4 cur[RB], prev[RB], wa[RB];
-      f32x2 wb[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int m = rsub + RSTEP * (i0 + i);
-        const lptr_t row = xp3 + i * RSTEP * XS;
-        cur[i] = *(lvec_t)(row);
-        wa[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS]);
-        wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 4]);
-      }
-      prevs_of(pb3, rsub + RSTEP * i0, 0, prev);
-      carry_out(xp3, 0, cur);                          // H1's last 4 columns, before the row is overwritten in place
-      if constexpr (STREAM) {
-        if (cs.tail && !warm && a.hist1_out != nullptr) {      // one exec-mask region per batch, not per row
-#pragma unroll
-          for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4*>(a.hist1_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
-        }
-      }
-      f32x4 o[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
-        const float w[5] = {wa[i].x, wa[i].y, wa[i].z, wa[i].w, wb[i].x};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float s = 0.f;
-#pragma unroll
-          for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
-          o[i][e] = elu_fast(__fadd_rn(s, wb[i].y));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-        *(lvec_t)(xp3 + i * RSTEP * XS) = o[i];
-      xp3 += RB * RSTEP * XS;
-      pb3 += RB * RSTEP * XS;
-      asm volatile("" : "+v"(xp3), "+v"(pb3));
-      __builtin_amdgcn_sched_barrier(0);   // batches stay batches: hoisting every row's reads costs RW * 14 registers
-    }
-    lds_barrier();
-    STAMP(4);
-
-    // ---- P4
-    if constexpr (X3) gemm_phase_x3<K>(w2t, X, acc, wp, colblk, lane);
-    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
-    else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
-    // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
-    // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
-    const bool have_next = next < run1;
-    const Cols cn = columns_of(have_next ? next : tile);
-    if constexpr (!STREAM) {
-      long nb;
-      int nt0;
-      if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
-        const int nf0 = (int)(have_next ? next : tile) * TO - K::HALO;
-        const unsigned q = __umulhi((unsigned)(nf0 < 0 ? 0 : nf0), a.div_magic) >> a.div_shift;
-        nb = q;
-        nt0 = nf0 - (int)q * T;
-      } else {
-        const long nt = have_next ? next : tile;
-        nb = nt / a.tiles;
-        nt0 = (int)(nt - nb * a.tiles) * TO;
-      }
-      const float* nx = a.x + nb * (long)C * T;
-#pragma unroll
-      for (int i = 0; i < NTOUCH; ++i) {
-        int e = tid + NT * i;
-        e = e < C * LPR ? e : C * LPR - 1;
-        int tt = nt0 + (e % LPR) * 32;
-        tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
-        tv[i] = nx[(long)(e / LPR) * T + tt];
-      }
-    }
-    // ---- P5
-    lds_barrier();
-    STAMP(5);
-    acc_to_x<K>(acc, X, rowblk0, colblk, lane);
-    lds_barrier();
-    STAMP(6);
-
-    // ---- P6: y = (dw2(H2) + b2) * out_scale + x  for t < T (not in a warm-up tile); then this batch's x registers take the
-    //      next tile's rows
-    const bool out_ok = !warm && (STREAM ? (c4 >= K::HALO && cs.t_in) : cs.t < T);
-    lptr_t xp6 = (lptr_t)(X + rsub * XS + c4);
-    lptr_t pb6 = prev_base(1);
-#pragma unroll
-    for (int i0 = 0; i0 < RW; i0 += RB) {
-      f32x4 cur[RB], prev[RB], wc[RB];
-      f32x2 wb[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int m = rsub + RSTEP * (i0 + i);
-        const lptr_t row = xp6 + i * RSTEP * XS;
-        cur[i] = *(lvec_t)(row);
-        wb[i] = *reinterpret_cast<const f32x2*>(&DW[m * DWS + 6]);   // w2_0, w2_1
-        wc[i] = *reinterpret_cast<const f32x4*>(&DW[m * DWS + 8]);   // w2_2, w2_3, w2_4, b2
-      }
-      prevs_of(pb6, rsub + RSTEP * i0, 1, prev);
-      carry_out(xp6, 1, cur);
-      if constexpr (STREAM) {
-        if (cs.tail && !warm && a.hist2_out != nullptr) {
-#pragma unroll
-          for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4*>(a.hist2_out + cs.hoff + (rsub + RSTEP * (i0 + i)) * 4) = cur[i];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int m = rsub + RSTEP * (i0 + i);
-        const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
-        const float w[5] = {wb[i].x, wb[i].y, wc[i].x, wc[i].y, wc[i].z};
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float s = 0.f;
-#pragma unroll
-          for (int j = 0; j < 5; ++j) s = fmaf(w[j], v[e + j], s);
-          s = __fmul_rn(__fadd_rn(s, wc[i].w), a.out_scale);
-          o[e] = __fadd_rn(s, xr[i0 + i][e]);
-        }
-        if (out_ok) *yrow(cs, m) = o;
-      }
-      if (have_next) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) xr[i0 + i] = *xrow(cn, rsub + RSTEP * (i0 + i));
-      }
-      xp6 += RB * RSTEP * XS;
-      pb6 += RB * RSTEP * XS;
-      asm volatile("" : "+v"(xp6), "+v"(pb6));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    STAMP(7);
-    lds_barrier();   // the next tile's P0 overwrites X
-    tile = next;
-    cs = cn;
-  }
-  if (!K::CARRYMODE && K::NW == 4 && a.sched != nullptr && tid == 0) {   // last workgroup out re-arms the scheduler for the next launch
-    if (atomicAdd(a.sched + 1, 1) == (int)gridDim.x - 1) {
-      a.sched[0] = 0;
-      a.sched[1] = 0;
-    }
-  }
-  if (touch == 1.2345678e-30f) a.y[0] = touch;   // keeps the touch loads alive; never true in practice
-#undef STAMP
-}
-
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false>
-int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
-  a.B = B;
-  {  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
-    int l = 0;
-    while ((1L << l) < a.T) ++l;
-    if (l < 1) l = 1;
-    const unsigned long long p = 1ULL << (31 + l);
-    a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
-    a.div_shift = (unsigned)(l - 1);
-  }
-  using K = Cfg<C, STREAM, X3, SCARRY>;
-  constexpr int TO = K::TO;
-  a.tiles = (a.T + TO - 1) / TO;
-  a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
-  // persistent grid = exactly what can be resident (a surplus workgroup would only start after a resident one has
-  // walked its whole tile list).  Immutable per-device facts, looked up once per device (a process may drive several GPUs).
-  constexpr int MAXDEV = 64;
-  static std::atomic<int> resident_cache[MAXDEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return HILC_ERR_LAUNCH;
-  int cached = dev >= 0 && dev < MAXDEV ? resident_cache[dev].load(std::memory_order_relaxed) : 0;
-  if (cached == 0) {
-    int n_cu = 0, occ = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
-      return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, X3, SCARRY>, K::NT, 0) != hipSuccess || occ < 1)
-      return HILC_ERR_LAUNCH;
-    cached = n_cu * occ;
-    if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
-  }
-  const long resident = cached;
-  if constexpr (STREAM && !SCARRY && !X3 && (C == 96 || C == 192)) {
-    // The carry form for this hop?  Only where every run is the same whole number of streams (so that no run starts inside a
-    // stream and pays a warm-up tile) and the runs are fewer tile-times than the rounds of the halo form.
-    constexpr int NC = K::NCOL;
-    long g = a.T, h = NC;
-    while (h != 0) { const long t = g % h; g = h; h = t; }                      // gcd(T, NCOL)
-    const long unit = (long)a.T / g;                                              // tiles of the shortest aligned run
-    const long cols = (long)B * a.T;
-    if (cols % (unit * NC) == 0) {
-      const long units = cols / (unit * NC);
-      const long k = (units + resident - 1) / resident;                          // aligned runs per workgroup (same residency: 8 KB of LDS more)
-      const long halo_rounds = (a.total_tiles + resident - 1) / resident;
-      if (units % k == 0 && k * unit < halo_rounds) return launch_res<C, STREAM, X3, true>(a, B, s, units / k);
-    }
-  }
-  long blocks = a.total_tiles < resident ? a.total_tiles : resident;
-  if (SCARRY && carry_grid > 0 && carry_grid <= resident) blocks = carry_grid;
-  a.classes = 0;
-  if constexpr (!STREAM) {
-    int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0 && blocks == resident &&
-        resident % n_cu == 0 && resident / n_cu >= 2 && resident / n_cu <= 4 && a.total_tiles >= 8 * resident) {
-      const int cls = (int)(resident / n_cu);
-      // shares of the dispatch classes (first-dispatched first), measured: see tools/res_wg_times.py and profiles/r03_experiments.md
-      double share[4] = {0, 0, 0, 0};
-      if (cls == 2) { share[0] = HILC_RES_SHARE2_0; share[1] = 1.0 - share[0]; }
-      else if (cls == 3) { share[0] = HILC_RES_SHARE3_0; share[1] = HILC_RES_SHARE3_1; share[2] = 1.0 - share[0] - share[1]; }
-      else { for (int i = 0; i < cls; ++i) share[i] = 1.0 / cls; }
-#ifdef HILC_RES_SHARE_ENV      // tuning builds only
-      if (cls == 2) { if (const char* e = getenv("HILC_SHARE2_0")) { share[0] = atof(e); share[1] = 1.0 - share[0]; } }
-      if (cls == 3) {
-        if (const char* e = getenv("HILC_SHARE3_0")) share[0] = atof(e);
-        if (const char* e = getenv("HILC_SHARE3_1")) share[1] = atof(e);
-        share[2] = 1.0 - share[0] - share[1];
-      }
-#endif
-      double acc = 0;
-      a.cum[0] = 0;
-      for (int i = 0; i < cls; ++i) { acc += share[i]; a.cum[i + 1] = (unsigned)(acc * 65536.0 + 0.5); }
-      a.cum[cls] = 65536u;
-      a.classes = cls;
-    }
-  }
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
-
 }  // namespace
 
 namespace {
@@ -1003,9 +40,11 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
   if (T % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
     return HILC_ERR_UNSUPPORTED;             // callers fall back to two hilc_dws_conv launches
   ResArgs a;
-  a.x = x; a.w1t = w1t; a.dw1_w = dw1_w; a.dw1_b = dw1_b; a.w2t = w2t; a.dw2_w = dw2_w; a.dw2_b = dw2_b;
-  a.y = y; a.T = T; a.tiles = 0; a.pre_scale = pre_scale; a.out_scale = out_scale;
-  a.hist1 = hist1; a.hist2 = hist2; a.hist1_out = hist1_out; a.hist2_out = hist2_out;
+  ResBlk& b0 = a.blk[0];
+  a.x = x; b0.w1t = w1t; b0.dw1_w = dw1_w; b0.dw1_b = dw1_b; b0.w2t = w2t; b0.dw2_w = dw2_w; b0.dw2_b = dw2_b;
+  a.y = y; a.T = T; a.tiles = 0; b0.pre_scale = pre_scale; b0.out_scale = out_scale;
+  b0.hist1 = hist1; b0.hist2 = hist2; b0.hist1_out = hist1_out; b0.hist2_out = hist2_out;
+  a.nblk = 1; a.run_tiles = 0;
   a.sched = sched;
 #ifdef HILC_DEBUG_STAMPS
   a.dbg = g_dbg;
@@ -1062,6 +101,16 @@ extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C,
                 Cfg<64, true>::RH == 1 && Cfg<96, true>::RH == 1 && Cfg<128, true>::RH == 1 && Cfg<192, true>::RH == 2, "packed layout");
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, packed, C, RH);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
+extern "C" int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream) {
+  if (!wt || !packed) return HILC_ERR_NULL;
+  if (C <= 0 || C % 32 != 0 || row_classes < 1 || (C / 32) % row_classes != 0) return HILC_ERR_UNSUPPORTED;
+  if (wt == packed) return HILC_ERR_UNSUPPORTED;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt, packed, C, row_classes);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

@@ -1,0 +1,59 @@
+// A stage's residual blocks in ONE launch (kernel: resblock_kernel.h, NB > 1): hilc_resblock_chain.
+//
+// The reference runs the blocks of a stage one after the other (seanet.py:316-330 `self.blocks[i]`, decoder: the
+// SEANetResnetBlocks after each up-sampling layer, seanet.py:437-452; streaming.py:497-503, 633-639).  Here the 2 (encoder) or 3
+// (decoder) blocks of a stage are one launch: per tile the blocks run back to back and a block's output stays in registers as
+// the next block's input and shortcut — the activations between the blocks of a stage never reach HBM, and a streaming hop
+// loses 2 of 3 launch boundaries per stage (at 1024 streams a launch is 5-10 tiles per workgroup: its ends are 10-20 % of it).
+// Same products in the same order as hilc_resblock / hilc_resblock_stream: bit-identical (tests/test_gpu_ops.py).
+#include "resblock_kernel.h"
+
+namespace {
+constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C == 192; }
+}
+
+extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming) {
+  if (nblk < 2 || nblk > MAXBLK || T <= 0 || T % 4 != 0) return 0;
+  if (!streaming) return 0;                          // offline chains: not instantiated (see profiles/r04_experiments.md)
+  if (chain_width(C)) return 1;
+  return (C == 512 || C == 768) && 32 % T == 0;
+}
+
+// packed pointwise weights of a chain launch: the 8-wave shapes split the rows in two classes also below C = 192
+extern "C" int hilc_resblock_chain_row_classes(int C) {
+  static_assert(Cfg<64, true, false, true, 2, true>::RH == 2 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
+                Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
+                Cfg<512, true, false, false, 2, false>::RH == 8 && Cfg<768, true, false, false, 3, false>::RH == 8, "packed layout");
+  return C >= 512 ? 8 : (C == 96 ? 1 : (chain_width(C) ? 2 : 0));
+}
+
+extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
+                                   int B, int C, int T, void* stream) {
+  if (!x || !y || !blocks) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_resblock_chain_supported(C, T, nblk, streaming)) return HILC_ERR_UNSUPPORTED;
+  if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
+  if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
+  ResArgs a;
+  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  for (int i = 0; i < nblk; ++i) {
+    const hilc_resblock_params& p = blocks[i];
+    if (!p.w1t || !p.dw1_w || !p.dw1_b || !p.w2t || !p.dw2_w || !p.dw2_b) return HILC_ERR_NULL;
+    if ((p.hist1 && p.hist1 == p.hist1_out) || (p.hist2 && p.hist2 == p.hist2_out)) return HILC_ERR_UNSUPPORTED;
+    ResBlk& b = a.blk[i];
+    b.w1t = p.w1t; b.dw1_w = p.dw1_w; b.dw1_b = p.dw1_b; b.w2t = p.w2t; b.dw2_w = p.dw2_w; b.dw2_b = p.dw2_b;
+    b.hist1 = p.hist1; b.hist2 = p.hist2; b.hist1_out = p.hist1_out; b.hist2_out = p.hist2_out;
+    b.pre_scale = p.pre_scale; b.out_scale = p.out_scale;
+  }
+  for (int i = nblk; i < MAXBLK; ++i) a.blk[i] = a.blk[0];
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 64: return launch_chain<64, true, 2, true>(a, B, s);          // the encoder's stages hold 2 blocks; 3 fit the same kernel's loop
+    case 96: return launch_chain<96, true, 3, false>(a, B, s);         // 3 row blocks do not split in two classes: 4 waves, two workgroups per CU
+    case 128: return launch_chain<128, true, 2, true>(a, B, s);
+    case 192: return launch_chain<192, true, 3, false>(a, B, s);
+    case 512: return launch_chain<512, true, 2, false>(a, B, s);
+    case 768: return launch_chain<768, true, 3, false>(a, B, s);
+    default: return HILC_ERR_UNSUPPORTED;
+  }
+}

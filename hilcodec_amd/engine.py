@@ -46,6 +46,7 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
+    stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
 
 
 _DEFAULT_OPTIONS = ExecOptions()
@@ -92,6 +93,8 @@ class ResBlockSpec:
     out_scale: float        # res_scale * res_scale_param (seanet.py:144-148); 1.0 when merged into dw2
     pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec): C <= 192, streaming plans also 256 ... 768
     pw2_packed: Optional[Tensor] = None
+    pw1_chain: Optional[Tensor] = None    # the same for a chain launch (streaming plans; another row split below C = 192, else the tensors above)
+    pw2_chain: Optional[Tensor] = None
 
 
 @dataclass
@@ -179,6 +182,10 @@ def finalize_block(rb: "ResBlockSpec", streaming: bool = False) -> "ResBlockSpec
             and (narrow or (streaming and c in STREAM_WIDE_C))):
         rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
         rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
+    if streaming and rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or c in (512, 768)):
+        same = ops.resblock_chain_row_classes(c) == (8 if c >= 512 else (2 if c == 192 else 1))     # hilc_resblock_pack_weights' own split
+        rb.pw1_chain = rb.pw1_packed if same else ops.resblock_chain_pack(rb.pw1_wt)
+        rb.pw2_chain = rb.pw2_packed if same else ops.resblock_chain_pack(rb.pw2_wt)
     return rb
 
 
@@ -291,6 +298,29 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
                         hist_out=o1)
     new_caches.extend([c0, c1])
     return y
+
+
+def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Sequence[Tensor]], ci: int, new_caches: Optional[list],
+                  caches_out: Optional[Sequence[Tensor]], x3: bool, opts: ExecOptions) -> Tensor:
+    """The residual blocks of one stage.  Streaming hop, fp32: ONE chain launch where the kernel exists (the blocks run back to
+    back per tile, the activations between them stay in registers: `ops.resblock_chain`); otherwise block by block."""
+    n = len(blocks)
+    streaming = caches is not None
+    if (streaming and not x3 and FUSE_RESBLOCK and FUSE_STREAM and opts.stream_chain_blocks and n >= 2 and x.shape[2] >= 4
+            and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+                    and rb.dw2_b is not None for rb in blocks)
+            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.stream_wide_blocks)
+            and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0])):
+        y, cs = ops.resblock_chain(
+            x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks],
+            [caches[ci + 2 * i: ci + 2 * i + 2] for i in range(n)],
+            [caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(n)] if caches_out is not None else None)
+        new_caches.extend(cs)
+        return y
+    for i, rb in enumerate(blocks):
+        x = _resblock(rb, x, caches[ci + 2 * i: ci + 2 * i + 2] if streaming else None, new_caches,
+                      caches_out[ci + 2 * i: ci + 2 * i + 2] if caches_out is not None else None, x3=x3, opts=opts)
+    return x
 
 
 def _spec_fused(sb: SpecBlockSpec, wav: Tensor, wav_hist: Optional[Tensor]) -> bool:
@@ -413,14 +443,13 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
-    early = _early_spectra(es, wav, wav_hist, _SIDE_STREAM.get(), skip=(sb0,) if fuse_pre else ()) if streaming else None
+    side = None if torch.compiler.is_compiling() else _SIDE_STREAM.get()          # (a tracing compiler cannot read a ContextVar; it never forks streams)
+    early = _early_spectra(es, wav, wav_hist, side, skip=(sb0,) if fuse_pre else ()) if streaming else None
     for si, st in enumerate(es.stages):
         if not (fuse_pre and si == 0):
             x = _spec_block(st.spec, x, wav, wav_hist, early)
-        for rb in st.blocks:
-            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
-                          caches_out[ci:ci + 2] if caches_out is not None else None, opts=opts)
-            ci += 2
+        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, False, opts)
+        ci += 2 * len(st.blocks)
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
             x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci],
                                        stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))
@@ -511,10 +540,8 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             u = ops.dw_convtr(x, st.tr_w, st.ratio, in_scale=st.in_scale, in_elu=True)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
         ci += 1
-        for rb in st.blocks:
-            x = _resblock(rb, x, caches[ci:ci + 2] if streaming else None, new_caches,
-                          caches_out[ci:ci + 2] if caches_out is not None else None, x3=x3, opts=opts)
-            ci += 2
+        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, x3, opts)
+        ci += 2 * len(st.blocks)
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
                                out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True,

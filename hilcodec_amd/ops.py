@@ -454,6 +454,45 @@ _register("resblock", "(Tensor x, Tensor w1p, Tensor dw1_w, Tensor dw1_b, Tensor
           torch.empty_like(x))
 
 
+def _resblock_chain(x, params, hist_in, hist_out, pre_scales, out_scales):
+    from ._lib import ResblockParams
+    B, Cc, T = x.shape
+    n = len(pre_scales)
+    if len(params) != 6 * n or len(hist_in) != 2 * n or len(hist_out) != 2 * n or len(out_scales) != n:
+        raise RuntimeError("resblock_chain: 6 parameter tensors, 2 caches in and 2 caches out per block")
+    for h in list(hist_in) + list(hist_out):
+        if tuple(h.shape) != (B, Cc, 4):
+            raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h.shape)}")
+    blocks = (ResblockParams * n)()
+    for i in range(n):
+        w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), _ptr(hist_in[2 * i]),
+                                   _ptr(hist_in[2 * i + 1]), _ptr(hist_out[2 * i]), _ptr(hist_out[2 * i + 1]),
+                                   float(pre_scales[i]), float(out_scales[i]))
+    y = torch.empty_like(x)
+    import ctypes
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc, f"C{Cc} T{T} stream chain x{n}"):
+        check(lib.hilc_resblock_chain(_ptr(x), _ptr(y), ctypes.cast(blocks, ctypes.c_void_p), n, 1, B, Cc, T, _stream()),
+              "hilc_resblock_chain")
+    return y
+
+
+_register("resblock_chain", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tensor(a!)[] hist_out, float[] pre_scales, "
+          "float[] out_scales) -> Tensor", _resblock_chain,
+          lambda x, params, hist_in, hist_out, pre_scales, out_scales: torch.empty_like(x))
+
+
+def _resblock_pack_rc(wt, row_classes):
+    Cc = wt.shape[0]
+    out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
+    check(lib.hilc_resblock_pack_weights_rc(_ptr(wt), _ptr(out), Cc, int(row_classes), _stream()), "hilc_resblock_pack_weights_rc")
+    return out
+
+
+_register("resblock_pack_rc", "(Tensor wt, int row_classes) -> Tensor", _resblock_pack_rc,
+          lambda wt, row_classes: wt.new_empty(wt.shape[0] * wt.shape[0]))
+
+
 # ======================================================================================================
 # HBM-bound element-wise ops
 # ======================================================================================================
@@ -791,6 +830,42 @@ def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> b
     if B * C * T * 4 >= (1 << 32):
         return False
     return C in (64, 96, 128, 192, 256, 384) or (C in (512, 768) and 32 % T == 0)
+
+
+def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1) -> bool:
+    """mirror of hilc_resblock_chain_supported (streaming form): the blocks of one stage in one launch"""
+    if nblk < 2 or nblk > 3 or T <= 0 or T % 4 != 0 or B * C * T * 4 >= (1 << 32):
+        return False
+    return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
+
+
+def resblock_chain_row_classes(C: int) -> int:
+    """mirror of hilc_resblock_chain_row_classes: the row split of the packed weights a chain launch reads"""
+    return 8 if C >= 512 else (1 if C == 96 else 2)
+
+
+def resblock_chain_pack(wt: Tensor) -> Tensor:
+    """k-major `[C,C]` pointwise weights -> the packed layout of hilc_resblock_chain for this width"""
+    return _OPS.resblock_pack_rc(wt, resblock_chain_row_classes(wt.shape[0]))
+
+
+def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Sequence[Sequence[Tensor]],
+                   hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None):
+    """The residual blocks of ONE stage of a streaming hop in one launch (hilc_resblock_chain): `blocks[i]` =
+    (w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, pre_scale, out_scale) with w1p / w2p packed by `resblock_chain_pack`, `hist[i]` =
+    that block's two caches, `hist_out[i]` = where its new caches go (None: fresh tensors).  Returns (y, [new caches of block 0,
+    of block 1, ...]) — equal, bit for bit, to the blocks launched one by one."""
+    B, Cc, _ = x.shape
+    params, hin, hout, pre, post = [], [], [], [], []
+    for i, blk in enumerate(blocks):
+        params.extend(blk[:6])
+        pre.append(float(blk[6]))
+        post.append(float(blk[7]))
+        hin.extend(hist[i])
+        given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
+        hout.extend([_state_out(given[0], x, B, Cc, 4), _state_out(given[1], x, B, Cc, 4)])
+    y = _OPS.resblock_chain(x, params, hin, hout, pre, post)
+    return y, hout
 
 
 def resblock_pack(wt: Tensor) -> Tensor:

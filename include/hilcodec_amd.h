@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 9   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream) */
+#define HILC_ABI_VERSION 10   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -176,6 +176,30 @@ int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w,
                            const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
                            const float* hist2, float* hist1_out, float* hist2_out, float* y, int* sched,
                            int streaming, int B, int C, int T, float pre_scale, float out_scale, void* stream);
+
+/* ---- the residual blocks of ONE STAGE in one launch (ABI 10) --------------------------------------------------------
+ * The reference runs a stage's blocks one after the other: encoder `seanet.py:316-330` (`self.blocks[i]`, 2 per stage),
+ * decoder `seanet.py:437-452` (3 after each up-sampling layer); streaming `streaming.py:497-503` / `:633-639` with two
+ * caches per block.  hilc_resblock_chain(x, y, blocks, nblk, ...) == nblk calls of hilc_resblock_stream with the output of
+ * one as the input of the next, bit for bit — but per tile the blocks run back to back and a block's output stays in
+ * registers as the next block's input and shortcut: the activations between the blocks never reach HBM and the stage is one
+ * launch instead of nblk (a streaming hop of 1024 streams is 5-10 tiles per workgroup and launch).
+ * blocks[i]: that block's parameters; w1t / w2t PACKED by hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C))
+ * (the chain's 8-wave shapes split the rows in two classes also below C = 192, so the layout differs from hilc_resblock's);
+ * hist* as in hilc_resblock_stream (each optional).  streaming must be 1 (offline chains are not instantiated).
+ * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0,
+ * C in {512, 768} with whole streams tiling 32 columns; nblk 2..3.  Else HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
+typedef struct hilc_resblock_params {
+  const float* w1t; const float* dw1_w; const float* dw1_b;
+  const float* w2t; const float* dw2_w; const float* dw2_b;
+  const float* hist1; const float* hist2; float* hist1_out; float* hist2_out;
+  float pre_scale, out_scale;
+} hilc_resblock_params;
+int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming);
+int hilc_resblock_chain_row_classes(int C);
+int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
+int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
+                        int B, int C, int T, void* stream);
 
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)

@@ -366,6 +366,60 @@ def test_wide_stream_block_equals_two_launches(env, C, T, B):
     assert torch.equal(y, y2) and torch.equal(o[0], c0) and torch.equal(o[1], c1)
 
 
+@pytest.mark.parametrize("C,T,B,n", [(64, 320, 5, 2), (64, 320, 1024, 2), (96, 320, 3, 3), (96, 320, 1024, 3), (128, 160, 7, 2), (128, 160, 1024, 2),
+                                      (192, 160, 6, 3), (192, 160, 1024, 3), (512, 8, 21, 2), (512, 8, 1024, 2), (768, 8, 37, 3),
+                                      (768, 8, 1024, 3), (96, 640, 2, 3), (64, 960, 3, 2), (192, 480, 2, 3), (128, 4, 9, 2), (96, 12, 70, 2),
+                                      (64, 320, 2, 3)])
+def test_resblock_chain_equals_block_by_block(env, C, T, B, n):
+    """The residual blocks of one stage of a streaming hop in ONE launch (hilc_resblock_chain: `streaming.py:497-503,633-639`
+    runs them one after the other) against the same blocks launched one by one (hilc_resblock_stream): output and all 2n new
+    caches bit for bit, over three hops — ragged stream counts (short last run), the full 1024 streams (256 equal runs),
+    multi-frame hops, hops shorter than a tile, zero history and caller-owned cache outputs."""
+    ops, fold, O, dev = env
+    from hilcodec_amd._lib import lib
+    assert ops.resblock_chain_supported(C, T, n, B) and lib.hilc_resblock_chain_supported(C, T, n, 1) == 1
+    assert lib.hilc_resblock_chain_row_classes(C) == ops.resblock_chain_row_classes(C)
+    blocks = []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        blocks.append(dict(single=(ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2),
+                           chain=(ops.resblock_chain_pack(w1), d1, b1, ops.resblock_chain_pack(w2), d2, b2),
+                           pre=(1.0 + j / 3.0) ** -0.5, post=0.4 + 0.1 * j))
+    ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
+    cb = [[c.clone() for c in pair] for pair in ca]
+    for h in range(3):
+        x = rnd(C + T + h, B, C, T).to(dev)
+        y, flat = ops.resblock_chain(x, [blk["chain"] + (blk["pre"], blk["post"]) for blk in blocks], ca)
+        ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+        y2 = x
+        for j, blk in enumerate(blocks):
+            y2, cb[j] = ops.resblock(y2, *blk["single"], blk["pre"], blk["post"], hist=cb[j])
+        assert torch.equal(y, y2), (h, float((y - y2).abs().max()))
+        for j in range(n):
+            assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
+    # zero history, caller-provided cache outputs
+    x = rnd(99, B, C, T).to(dev)
+    zeros = [[torch.zeros(B, C, 4, device=dev), torch.zeros(B, C, 4, device=dev)] for _ in range(n)]
+    outs = [[torch.full((B, C, 4), 7.0, device=dev), torch.full((B, C, 4), 7.0, device=dev)] for _ in range(n)]
+    y, flat = ops.resblock_chain(x, [blk["chain"] + (blk["pre"], blk["post"]) for blk in blocks], zeros, outs)
+    y2 = x
+    for j, blk in enumerate(blocks):
+        y2, cs = ops.resblock(y2, *blk["single"], blk["pre"], blk["post"], hist=zeros[j])
+        assert torch.equal(outs[j][0], cs[0]) and torch.equal(outs[j][1], cs[1]) and flat[2 * j] is outs[j][0]
+    assert torch.equal(y, y2)
+
+
+def test_resblock_chain_shapes_it_does_not_take(env):
+    ops, fold, O, dev = env
+    from hilcodec_amd._lib import lib
+    assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0
+    assert lib.hilc_resblock_chain_supported(96, 320, 1, 1) == 0 and lib.hilc_resblock_chain_supported(96, 320, 4, 1) == 0
+    assert lib.hilc_resblock_chain_supported(96, 320, 3, 0) == 0 and lib.hilc_resblock_chain_supported(96, 322, 3, 1) == 0
+    assert not ops.resblock_chain_supported(384, 40, 3, 8) and not ops.resblock_chain_supported(96, 320, 3, 40000)
+
+
 def test_wide_stream_block_shapes_it_does_not_take(env):
     """C = 512 / 768 need whole streams per 32-column tile: other hop lengths are refused (the engine then runs two launches)"""
     ops, fold, O, dev = env

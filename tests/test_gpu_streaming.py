@@ -413,18 +413,20 @@ def test_grouped_schedules_export_and_resume():
     assert torch.equal(p2.flush(), eager[hops - 1][1])
 
 
-def test_stream_wide_blocks_option_reaches_both_halves():
-    """`exec_options.stream_wide_blocks` (one launch per wide residual block of a hop, or two as in round 2) is honoured by
-    the ENCODER's and the DECODER's blocks and changes no bit (model level; the op-level pin is in test_gpu_ops.py)."""
+def test_stream_block_options_reach_both_halves():
+    """`exec_options.stream_chain_blocks` (the residual blocks of a stage as ONE launch, or one launch per block as in round 3)
+    and `exec_options.stream_wide_blocks` (one launch per wide residual block of a hop, or two as in round 2) are honoured by the
+    ENCODER's and the DECODER's blocks and change no bit (model level; the op-level pins are in test_gpu_ops.py)."""
     from hilcodec_amd import ops
     dev = torch.device("cuda:0")
     model, mk, sd = build_streaming()
     B, hops = 8, 3
     x = synth.synth_clips(B, 320 * hops, seed=80).to(dev)
 
-    def run(flag):
-        model.encoder.exec_options.stream_wide_blocks = flag
-        model.decoder.exec_options.stream_wide_blocks = flag
+    def run(chain, wide):
+        for half in (model.encoder, model.decoder):
+            half.exec_options.stream_chain_blocks = chain
+            half.exec_options.stream_wide_blocks = wide
         ce, cd = model.initialize_cache(x)
         outs, kinds = [], []
         with torch.no_grad():
@@ -436,53 +438,25 @@ def test_stream_wide_blocks_option_reaches_both_halves():
                     wav, cd = model.decoder(model.dequantizer(idx, 8), *cd)
                 kinds.append((sum(r[0] == "resblock" for r in t.records[:n_enc]), sum(r[0] == "resblock" for r in t.records[n_enc:])))
                 outs.append((z.clone(), idx.clone(), wav.clone()))
-        return outs, kinds, list(ce) + list(cd)
+        return outs, kinds[0], list(ce) + list(cd)
 
     try:
-        one, k_one, c_one = run(True)
-        two, k_two, c_two = run(False)
+        chained, k_chain, c_chain = run(True, True)
+        one, k_one, c_one = run(False, True)
+        two, k_two, c_two = run(False, False)
     finally:
-        model.encoder.exec_options.stream_wide_blocks = True
-        model.decoder.exec_options.stream_wide_blocks = True
-    # the encoder has 4 wide blocks (C = 256, 512 x 2 each), the decoder 6 (C = 768, 384 x 3 each) that leave the fused kernel
-    assert k_one[0][0] - k_two[0][0] == 4 and k_one[0][1] - k_two[0][1] == 6, (k_one[0], k_two[0])
-    for (z1, i1, w1), (z2, i2, w2) in zip(one, two):
-        assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
-    for a, b in zip(c_one, c_two):
-        assert torch.equal(a, b)
-
-
-def test_captured_resblock_needs_its_own_scheduler_words():
-    """The fused block's ticket words inside a graph capture: without an owner-provided workspace the launch refuses (allocating
-    them during capture would put a memset node and the buffer into that graph, and every later graph would share it); with
-    `ops.sched_workspace` the captured launch replays bit-identically, and the per-launch timer only records inside its context."""
-    from hilcodec_amd import ops
-    dev = torch.device("cuda:0")
-    C, Tn, B = 64, 480, 4
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(B, C, Tn, generator=g).to(dev)
-    w1, w2 = ops.resblock_pack((torch.randn(C, C, generator=g) / 8).to(dev)), ops.resblock_pack((torch.randn(C, C, generator=g) / 8).to(dev))
-    d1, b1 = torch.randn(C, 5, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
-    d2, b2 = torch.randn(C, 5, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
-    with ops.timed_launches() as t:
-        ref = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
-    assert len(t.records) == 1 and t.records[0][0] == "resblock"
-    n = len(t.records)
-    ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)                    # outside the context: not recorded
-    assert len(t.records) == n
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with pytest.raises(RuntimeError, match="sched_workspace"):
-        with torch.cuda.graph(graph):
-            ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
-    ws = ops.SchedWorkspace(dev, slots=2)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph), ops.sched_workspace(ws):
-        y = ops.resblock(x, w1, d1, b1, w2, d2, b2, 0.9, 0.5)
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(y, ref) and int(ws.words.abs().sum()) == 0          # the kernel re-armed its ticket words
+        for half in (model.encoder, model.decoder):
+            half.exec_options.stream_chain_blocks = True
+            half.exec_options.stream_wide_blocks = True
+    # launches of the fused-block kernel per hop: encoder 4 stages x 2 blocks, decoder 4 x 3.  Chains: every stage but C = 256
+    # (encoder) / C = 384 (decoder) is one launch; without the wide forms the 4 + 6 wide blocks are two GEMM launches each instead.
+    assert k_one == (8, 12) and k_two == (4, 6), (k_one, k_two)
+    assert k_chain == (3 + 2, 3 + 3), k_chain
+    for ref, other in ((chained, one), (chained, two)):
+        for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
+            assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
+    for a, b, c in zip(c_chain, c_one, c_two):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def test_streaming_weight_standardised_checkpoint(golden):
