@@ -72,6 +72,8 @@ def parse():
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--groups", type=int, default=1, help="with --graph: split the streams into this many groups whose "
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
+    ap.add_argument("--no-chain", action="store_true", help="streaming mode, A/B: one launch per residual block (round 3) instead "
+                    "of one launch per stage (hilc_resblock_chain); same arithmetic, bit-identical outputs")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     ap.add_argument("--emulate-rank", type=int, default=None, help="with --emulate-world W: run rank r's shard of the W-GPU job in this one process")
@@ -279,7 +281,7 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
     return step, n_clips * T / 24000.0, {"model": model, "sd": sd, "mk": mk, "last": last}
 
 
-def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1):
+def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1, chain: bool = True):
     from hilcodec_amd import synth
     from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
     mk = synth.model_kwargs(name)
@@ -289,6 +291,7 @@ def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, 
     model = StreamingHILCodec(24000, **smk).eval()
     model.load_offline_state_dict(sd)
     model.remove_weight_reparameterizations()
+    model.encoder.exec_options.stream_chain_blocks = model.decoder.exec_options.stream_chain_blocks = chain
     hop = 320
     nbuf = 8                                           # distinct input hops, cycled
     xs = [synth.synth_clips(n_streams, hop, seed=4321 + 7 * j, first=first).to(dev) for j in range(nbuf)]
@@ -391,7 +394,7 @@ def main():
     if args.mode == "offline":
         step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev)
     else:
-        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups)
+        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups, not args.no_chain)
         if args.graph:
             args.no_launch_timing = True
     model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]

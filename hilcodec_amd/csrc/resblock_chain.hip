@@ -15,6 +15,9 @@ constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C =
 extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming) {
   if (nblk < 2 || nblk > MAXBLK || T <= 0 || T % 4 != 0) return 0;
   if (!streaming) return 0;                          // offline chains: not instantiated (see profiles/r04_experiments.md)
+  // the instantiations hold the carry slots / tap tables of 2 blocks at the encoder's widths and of 3 at the decoder's
+  const int max_blocks = (C == 96 || C == 192 || C == 768) ? 3 : 2;
+  if (nblk > max_blocks) return 0;
   if (chain_width(C)) return 1;
   return (C == 512 || C == 768) && 32 % T == 0;
 }

@@ -834,7 +834,7 @@ def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> b
 
 def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1) -> bool:
     """mirror of hilc_resblock_chain_supported (streaming form): the blocks of one stage in one launch"""
-    if nblk < 2 or nblk > 3 or T <= 0 or T % 4 != 0 or B * C * T * 4 >= (1 << 32):
+    if nblk < 2 or nblk > (3 if C in (96, 192, 768) else 2) or T <= 0 or T % 4 != 0 or B * C * T * 4 >= (1 << 32):
         return False
     return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
 

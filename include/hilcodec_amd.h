@@ -188,7 +188,8 @@ int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w,
  * (the chain's 8-wave shapes split the rows in two classes also below C = 192, so the layout differs from hilc_resblock's);
  * hist* as in hilc_resblock_stream (each optional).  streaming must be 1 (offline chains are not instantiated).
  * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0,
- * C in {512, 768} with whole streams tiling 32 columns; nblk 2..3.  Else HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
+ * C in {512, 768} with whole streams tiling 32 columns; nblk = 2, or 3 at the decoder's widths (96, 192, 768).  Else
+ * HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
 typedef struct hilc_resblock_params {
   const float* w1t; const float* dw1_w; const float* dw1_b;
   const float* w2t; const float* dw2_w; const float* dw2_b;

@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--model", default="hil_speech")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
+ap.add_argument("--no-chain", action="store_true", help="streaming: one launch per residual block (round 3) instead of one per stage")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 mk = synth.model_kwargs(args.model)
@@ -38,6 +39,7 @@ if args.mode == "streaming":
     smodel = StreamingHILCodec(24000, **smk).eval()
     smodel.load_offline_state_dict(synth.synth_state_dict(args.model, 7))
     smodel.remove_weight_reparameterizations()
+    smodel.encoder.exec_options.stream_chain_blocks = smodel.decoder.exec_options.stream_chain_blocks = not args.no_chain
     nq = mk["vq_kwargs"]["num_quantizers"]
     xs = synth.synth_clips(args.batch, 320, seed=4321).to(dev)
     state = list(smodel.initialize_cache(xs))
