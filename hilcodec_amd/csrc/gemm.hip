@@ -511,12 +511,27 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
     // cache out of the last one
     if (ksize != 2 * stride || stride > 16 || res != nullptr || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
     if (T % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || !lin_ok(B, K, T)) return HILC_ERR_UNSUPPORTED;
+    const int H = (stride + 3) / 4 * 4;
+    int n_out = (BN - H - stride) / stride + 1;
+    while ((n_out * stride) % 4 != 0) --n_out;
+    const long nout_all = (long)B * (T / stride);
+    if (nout_all + T < (1L << 31) && (long)B * M * (T / stride) < (1L << 31) && stride <= DwStrideFlatEpilogue::HB &&
+        (T / stride) * DwStrideFlatEpilogue::NBND >= n_out + 1) {
+      // flat columns (stream-major): a tile is 97 % full whatever the hop length (per-stream tiles: 62 % at T = 160, 86 % at 320)
+      DwStrideFlatEpilogue ep;
+      ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.hist = hist; ep.hist_out = hist_out;
+      ep.B = B; ep.M = M; ep.T = T; ep.To = T / stride; ep.r = stride; ep.H = H; ep.n_out = n_out;
+      div_magic(ep.To, ep.to_magic, ep.to_shift);
+      FlatHaloCols fc;
+      fc.K = K; fc.T = T; fc.step = n_out * stride; fc.halo = H; fc.ncols = (long)B * T;
+      const long ntiles = (nout_all + n_out - 1) / n_out;
+      return launch_gemm_lin(wt, x, M, K, M, T, ntiles, in_scale, in_elu != 0, fc, ep, (hipStream_t)stream);
+    }
     DwStrideEpilogue ep;
     ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.M = M; ep.r = stride; ep.hist = hist; ep.hist_out = hist_out; ep.T = T;
     ep.To = T / stride;
-    ep.H = (stride + 3) / 4 * 4;
-    ep.n_out = (BN - ep.H - stride) / stride + 1;
-    while ((ep.n_out * stride) % 4 != 0) --ep.n_out;
+    ep.H = H;
+    ep.n_out = n_out;
     ep.tiles = (ep.To + ep.n_out - 1) / ep.n_out;
     TileCols tc;
     tc.K = K; tc.T = T; tc.tiles = ep.tiles; tc.step = ep.n_out * stride; tc.halo = ep.H;

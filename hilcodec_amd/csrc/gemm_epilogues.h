@@ -559,6 +559,132 @@ struct DwStrideEpilogue {
   }
 };
 
+// The same down-sampling conv for a STREAMING hop longer than one tile (the encoder's first two stages: 320 / 160 samples
+// per stream), on FLAT columns (FlatHaloCols): tile = flat inputs [ntile*n_out*r - H, +128) of the stream-major column
+// space, outputs O = ntile*n_out + lane of the flat output space [B*To].  A stream's FIRST output takes its first r taps from
+// that stream's cache (zeros without one) instead of the columns to its left, which belong to the previous stream: the cache
+// words of the (at most NBND) stream starts of a tile are staged into a small LDS side buffer while the accumulators go to
+// LDS (published by the same barrier), and a head lane reads the FIRST HALF of its 2r operands through a pointer into that
+// buffer — every lane issues the same two vector reads.  The new cache = a stream's last r pointwise outputs, written by r lanes
+// per row where a stream ends in the tile.  Same fmaf chain (taps j ascending) as DwStrideEpilogue: bit-identical outputs.
+struct DwStrideFlatEpilogue {
+  float* y;
+  const float* dw_w;   // [M][2r]
+  const float* dw_b;
+  const float* hist = nullptr;    // [B][M][r]
+  float* hist_out = nullptr;
+  int B, M, T, To, r, H, n_out;
+  unsigned to_magic, to_shift;    // O / To for O < 2^31
+  static constexpr int NBND = 2;  // stream starts per tile the side buffer holds (the launcher checks To >= n_out / NBND)
+  static constexpr int HB = 8;    // side-buffer floats per (boundary, row): r <= 8 (4 KB: four workgroups per CU still fit)
+  template <int MB> static constexpr int lds_floats() { return 32 * (MB < CH ? MB : CH) * HS + NBND * 32 * CH * HB; }
+
+  template <int MB, int KR>
+  __device__ void rows(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    const int k = KR > 0 ? KR : 2 * r;
+    float* const hbuf = smem + 32 * (MB < CH ? MB : CH) * HS;       // [NBND][rows of a chunk][HB]
+    // everything below is 32-bit (the launcher checks B*To < 2^31 and B*M*To < 2^31): the kernel sits at its register budget
+    const int O0 = (int)ntile * n_out;                    // first flat output of the tile (uniform)
+    const int O = O0 + lane;
+    const bool in_range = lane < n_out && O < B * To;
+    const unsigned ob = in_range ? __umulhi((unsigned)O, to_magic) >> to_shift : 0u;     // stream of this lane's output
+    const int o_in = O - (int)ob * To;
+    const unsigned yoff = ob * (unsigned)(M * To) + (unsigned)o_in;                      // + m * To
+    // stream boundaries b*To inside [O0, O0 + n_out]: b = hb0, hb0 + 1, ... (uniform); a head lane's boundary slot = ob - hb0
+    const int hb0 = (int)(__umulhi((unsigned)(O0 + To - 1), to_magic) >> to_shift);
+    const bool head = in_range && o_in == 0;
+    const int hslot = head ? (int)ob - hb0 : 0;           // < NBND
+    constexpr int RG = KR > 0 && KR <= 8 ? 4 : 2;
+#pragma unroll
+    for (int ch = 0; ch < (MB + CH - 1) / CH; ++ch) {
+      // accumulators of the chunk -> LDS (acc_chunk_to_lds), and the cache words of the tile's stream starts -> side buffer
+      __syncthreads();
+      const int nblk = (MB - ch * CH) < CH ? (MB - ch * CH) : CH;
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        if (i >= ch * CH && i < ch * CH + CH) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            smem[((i - ch * CH) * 32 + acc_row(q, lane)) * HS + wave * 32 + (lane & 31)] = acc[i][q];
+        }
+      }
+      for (int e = tid; e < NBND * 32 * CH * HB; e += NT) {
+        const int j = e % HB, row = (e / HB) % (32 * CH), slot = e / (HB * 32 * CH);
+        const int bq = hb0 + slot, m = m0 + ch * CH * 32 + row;
+        float v = 0.f;
+        if (hist != nullptr && j < r && bq < B && m < M && row < 32 * nblk) v = hist[(long)(bq * M + m) * r + j];
+        hbuf[e] = v;
+      }
+      __syncthreads();
+      for (int s0 = 0; s0 < 8 * nblk; s0 += RG) {
+        float wv[RG][KR > 0 ? KR : 1];
+        float bv[RG];
+        int mrow[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const int row = __builtin_amdgcn_readfirstlane(wave + 4 * (s0 + g));
+          const int m = m0 + ch * CH * 32 + row;
+          mrow[g] = m;
+          const int mc = m < M ? m : M - 1;
+          if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < (KR > 0 ? KR : 1); ++j) wv[g][j] = dw_w[(long)mc * k + j];
+          }
+          bv[g] = dw_b ? dw_b[mc] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const int row = __builtin_amdgcn_readfirstlane(wave + 4 * (s0 + g));
+          const int m = mrow[g];
+          if (s0 + g >= 8 * nblk || m >= M) continue;      // uniform
+          const float* w = dw_w + (long)m * k;
+          const float* hhi = smem + row * HS + H + (in_range ? lane : 0) * r;         // second half: the output's own r columns
+          const float* hlo = head ? hbuf + (hslot * 32 * CH + row) * HB : hhi - r;   // first half: the r columns before, or the cache
+          float a = 0.f;
+          if (KR == 8) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(hlo), v1 = *reinterpret_cast<const f32x4*>(hhi);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(wv[g][j < KR ? j : 0], v[j], a);
+          } else if (KR == 4) {
+            const f32x2 v0 = *reinterpret_cast<const f32x2*>(hlo), v1 = *reinterpret_cast<const f32x2*>(hhi);
+            const float v[4] = {v0.x, v0.y, v1.x, v1.y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a = fmaf(wv[g][j < KR ? j : 0], v[j], a);
+          } else if (KR > 0) {
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) a = fmaf(wv[g][j], hlo[j], a);
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) a = fmaf(wv[g][KR / 2 + j], hhi[j], a);
+          } else {
+            for (int j = 0; j < r; ++j) a = fmaf(w[j], hlo[j], a);
+            for (int j = 0; j < r; ++j) a = fmaf(w[r + j], hhi[j], a);
+          }
+          if (dw_b) a = __fadd_rn(a, bv[g]);
+          if (in_range) y[yoff + (unsigned)(m * To)] = a;
+          if (hist_out != nullptr && lane < r) {           // streams that END in this tile: their last r columns are the new cache
+            for (int bq = hb0 > 1 ? hb0 : 1; (bq - 1) * To + To - 1 < O0 + n_out && bq <= B; ++bq) {      // uniform: 0-2 of them
+              if (bq * To - 1 >= O0)
+                hist_out[(long)((bq - 1) * M + m) * r + lane] = smem[row * HS + H + (bq * To - O0) * r - r + lane];
+            }
+          }
+        }
+      }
+    }
+  }
+
+  template <int MB>
+  __device__ void run(const f32x16 (&acc)[MB], float* smem, int m0, long ntile, int wave, int lane, int tid) const {
+    switch (r) {                                 // uniform
+      case 2: rows<MB, 4>(acc, smem, m0, ntile, wave, lane, tid); break;
+      case 4: rows<MB, 8>(acc, smem, m0, ntile, wave, lane, tid); break;
+      case 5: rows<MB, 10>(acc, smem, m0, ntile, wave, lane, tid); break;
+      case 8: rows<MB, 16>(acc, smem, m0, ntile, wave, lane, tid); break;
+      default: rows<MB, 0>(acc, smem, m0, ntile, wave, lane, tid); break;
+    }
+  }
+};
+
 // Streaming hop, wide layers (T <= 128 samples per stream and call): a tile holds `cpt` WHOLE clips
 // (columns q*T + t), so there is no halo — the samples before t = 0 come from the cache
 // hist[b][m][pad] (pad = ksize - stride: the last `pad` pointwise outputs of the previous hop,

@@ -54,6 +54,25 @@ struct TileCols {
   }
 };
 
+// flat (stream-major) columns with a left halo: tile covers flat columns [ntile*step - halo, +BN) of the [B*T] column space.
+// For the strided depthwise epilogue of a streaming hop that is longer than one tile (DwStrideFlatEpilogue): per-stream tiles
+// are 62 % (T = 160) / 86 % (T = 320) full, flat ones 97 %.  T % 4 == 0, step % 4 == 0, halo % 4 == 0: a 4-column group never
+// straddles streams.  Columns before the first stream / past the last are never read back (the epilogue takes the cache or
+// zeros at a stream's first output).
+struct FlatHaloCols {
+  int K, T, step, halo;
+  long ncols;
+  static constexpr bool kZeroInvalid = false;
+  __device__ LinCol at(long ntile, int c) const {
+    LinCol r;
+    const long n = ntile * step - halo + c;
+    r.ok = n >= 0 && n < ncols;
+    const long b = r.ok ? n / T : 0;
+    r.off = r.ok ? (unsigned)(b * (long)K * T + (n - b * T)) : 0u;
+    return r;
+  }
+};
+
 // ---- B-operand policies: everything loop-invariant lives in State, a fetch is "uniform base + 32-bit offset"
 // rows of a [.., K, T] tensor through the Scale / ELU prologue
 template <class Cols, bool ELU>

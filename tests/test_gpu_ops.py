@@ -473,9 +473,11 @@ def test_up_conv_vs_oracle(env, K, M, Tin, r):
                                            (64, 128, 12, 5, 1, 11),
                                            # hops longer than one tile (the encoder's first two down-sampling layers)
                                            (64, 128, 320, 4, 2, 5), (128, 256, 160, 8, 4, 6), (96, 192, 132, 4, 2, 3),
-                                           (64, 96, 640, 10, 5, 2)])
+                                           (64, 96, 640, 10, 5, 2),
+                                           # the same on many streams: flat tiles straddle one or two stream boundaries, ragged last tile
+                                           (128, 256, 160, 8, 4, 131), (64, 128, 320, 4, 2, 77), (64, 128, 136, 16, 8, 40), (128, 256, 160, 8, 4, 1)])
 def test_dws_conv_stream_vs_unfused_and_offline(env, K, M, Tn, k, s, B):
-    """hilc_dws_conv_stream (whole-clip tiles, or per-clip halo tiles for T > 128; cache-aware epilogues) over 3 hops: against the pointwise GEMM +
+    """hilc_dws_conv_stream (whole-clip tiles, or flat stream-major halo tiles for T > 128; cache-aware epilogues) over 3 hops: against the pointwise GEMM +
     cached depthwise conv (the already oracle-pinned streaming ops), and — concatenated — against the oracle's
     offline causal conv of the whole signal (causal_layers.py:147-165 cache semantics)."""
     ops, fold, O, dev = env
