@@ -410,7 +410,7 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
              (res == nullptr || (reinterpret_cast<uintptr_t>(res) & 15) == 0);
     ld.tiles = ep.tiles; ld.step = Dw5Epilogue::STEP; ld.halo = 4;
     ld.vec = aligned && (T % 4 == 0);
-    if (ld.vec && lin_ok(B, K, T)) {
+    if (ld.vec && lin_tile_ok(B, K, T)) {
       TileCols cols;
       cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
 #ifndef HILC_NO_WAVE_ROW
@@ -449,7 +449,7 @@ extern "C" int hilc_dws_conv(const float* x, const float* wt, const float* dw_w,
   ep.tiles = (ep.To + ep.n_out - 1) / ep.n_out;
   ld.tiles = ep.tiles; ld.step = ep.n_out * stride; ld.halo = ep.H;
   ld.vec = aligned && (T % 4 == 0);
-  if (ld.vec && lin_ok(B, K, T)) {
+  if (ld.vec && lin_tile_ok(B, K, T)) {
     TileCols cols;
     cols.K = K; cols.T = T; cols.tiles = ep.tiles; cols.step = ld.step; cols.halo = ld.halo;
 #ifndef HILC_NO_WAVE_ROW

@@ -7,8 +7,9 @@
 namespace hilc {
 
 // the linear-addressing cores use 32-bit byte offsets into x
-// 32-bit byte offsets per thread, and `tc` of gemm_lin.h clamps a column group to [0, T - 4]: needs T >= 4
-static inline bool lin_ok(int B, int K, int T) { return T >= 4 && (long)B * K * T * 4 < (1L << 32); }
+static inline bool lin_ok(int B, int K, int T) { return (long)B * K * T * 4 < (1L << 32); }
+// per-clip halo tiles (TileCols) clamp a column group to [0, T - 4]: they need T >= 4 on top
+static inline bool lin_tile_ok(int B, int K, int T) { return T >= 4 && lin_ok(B, K, T); }
 
 // n / d for n < 2^31 as __umulhi(n, magic) >> shift (Granlund-Montgomery): l = ceil(log2 d), magic = ceil(2^(31+l)/d); d >= 2
 static inline void div_magic(int d, unsigned& m, unsigned& sh) {

@@ -9,12 +9,14 @@
 // candidates as `-2 r@e^T + |e|^2`, models/hilcodec/vector_quantize.py:146-152); the arg-min keeps
 // the LOWEST index among equal distances (torch CPU `min(dim)` behaviour) through a
 // lexicographic (distance, index) wave64 shuffle reduction followed by a 4-wave LDS reduction.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 // frames per workgroup: 16 for large batches; 4 when 16 would leave most CUs idle (a streaming hop of 1024 frames
-// = 64 workgroups otherwise) — the code scores are independent of FR, only the work split changes
+// = 64 workgroups otherwise) — the code scores are independent of FR and of the threads per workgroup, only the work split changes
 constexpr int RS = 20;   // LDS row stride (floats) of the [c][frame] tiles: 16-B aligned, spreads banks
 constexpr int CPT = 4;   // codes per thread (K / 256 for K = 1024)
 
@@ -38,13 +40,16 @@ __device__ __forceinline__ long zoff(const RvqArgs& a, long g, int c) {
   return (b * a.C + c) * (long)a.T + t;
 }
 
-template <int C, int FR>
-__global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
+// NTH threads per workgroup, CPTK = K / NTH codes per thread: 256 x 4 for large batches; a streaming hop (1024 frames, FR = 4: one
+// workgroup per CU) is bound by the L2 round trips of the code words, and 1024 x 1 puts four waves on every SIMD to hide them
+template <int C, int FR, int NTH = 256>
+__global__ __launch_bounds__(NTH) void rvq_encode_kernel(RvqArgs a) {
+  constexpr int CPTK = 1024 / NTH, NWV = NTH / 64;
   static_assert(FR % 4 == 0 && FR <= RS, "frames are read as float4 rows");
   __shared__ __attribute__((aligned(16))) float res[C][RS];
   __shared__ __attribute__((aligned(16))) float qsum[C][RS];
-  __shared__ float wbest[4][FR];
-  __shared__ int widx[4][FR];
+  __shared__ float wbest[NWV][FR];
+  __shared__ int widx[NWV][FR];
   __shared__ int sel[FR];
   __shared__ int nfr[FR];   // stages of each frame's clip
 
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
   const long nframes = (long)a.B * a.T;
   const long g0 = (long)blockIdx.x * FR;
 
-  for (int e = tid; e < FR * C; e += 256) {
+  for (int e = tid; e < FR * C; e += NTH) {
     int f = e % FR, c = e / FR;
     long g = g0 + f;
     res[c][f] = g < nframes ? a.z[zoff(a, g, c)] : 0.f;
@@ -75,9 +80,9 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     const float* cb = a.cb + (long)s * a.K * C;
     const float* nrm = a.norms + (long)s * a.K;
 
-    float acc[CPT][FR];
+    float acc[CPTK][FR];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j)
+    for (int j = 0; j < CPTK; ++j)
 #pragma unroll
       for (int f = 0; f < FR; ++f) acc[j][f] = 0.f;
 
@@ -85,14 +90,14 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     // worth of loads are issued before the first FMA of the group needs one.  With FR = 4 a CU holds one wave per
     // SIMD and nothing else hides the L2 round trip, so the group is deep (64 loads in flight per thread); with
     // FR = 16 the 64 accumulators leave room for 2 channels.
-    constexpr int UC = FR <= 4 ? 16 : 2;
+        constexpr int UC = FR <= 4 ? 16 : 2;          // (512 threads: 8 -> 113 us, 16 -> 96 us, 32 -> 132 us)
     static_assert(C % UC == 0, "channel groups");
     for (int c0 = 0; c0 < C; c0 += UC) {
-      float e[UC][CPT];
+      float e[UC][CPTK];
 #pragma unroll
       for (int u = 0; u < UC; ++u)
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) e[u][j] = cbt[(long)(c0 + u) * a.K + tid + 256 * j];
+        for (int j = 0; j < CPTK; ++j) e[u][j] = cbt[(long)(c0 + u) * a.K + tid + NTH * j];
 #pragma unroll
       for (int u = 0; u < UC; ++u) {
         float r[FR];
@@ -102,24 +107,24 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
           r[f4] = v.x; r[f4 + 1] = v.y; r[f4 + 2] = v.z; r[f4 + 3] = v.w;
         }
 #pragma unroll
-        for (int j = 0; j < CPT; ++j)
+        for (int j = 0; j < CPTK; ++j)
 #pragma unroll
           for (int f = 0; f < FR; ++f) acc[j][f] = fmaf(r[f], e[u][j], acc[j][f]);
       }
     }
 
-    float nk[CPT];
+    float nk[CPTK];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) nk[j] = nrm[tid + 256 * j];
+    for (int j = 0; j < CPTK; ++j) nk[j] = nrm[tid + NTH * j];
 
 #pragma unroll
     for (int f = 0; f < FR; ++f) {
       float best = fmaf(-2.f, acc[0][f], nk[0]);
       int bi = tid;
 #pragma unroll
-      for (int j = 1; j < CPT; ++j) {
+      for (int j = 1; j < CPTK; ++j) {
         float d = fmaf(-2.f, acc[j][f], nk[j]);
-        if (d < best) { best = d; bi = tid + 256 * j; }   // ascending index order, strict <
+        if (d < best) { best = d; bi = tid + NTH * j; }   // ascending index order, strict <
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
       float best = wbest[0][tid];
       int bi = widx[0][tid];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
+      for (int w = 1; w < NWV; ++w) {
         float od = wbest[w][tid];
         int oi = widx[w][tid];
         if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     }
     __syncthreads();
     // residual -= E[idx]; quantized_out += E[idx]   (vector_quantize.py:225-229)
-    for (int e = tid; e < FR * C; e += 256) {
+    for (int e = tid; e < FR * C; e += NTH) {
       int c = e % C, f = e / C;
       const int k = sel[f];
       if (k >= 0) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqArgs a) {
     __syncthreads();
   }
 
-  for (int e = tid; e < FR * C; e += 256) {
+  for (int e = tid; e < FR * C; e += NTH) {
     int f = e % FR, c = e / FR;
     long g = g0 + f;
     if (g < nframes && a.q != nullptr) a.q[zoff(a, g, c)] = qsum[c][f];
@@ -347,8 +352,11 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   a.channel_last = channel_last; a.stage_major = stage_major;
   long nframes = (long)B * T;
   HILC_CLEAR_ERROR();
+  // small batches (a streaming hop: 1024 frames): 4 frames per workgroup = one workgroup per CU, 512 threads x 2 codes = two waves per
+  // SIMD to hide the L2 round trips of the code words (256 x 4: 143 us, 512 x 2: 96 us, 1024 x 1: 107 us; 8 / 16 frames per
+  // workgroup: 240 / 369 us — profiles/r04_experiments.md)
   if (nframes <= 16 * 512)
-    hipLaunchKernelGGL((rvq_encode_kernel<128, 4>), dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((rvq_encode_kernel<128, 4, 512>), dim3((unsigned)((nframes + 3) / 4)), dim3(512), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((rvq_encode_kernel<128, 16>), dim3((unsigned)((nframes + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();

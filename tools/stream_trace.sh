@@ -2,7 +2,7 @@
 # kernel trace of the streaming hop graph (one chain): per-kernel durations inside the replayed graph and the gaps between them
 TAG=${1:-stream_trace}; R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/t -o st -- python $R/bench.py --mode streaming --graph --steps 20 --warmup 4 --no-cpu-baseline --no-clock-probe --no-launch-timing --no-other-configs > $O/bench.json 2> $O/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/t -o st -- python $R/bench.py --mode streaming --graph $EXTRA --steps 20 --warmup 4 --no-cpu-baseline --no-clock-probe --no-launch-timing --no-other-configs > $O/bench.json 2> $O/err.txt
 cd $R
 f=$(find $O/t -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY' | tee $O/summary.txt
@@ -28,5 +28,14 @@ print(f"{n} hops: kernel time {tot_k / n:.1f} us per hop, idle gaps between kern
       f"period {(rows[starts[-1]][0] - rows[starts[0]][0]) / n / 1e3:.1f} us, kernels per hop {sum(v[0] for v in per.values()) / n:.1f}")
 for k, v in sorted(per.items(), key=lambda kv: -kv[1][1]):
     print(f"{v[1] / n:9.1f} us/hop  {v[0] / n:5.1f} launches  {k}")
+# timeline of the last complete hop: start offset, duration, gap to the previous kernel's end (negative = overlap with another branch)
+a, b = starts[-2], starts[-1]
+t0 = rows[a][0]
+end = t0
+print("\ntimeline of one hop (us):   start   dur   gap  kernel")
+for s_, e_, k in rows[a:b]:
+    short = k.replace("hilc::", "").replace("(anonymous namespace)::", "")[:90]
+    print(f"  {(s_ - t0) / 1e3:8.1f} {(e_ - s_) / 1e3:7.1f} {(s_ - end) / 1e3:6.1f}  {short}")
+    end = max(end, e_)
 PY
 rm -rf $O/t
