@@ -509,7 +509,7 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
     // a hop longer than one tile (the encoder's first two down-sampling layers: 320 / 160 samples per stream): per-clip
     // tiles with a recomputed halo, exactly the offline kernel, plus the cache in front of the first tile and the new
     // cache out of the last one
-    if (ksize != 2 * stride || stride > 16 || res != nullptr || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
+    if (ksize != 2 * stride || stride > 16 || out_elu || out_scale != 1.0f) return HILC_ERR_UNSUPPORTED;
     if (T % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || !lin_ok(B, K, T)) return HILC_ERR_UNSUPPORTED;
     const int H = (stride + 3) / 4 * 4;
     int n_out = (BN - H - stride) / stride + 1;
@@ -519,7 +519,7 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
         (T / stride) * DwStrideFlatEpilogue::NBND >= n_out + 1) {
       // flat columns (stream-major): a tile is 97 % full whatever the hop length (per-stream tiles: 62 % at T = 160, 86 % at 320)
       DwStrideFlatEpilogue ep;
-      ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.hist = hist; ep.hist_out = hist_out;
+      ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.hist = hist; ep.hist_out = hist_out; ep.res = res;
       ep.B = B; ep.M = M; ep.T = T; ep.To = T / stride; ep.r = stride; ep.H = H; ep.n_out = n_out;
       div_magic(ep.To, ep.to_magic, ep.to_shift);
       FlatHaloCols fc;
@@ -527,6 +527,7 @@ extern "C" int hilc_dws_conv_stream(const float* x, const float* wt, const float
       const long ntiles = (nout_all + n_out - 1) / n_out;
       return launch_gemm_lin(wt, x, M, K, M, T, ntiles, in_scale, in_elu != 0, fc, ep, (hipStream_t)stream);
     }
+    if (res != nullptr) return HILC_ERR_UNSUPPORTED;     // (per-stream tiles: the fallback for > 2^31 outputs has no shortcut)
     DwStrideEpilogue ep;
     ep.y = y; ep.dw_w = dw_w; ep.dw_b = dw_b; ep.M = M; ep.r = stride; ep.hist = hist; ep.hist_out = hist_out; ep.T = T;
     ep.To = T / stride;

@@ -574,6 +574,7 @@ struct DwStrideFlatEpilogue {
   const float* dw_b;
   const float* hist = nullptr;    // [B][M][r]
   float* hist_out = nullptr;
+  const float* res = nullptr;     // [B][M][To] added to the output (the next stage's SpecBlock branch); may not alias y
   int B, M, T, To, r, H, n_out;
   unsigned to_magic, to_shift;    // O / To for O < 2^31
   static constexpr int NBND = 2;  // stream starts per tile the side buffer holds (the launcher checks To >= n_out / NBND)
@@ -662,7 +663,10 @@ struct DwStrideFlatEpilogue {
             for (int j = 0; j < r; ++j) a = fmaf(w[r + j], hhi[j], a);
           }
           if (dw_b) a = __fadd_rn(a, bv[g]);
-          if (in_range) y[yoff + (unsigned)(m * To)] = a;
+          if (in_range) {
+            const unsigned yo = yoff + (unsigned)(m * To);
+            y[yo] = res != nullptr ? __fadd_rn(a, res[yo]) : a;
+          }
           if (hist_out != nullptr && lane < r) {           // streams that END in this tile: their last r columns are the new cache
             for (int bq = hb0 > 1 ? hb0 : 1; (bq - 1) * To + To - 1 < O0 + n_out && bq <= B; ++bq) {      // uniform: 0-2 of them
               if (bq * To - 1 >= O0)

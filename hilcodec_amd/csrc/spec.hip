@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
       if constexpr (!PRE) {       // all residual loads before the first store (x may alias y: later loads would wait behind it)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          if (f0 + c0 + 4 * g < a.Tf) rq[g] = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+          if (a.x != nullptr && f0 + c0 + 4 * g < a.Tf) rq[g] = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
             float t = v[e];
             if (a.bias != nullptr) t = __fadd_rn(t, bv);
             t = __fmul_rn(t, a.out_scale);
-            v[e] = __fadd_rn(t, rr[e]);                  // separate roundings: y.mul_(scale); x.add_(y)
+            v[e] = (PRE || a.x != nullptr) ? __fadd_rn(t, rr[e]) : t;   // separate roundings: y.mul_(scale); x.add_(y)  (x NULL: the branch alone)
           }
           *reinterpret_cast<f32x4*>(a.y + off0 + 4 * g) = v;
         }
@@ -349,7 +349,7 @@ extern "C" int hilc_spec_block(const float* wav, const float* hist, int hist_len
                                const float* nyq_sin, const float* pw_packed, const float* bias, const float* x, float* y,
                                int B, int T, int n_fft, int hop, float mean, float stdv, int normalize, float out_scale,
                                void* stream) {
-  if (!wav || !dft_packed || !nyq_sin || !pw_packed || !x || !y) return HILC_ERR_NULL;
+  if (!wav || !dft_packed || !nyq_sin || !pw_packed || !y) return HILC_ERR_NULL;      // x NULL: y = out_scale * (W spec + bias)
   if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
   if (hist != nullptr && hist_len < n_fft - 1) return HILC_ERR_SHAPE;
   if (!hilc_spec_block_supported(n_fft, hop, n_fft, T)) return HILC_ERR_UNSUPPORTED;

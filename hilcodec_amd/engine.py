@@ -46,6 +46,7 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
+    stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
     stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
 
 
@@ -328,28 +329,29 @@ def _spec_fused(sb: SpecBlockSpec, wav: Tensor, wav_hist: Optional[Tensor]) -> b
                 and ops.spec_block_profitable(sb.n_fft, sb.hop, sb.wt.shape[1], wav.shape[2]))
 
 
-def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor], early: Optional[dict] = None) -> Tensor:
+def _spec_block(sb: SpecBlockSpec, x: Tensor, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
     if _spec_fused(sb, wav, wav_hist):
         return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, x, sb.n_fft, sb.hop, sb.mean, sb.std,
                               sb.normalize, sb.out_scale, hist=wav_hist)
-    if early is not None and id(sb) in early:
-        s, done = early[id(sb)]
-        torch.cuda.current_stream(x.device).wait_event(done)
-    else:
-        s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+    s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
     return ops.pw_conv(s, sb.wt, sb.bias, res=x, out_scale=sb.out_scale)
 
 
-def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor], side, skip=()) -> Optional[dict]:
-    """Streaming hop inside a captured graph: the log-magnitude spectra of the un-fused SpecBlocks depend on the
-    waveform only, so they are computed on `side` (`spectra_side_stream`) beside the first encoder stages (their small launches fill
-    idle CUs instead of standing in the chain); `_spec_block` waits for each one's event.  Same launches, same
-    results."""
-    if side is None or torch.compiler.is_compiling() or not wav.is_cuda:
-        return None
-    todo = [sb for sb in [st.spec for st in es.stages] + [es.spec_post]
-            if not _spec_fused(sb, wav, wav_hist) and not any(sb is k for k in skip)]
-    if not todo:                      # nothing un-fused: do not fork a stream that nothing joins
+def _spec_branch(sb: SpecBlockSpec, wav: Tensor, wav_hist: Optional[Tensor]) -> Tensor:
+    """The SpecBlock's branch ALONE: out_scale * (W logspec(wav) + bias) `[B, C, T_f]` — what `x.add_()` adds
+    (`seanet.py:220-246`; streaming, merged: `streaming.py:346-366`).  It depends on the waveform only."""
+    if _spec_fused(sb, wav, wav_hist):
+        return ops.spec_block(wav, sb.fused[0], sb.fused[1], sb.fused[2], sb.bias, None, sb.n_fft, sb.hop, sb.mean, sb.std,
+                              sb.normalize, sb.out_scale, hist=wav_hist)
+    s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+    return ops.pw_conv(s, sb.wt, sb.bias, out_scale=sb.out_scale)
+
+
+def _early_branches(todo: Sequence[SpecBlockSpec], wav: Tensor, wav_hist: Optional[Tensor], side) -> Optional[dict]:
+    """Streaming hop inside a captured graph: the SpecBlock branches of the later stages depend on the waveform only, so they
+    are computed on `side` (`spectra_side_stream`) beside the first encoder stages (their launches fill idle CUs instead of
+    standing in the chain); the consumer waits for each one's event.  Same launches, same results."""
+    if side is None or torch.compiler.is_compiling() or not wav.is_cuda or not todo:
         return None
     main = torch.cuda.current_stream(wav.device)
     capturing = torch.cuda.is_current_stream_capturing()
@@ -357,12 +359,12 @@ def _early_spectra(es: "EncoderSpec", wav: Tensor, wav_hist: Optional[Tensor], s
     side.wait_stream(main)
     with torch.cuda.stream(side):
         for sb in todo:
-            s = ops.stft_logmag(wav, sb.basis_t, sb.n_fft, sb.hop, sb.mean, sb.std, sb.normalize, hist=wav_hist)
+            r = _spec_branch(sb, wav, wav_hist)
             if not capturing:
-                s.record_stream(main)
+                r.record_stream(main)
             done = torch.cuda.Event()
             done.record(side)
-            early[id(sb)] = (s, done)
+            early[id(sb)] = (r, done)
     return early
 
 
@@ -443,21 +445,37 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
     else:
         x = ops.conv_pre(wav, es.pre_w, es.pre_b, in_scale=es.pre_in_scale, hist=wav_hist)
+    # Streaming hop: the SpecBlock branch of stage s + 1 (and spec_post's) is `x.add_(branch)` right after stage s's
+    # down-sampling layer (`streaming.py:497-511`), and the branch depends on the waveform only.  It is computed on its own —
+    # inside a captured graph beside the earlier stages, on the side stream — and ADDED BY THE DOWN-SAMPLING LAYER'S EPILOGUE
+    # (`res`): one launch and one read + write of x less per stage on the critical path, the same two roundings in the same
+    # order (`fadd(down, branch)`), bit-identical to the in-line form.
+    later = [st.spec for st in es.stages[1:]] + [es.spec_post]
+    defer = streaming and FUSE_STREAM and opts.stream_defer_spec
     side = None if torch.compiler.is_compiling() else _SIDE_STREAM.get()          # (a tracing compiler cannot read a ContextVar; it never forks streams)
-    early = _early_spectra(es, wav, wav_hist, side, skip=(sb0,) if fuse_pre else ()) if streaming else None
+    early = _early_branches(later, wav, wav_hist, side) if defer else None
+
+    def branch_of(sb):
+        if early is not None and id(sb) in early:
+            r, done = early[id(sb)]
+            torch.cuda.current_stream(wav.device).wait_event(done)
+            return r
+        return _spec_branch(sb, wav, wav_hist)
+
     for si, st in enumerate(es.stages):
-        if not (fuse_pre and si == 0):
-            x = _spec_block(st.spec, x, wav, wav_hist, early)
+        if not (fuse_pre and si == 0) and not (defer and si > 0):
+            x = _spec_block(st.spec, x, wav, wav_hist)
         x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, False, opts)
         ci += 2 * len(st.blocks)
+        nxt = later[si] if defer else None
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
-            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci],
+            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci], res=branch_of(nxt) if defer else None,
                                        stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
         elif streaming:
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
-            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio, hist=caches[ci], want_hist=True,
-                               hist_out=out(ci))
+            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, res=branch_of(nxt) if defer else None, stride=st.ratio, hist=caches[ci],
+                               want_hist=True, hist_out=out(ci))
             new_caches.append(c)
         elif FUSE_DWS and st.down_dw_w.shape[1] == 2 * st.ratio:
             x = ops.dws_conv(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, stride=st.ratio,
@@ -466,7 +484,8 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
             x = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, stride=st.ratio)
         ci += 1
-    x = _spec_block(es.spec_post, x, wav, wav_hist, early)
+    if not defer:
+        x = _spec_block(es.spec_post, x, wav, wav_hist)
     if streaming:
         h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)

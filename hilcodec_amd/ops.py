@@ -593,19 +593,19 @@ def _spec_block(wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, 
     B, one, T = wav.shape
     hl = hist.shape[-1] if hist is not None else 0
     Tf = (T - 1) // hop + 1
-    if tuple(x.shape) != (B, n_fft, Tf):
+    if x is not None and tuple(x.shape) != (B, n_fft, Tf):
         raise RuntimeError(f"spec_block: x must be [{B},{n_fft},{Tf}], got {tuple(x.shape)}")
-    y = torch.empty_like(x)
+    y = torch.empty(B, n_fft, Tf, device=wav.device, dtype=torch.float32)
     with _timed("spec_block", 2.0 * B * Tf * n_fft * (n_fft + 1 + n_fft // 2 + 1), f"N{n_fft} hop{hop}"):
         check(lib.hilc_spec_block(_ptr(wav), _ptr(hist), hl, _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(x), _ptr(y),
                                   B, T, n_fft, hop, mean, std, normalize, out_scale, _stream()), "hilc_spec_block")
     return y
 
 
-_register("spec_block", "(Tensor wav, Tensor? hist, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor x, "
+_register("spec_block", "(Tensor wav, Tensor? hist, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor? x, "
           "int n_fft, int hop, float mean, float std, int normalize, float out_scale) -> Tensor", _spec_block,
           lambda wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, n_fft, hop, mean, std, normalize, out_scale:
-          torch.empty_like(x))
+          wav.new_empty(wav.shape[0], n_fft, (wav.shape[2] - 1) // hop + 1))
 
 
 def _spec_block_conv_pre(wav, hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, n_fft, hop, mean, std,
@@ -960,11 +960,11 @@ def spec_block_tables(basis_t: Tensor, wt: Tensor, n_fft: int):
     return (_OPS.spec_block_pack(dft, int(n_fft), 0), nyq, _OPS.spec_block_pack(wt.contiguous(), int(n_fft), 1))
 
 
-def spec_block(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor], x: Tensor,
+def spec_block(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_packed: Tensor, bias: Optional[Tensor], x: Optional[Tensor],
                n_fft: int, hop: int, mean: float = 0.0, std: float = 1.0, normalize=True, out_scale: float = 1.0,
                hist: Optional[Tensor] = None) -> Tensor:
     """One-launch SpecBlock (hilc_spec_block): wav `[B,1,T]`, x `[B,n_fft,T/hop]` -> x + out_scale * (W spec + bias);
-    hist `[B,1,L]` (L >= n_fft-1) = the waveform before t = 0 (streaming hop)."""
+    hist `[B,1,L]` (L >= n_fft-1) = the waveform before t = 0 (streaming hop).  x None: the branch alone."""
     return _OPS.spec_block(wav, hist, dft_packed, nyq_sin, pw_packed, bias, x, int(n_fft), int(hop), float(mean), float(std),
                            int(normalize), float(out_scale))
 

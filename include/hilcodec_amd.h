@@ -251,6 +251,8 @@ int hilc_stft_logmag(const float* wav, const float* hist, int hist_len, const fl
  * i.e. SpecBlock.forward (`models/hilcodec/modules/seanet.py:220-246`: CausalSTFT `conv.py:329-358`, log / normalise,
  * 1x1 conv, `x.add_(y.mul_(scale))`) without the [n_fft/2+1 x T_f] tensor ever reaching HBM.  Bit-identical to
  * hilc_stft_logmag + hilc_pw_conv(res = x).  T_f = (T-1)/hop + 1 must be a multiple of 4; x, y 16-B aligned, y != x.
+ * x == NULL: the branch alone, y = out_scale * (W spec + bias) — it depends on the waveform only, so a streaming hop computes it
+ * beside the previous stage and the down-sampling layer in front adds it as its `res` (same two roundings, same result).
  * dft_packed / pw_packed: hilc_spec_block_pack of
  *   which = 0: the k-major `[n_fft][n_fft]` DFT matrix whose columns are (cos_0, cos_{N/2}, cos_1, sin_1, cos_2, sin_2, ...,
  *              cos_{N/2-1}, sin_{N/2-1}) * hann — the reference basis without the all-zero sin_0 row and without sin_{N/2};

@@ -411,6 +411,42 @@ def test_resblock_chain_equals_block_by_block(env, C, T, B, n):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("K,M,T,r,B", [(64, 128, 320, 2, 9), (128, 256, 160, 4, 33), (256, 512, 40, 5, 7), (512, 1024, 8, 8, 21)])
+def test_down_conv_stream_adds_the_next_spec_branch(env, K, M, T, r, B):
+    """`res` of the streaming down-sampling layer (flat strided epilogue for T > 128, whole-stream tiles below): the next stage's
+    SpecBlock branch is added by the epilogue, fadd(down, branch) — the same bits as the in-line `x.add_(branch)` one launch
+    later (`streaming.py:497-511`)."""
+    ops, fold, O, dev = env
+    wt = (rnd(1, K, M) / K ** 0.5).to(dev)
+    dw, db = (rnd(2, M, 2 * r) * 0.4).to(dev), (rnd(3, M) * 0.2).to(dev)
+    x = rnd(4, B, K, T).to(dev)
+    cache = (rnd(5, B, M, r) * 0.5).to(dev)
+    branch = rnd(6, B, M, T // r).to(dev)
+    y0, c0 = ops.dws_conv_stream(x, wt, dw, db, cache, stride=r, in_scale=0.77, in_elu=True)
+    y1, c1 = ops.dws_conv_stream(x, wt, dw, db, cache, res=branch, stride=r, in_scale=0.77, in_elu=True)
+    assert torch.equal(y1, y0 + branch) and torch.equal(c0, c1)
+
+
+@pytest.mark.parametrize("n_fft,hop,B,T", [(128, 2, 5, 320), (64, 1, 2, 640), (256, 8, 3, 2048)])
+def test_spec_block_branch_alone(env, n_fft, hop, B, T):
+    """hilc_spec_block with x = NULL: the branch alone (what a streaming hop computes beside the previous stage); branch + x in a
+    separate add equals the one-launch block bit for bit."""
+    ops, fold, O, dev = env
+    from hilcodec_amd.models.hilcodec.modules.conv import CausalSTFT
+    st = CausalSTFT(n_fft, hop)
+    basis = fold.stft_basis_layout(st.weight).to(dev)
+    C = n_fft
+    w = (rnd(1, n_fft // 2 + 1, C) / n_fft ** 0.5).to(dev)
+    bias = (rnd(2, C) * 0.1).to(dev)
+    tables = ops.spec_block_tables(basis, w, n_fft)
+    wav = (rnd(3, B, 1, T) * 0.1).to(dev)
+    hist = (rnd(4, B, 1, n_fft - 1) * 0.1).to(dev)
+    x = rnd(5, B, C, (T - 1) // hop + 1).to(dev)
+    full = ops.spec_block(wav, tables[0], tables[1], tables[2], bias, x, n_fft, hop, -4.0, 2.8, True, 0.45, hist=hist)
+    alone = ops.spec_block(wav, tables[0], tables[1], tables[2], bias, None, n_fft, hop, -4.0, 2.8, True, 0.45, hist=hist)
+    assert torch.equal(alone + x, full)
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib

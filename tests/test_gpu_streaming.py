@@ -423,7 +423,8 @@ def test_stream_block_options_reach_both_halves():
     B, hops = 8, 3
     x = synth.synth_clips(B, 320 * hops, seed=80).to(dev)
 
-    def run(chain, wide):
+    def run(chain, wide, defer=True):
+        model.encoder.exec_options.stream_defer_spec = defer
         for half in (model.encoder, model.decoder):
             half.exec_options.stream_chain_blocks = chain
             half.exec_options.stream_wide_blocks = wide
@@ -444,7 +445,9 @@ def test_stream_block_options_reach_both_halves():
         chained, k_chain, c_chain = run(True, True)
         one, k_one, c_one = run(False, True)
         two, k_two, c_two = run(False, False)
+        inline, _, c_inline = run(True, True, defer=False)          # SpecBlock branches added in-line (round 3) instead of by the down-sampling epilogues
     finally:
+        model.encoder.exec_options.stream_defer_spec = True
         for half in (model.encoder, model.decoder):
             half.exec_options.stream_chain_blocks = True
             half.exec_options.stream_wide_blocks = True
@@ -452,11 +455,11 @@ def test_stream_block_options_reach_both_halves():
     # (encoder) / C = 384 (decoder) is one launch; without the wide forms the 4 + 6 wide blocks are two GEMM launches each instead.
     assert k_one == (8, 12) and k_two == (4, 6), (k_one, k_two)
     assert k_chain == (3 + 2, 3 + 3), k_chain
-    for ref, other in ((chained, one), (chained, two)):
+    for ref, other in ((chained, one), (chained, two), (chained, inline)):
         for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
             assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
-    for a, b, c in zip(c_chain, c_one, c_two):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b, c, d in zip(c_chain, c_one, c_two, c_inline):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
 
 
 def test_streaming_weight_standardised_checkpoint(golden):
