@@ -72,6 +72,8 @@ def parse():
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--groups", type=int, default=1, help="with --graph: split the streams into this many groups whose "
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
+    ap.add_argument("--no-offline-chain", action="store_true", help="offline mode, A/B: one launch per residual block (round 3) instead of "
+                    "one per stage (hilc_resblock_chain, streaming = 0); same arithmetic, bit-identical outputs")
     ap.add_argument("--no-chain", action="store_true", help="streaming mode, A/B: one launch per residual block (round 3) instead "
                     "of one launch per stage (hilc_resblock_chain); same arithmetic, bit-identical outputs")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
@@ -259,7 +261,7 @@ def parity_census(model, sd, nq, z, idx, wav, oracle_out):
 # ---------------------------------------------------------------------------------------------------------------------
 # workloads: each returns (step, audio_seconds_per_step, context)
 # ---------------------------------------------------------------------------------------------------------------------
-def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
+def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bool = True):
     import hilcodec_amd
     from hilcodec_amd import synth
     mk = synth.model_kwargs(name)
@@ -268,6 +270,7 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
     model.load_state_dict(sd, strict=False)
     for l in model.quantizer.layers:
         l.initted = True
+    model.encoder.exec_options.offline_chain_blocks = model.decoder.exec_options.offline_chain_blocks = chain
     x = synth.synth_clips(n_clips, T, seed=1234, first=first).to(dev)
     last = {}
 
@@ -392,7 +395,7 @@ def main():
     lo, hi = D.shard_range(B * shard_world, shard_rank, shard_world)
 
     if args.mode == "offline":
-        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev)
+        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev, not args.no_offline_chain)
     else:
         step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups, not args.no_chain)
         if args.graph:

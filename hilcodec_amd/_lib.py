@@ -43,6 +43,7 @@ SIGNATURES = {
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "hilc_resblock_chain_supported": [_i, _i, _i, _i],
     "hilc_resblock_chain_row_classes": [_i],
+    "hilc_resblock_chain_row_classes_offline": [_i],
     "hilc_resblock_pack_weights_rc": [_p, _p, _i, _i, _p],
     "hilc_resblock_chain": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],

@@ -14,15 +14,21 @@ constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C =
 
 extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming) {
   if (nblk < 2 || nblk > MAXBLK || T <= 0 || T % 4 != 0) return 0;
-  if (!streaming) return 0;                          // offline chains: not instantiated (see profiles/r04_experiments.md)
   // the instantiations hold the carry slots / tap tables of 2 blocks at the encoder's widths and of 3 at the decoder's
   const int max_blocks = (C == 96 || C == 192 || C == 768) ? 3 : 2;
   if (nblk > max_blocks) return 0;
   if (chain_width(C)) return 1;
-  return (C == 512 || C == 768) && 32 % T == 0;
+  return streaming && (C == 512 || C == 768) && 32 % T == 0;
 }
 
 // packed pointwise weights of a chain launch: the 8-wave shapes split the rows in two classes also below C = 192
+// (offline: C = 64 keeps four waves = one row class; the other widths as in the streaming form)
+extern "C" int hilc_resblock_chain_row_classes_offline(int C) {
+  static_assert(Cfg<64, false, false, false, 2, false>::RH == 1 && Cfg<96, false, false, false, 3, false>::RH == 1 &&
+                Cfg<128, false, false, false, 2, true>::RH == 2 && Cfg<192, false, false, false, 3, false>::RH == 2, "packed layout");
+  return C == 128 || C == 192 ? 2 : (chain_width(C) ? 1 : 0);
+}
+
 extern "C" int hilc_resblock_chain_row_classes(int C) {
   static_assert(Cfg<64, true, false, true, 2, true>::RH == 2 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
                 Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
@@ -36,7 +42,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
   if (!hilc_resblock_chain_supported(C, T, nblk, streaming)) return HILC_ERR_UNSUPPORTED;
   if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
-  if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
+  if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
   ResArgs a;
   a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
   for (int i = 0; i < nblk; ++i) {
@@ -50,6 +56,15 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   }
   for (int i = nblk; i < MAXBLK; ++i) a.blk[i] = a.blk[0];
   hipStream_t s = (hipStream_t)stream;
+  if (!streaming) {        // offline: the carry form's contiguous runs (hilc_resblock), the blocks of the stage back to back per tile
+    switch (C) {
+      case 64: return launch_chain<64, false, 2, false>(a, B, s);
+      case 96: return launch_chain<96, false, 3, false>(a, B, s);
+      case 128: return launch_chain<128, false, 2, true>(a, B, s);
+      case 192: return launch_chain<192, false, 3, false>(a, B, s);
+      default: return HILC_ERR_UNSUPPORTED;
+    }
+  }
   switch (C) {
     case 64: return launch_chain<64, true, 2, true>(a, B, s);          // the encoder's stages hold 2 blocks; 3 fit the same kernel's loop
     case 96: return launch_chain<96, true, 3, false>(a, B, s);         // 3 row blocks do not split in two classes: 4 waves, two workgroups per CU

@@ -946,6 +946,33 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
 #undef STAMP
 }
 
+// Offline carry form with several workgroups per CU: runs in proportion to the speeds of the dispatch classes (see resblock_kernel)
+inline void set_class_shares(ResArgs& a, long blocks, long resident, int n_cu) {
+  a.classes = 0;
+  if (n_cu > 0 && blocks == resident && resident % n_cu == 0 && resident / n_cu >= 2 && resident / n_cu <= 4 &&
+      a.total_tiles >= 8 * resident) {
+    const int cls = (int)(resident / n_cu);
+    // shares of the dispatch classes (first-dispatched first), measured: see tools/res_wg_times.py and profiles/r03_experiments.md
+    double share[4] = {0, 0, 0, 0};
+    if (cls == 2) { share[0] = HILC_RES_SHARE2_0; share[1] = 1.0 - share[0]; }
+    else if (cls == 3) { share[0] = HILC_RES_SHARE3_0; share[1] = HILC_RES_SHARE3_1; share[2] = 1.0 - share[0] - share[1]; }
+    else { for (int i = 0; i < cls; ++i) share[i] = 1.0 / cls; }
+#ifdef HILC_RES_SHARE_ENV      // tuning builds only
+    if (cls == 2) { if (const char* e = getenv("HILC_SHARE2_0")) { share[0] = atof(e); share[1] = 1.0 - share[0]; } }
+    if (cls == 3) {
+      if (const char* e = getenv("HILC_SHARE3_0")) share[0] = atof(e);
+      if (const char* e = getenv("HILC_SHARE3_1")) share[1] = atof(e);
+      share[2] = 1.0 - share[0] - share[1];
+    }
+#endif
+    double acc = 0;
+    a.cum[0] = 0;
+    for (int i = 0; i < cls; ++i) { acc += share[i]; a.cum[i + 1] = (unsigned)(acc * 65536.0 + 0.5); }
+    a.cum[cls] = 65536u;
+    a.classes = cls;
+  }
+}
+
 // number of workgroups of this instantiation that can be resident on the device (CUs x occupancy), cached per device
 template <class KernelT>
 int resident_workgroups(KernelT kernel, int threads, std::atomic<int>* cache, int& n_cu_out) {
@@ -1006,6 +1033,7 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
     blocks = (a.total_tiles + a.run_tiles - 1) / a.run_tiles;
   } else {
     blocks = a.total_tiles < resident ? a.total_tiles : resident;
+    if constexpr (!STREAM) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
@@ -1067,28 +1095,7 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
   a.classes = 0;
   if constexpr (!STREAM) {
     int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0 && blocks == resident &&
-        resident % n_cu == 0 && resident / n_cu >= 2 && resident / n_cu <= 4 && a.total_tiles >= 8 * resident) {
-      const int cls = (int)(resident / n_cu);
-      // shares of the dispatch classes (first-dispatched first), measured: see tools/res_wg_times.py and profiles/r03_experiments.md
-      double share[4] = {0, 0, 0, 0};
-      if (cls == 2) { share[0] = HILC_RES_SHARE2_0; share[1] = 1.0 - share[0]; }
-      else if (cls == 3) { share[0] = HILC_RES_SHARE3_0; share[1] = HILC_RES_SHARE3_1; share[2] = 1.0 - share[0] - share[1]; }
-      else { for (int i = 0; i < cls; ++i) share[i] = 1.0 / cls; }
-#ifdef HILC_RES_SHARE_ENV      // tuning builds only
-      if (cls == 2) { if (const char* e = getenv("HILC_SHARE2_0")) { share[0] = atof(e); share[1] = 1.0 - share[0]; } }
-      if (cls == 3) {
-        if (const char* e = getenv("HILC_SHARE3_0")) share[0] = atof(e);
-        if (const char* e = getenv("HILC_SHARE3_1")) share[1] = atof(e);
-        share[2] = 1.0 - share[0] - share[1];
-      }
-#endif
-      double acc = 0;
-      a.cum[0] = 0;
-      for (int i = 0; i < cls; ++i) { acc += share[i]; a.cum[i + 1] = (unsigned)(acc * 65536.0 + 0.5); }
-      a.cum[cls] = 65536u;
-      a.classes = cls;
-    }
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
   hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);

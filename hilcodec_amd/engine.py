@@ -46,6 +46,7 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
+    offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
     stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
 
@@ -183,10 +184,10 @@ def finalize_block(rb: "ResBlockSpec", streaming: bool = False) -> "ResBlockSpec
             and (narrow or (streaming and c in STREAM_WIDE_C))):
         rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
         rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
-    if streaming and rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or c in (512, 768)):
-        same = ops.resblock_chain_row_classes(c) == (8 if c >= 512 else (2 if c == 192 else 1))     # hilc_resblock_pack_weights' own split
-        rb.pw1_chain = rb.pw1_packed if same else ops.resblock_chain_pack(rb.pw1_wt)
-        rb.pw2_chain = rb.pw2_packed if same else ops.resblock_chain_pack(rb.pw2_wt)
+    if rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or (streaming and c in (512, 768))):
+        same = ops.resblock_chain_row_classes(c, streaming) == (8 if c >= 512 else (2 if c == 192 else 1))     # hilc_resblock_pack_weights' own split
+        rb.pw1_chain = rb.pw1_packed if same else ops.resblock_chain_pack(rb.pw1_wt, streaming)
+        rb.pw2_chain = rb.pw2_packed if same else ops.resblock_chain_pack(rb.pw2_wt, streaming)
     return rb
 
 
@@ -318,6 +319,11 @@ def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Se
             [caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(n)] if caches_out is not None else None)
         new_caches.extend(cs)
         return y
+    if (not streaming and not x3 and FUSE_RESBLOCK and opts.offline_chain_blocks and n >= 2
+            and all(rb.pw1_chain is not None and _fusable(rb, x) for rb in blocks)
+            and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0], streaming=False)):
+        return ops.resblock_chain(
+            x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks])
     for i, rb in enumerate(blocks):
         x = _resblock(rb, x, caches[ci + 2 * i: ci + 2 * i + 2] if streaming else None, new_caches,
                       caches_out[ci + 2 * i: ci + 2 * i + 2] if caches_out is not None else None, x3=x3, opts=opts)

@@ -458,21 +458,23 @@ def _resblock_chain(x, params, hist_in, hist_out, pre_scales, out_scales):
     from ._lib import ResblockParams
     B, Cc, T = x.shape
     n = len(pre_scales)
-    if len(params) != 6 * n or len(hist_in) != 2 * n or len(hist_out) != 2 * n or len(out_scales) != n:
-        raise RuntimeError("resblock_chain: 6 parameter tensors, 2 caches in and 2 caches out per block")
+    streaming = len(hist_in) > 0                   # no caches: the offline causal model (zero padding in front of every clip)
+    if len(params) != 6 * n or len(out_scales) != n or (streaming and (len(hist_in) != 2 * n or len(hist_out) != 2 * n)) or \
+            (not streaming and len(hist_out) != 0):
+        raise RuntimeError("resblock_chain: 6 parameter tensors per block, and (streaming) 2 caches in and 2 caches out per block")
     for h in list(hist_in) + list(hist_out):
         if tuple(h.shape) != (B, Cc, 4):
             raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h.shape)}")
     blocks = (ResblockParams * n)()
     for i in range(n):
         w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
-        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), _ptr(hist_in[2 * i]),
-                                   _ptr(hist_in[2 * i + 1]), _ptr(hist_out[2 * i]), _ptr(hist_out[2 * i + 1]),
+        h = [_ptr(t) for t in (hist_in[2 * i], hist_in[2 * i + 1], hist_out[2 * i], hist_out[2 * i + 1])] if streaming else [None] * 4
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
                                    float(pre_scales[i]), float(out_scales[i]))
     y = torch.empty_like(x)
     import ctypes
-    with _timed("resblock", 4.0 * n * B * T * Cc * Cc, f"C{Cc} T{T} stream chain x{n}"):
-        check(lib.hilc_resblock_chain(_ptr(x), _ptr(y), ctypes.cast(blocks, ctypes.c_void_p), n, 1, B, Cc, T, _stream()),
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc, f"C{Cc} T{T}" + (" stream" if streaming else "") + f" chain x{n}"):
+        check(lib.hilc_resblock_chain(_ptr(x), _ptr(y), ctypes.cast(blocks, ctypes.c_void_p), n, int(streaming), B, Cc, T, _stream()),
               "hilc_resblock_chain")
     return y
 
@@ -832,24 +834,30 @@ def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> b
     return C in (64, 96, 128, 192, 256, 384) or (C in (512, 768) and 32 % T == 0)
 
 
-def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1) -> bool:
-    """mirror of hilc_resblock_chain_supported (streaming form): the blocks of one stage in one launch"""
-    if nblk < 2 or nblk > (3 if C in (96, 192, 768) else 2) or T <= 0 or T % 4 != 0 or B * C * T * 4 >= (1 << 32):
+def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1, streaming: bool = True) -> bool:
+    """mirror of hilc_resblock_chain_supported: the blocks of one stage in one launch"""
+    if nblk < 2 or nblk > (3 if C in (96, 192, 768) else 2) or T <= 0 or T % 4 != 0:
+        return False
+    if not streaming:
+        return C in (64, 96, 128, 192)
+    if B * C * T * 4 >= (1 << 32):
         return False
     return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
 
 
-def resblock_chain_row_classes(C: int) -> int:
-    """mirror of hilc_resblock_chain_row_classes: the row split of the packed weights a chain launch reads"""
+def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
+    """mirror of hilc_resblock_chain_row_classes(_offline): the row split of the packed weights a chain launch reads"""
+    if not streaming:
+        return 2 if C in (128, 192) else 1
     return 8 if C >= 512 else (1 if C == 96 else 2)
 
 
-def resblock_chain_pack(wt: Tensor) -> Tensor:
+def resblock_chain_pack(wt: Tensor, streaming: bool = True) -> Tensor:
     """k-major `[C,C]` pointwise weights -> the packed layout of hilc_resblock_chain for this width"""
-    return _OPS.resblock_pack_rc(wt, resblock_chain_row_classes(wt.shape[0]))
+    return _OPS.resblock_pack_rc(wt, resblock_chain_row_classes(wt.shape[0], streaming))
 
 
-def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Sequence[Sequence[Tensor]],
+def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Optional[Sequence[Sequence[Tensor]]] = None,
                    hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None):
     """The residual blocks of ONE stage of a streaming hop in one launch (hilc_resblock_chain): `blocks[i]` =
     (w1p, dw1_w, dw1_b, w2p, dw2_w, dw2_b, pre_scale, out_scale) with w1p / w2p packed by `resblock_chain_pack`, `hist[i]` =
@@ -857,6 +865,12 @@ def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Sequence[Sequenc
     of block 1, ...]) — equal, bit for bit, to the blocks launched one by one."""
     B, Cc, _ = x.shape
     params, hin, hout, pre, post = [], [], [], [], []
+    if hist is None:            # offline: (w1p, ...) packed with resblock_chain_pack(w, streaming=False); returns y only
+        for blk in blocks:
+            params.extend(blk[:6])
+            pre.append(float(blk[6]))
+            post.append(float(blk[7]))
+        return _OPS.resblock_chain(x, params, [], [], pre, post)
     for i, blk in enumerate(blocks):
         params.extend(blk[:6])
         pre.append(float(blk[6]))

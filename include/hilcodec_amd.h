@@ -186,7 +186,7 @@ int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w,
  * launch instead of nblk (a streaming hop of 1024 streams is 5-10 tiles per workgroup and launch).
  * blocks[i]: that block's parameters; w1t / w2t PACKED by hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C))
  * (the chain's 8-wave shapes split the rows in two classes also below C = 192, so the layout differs from hilc_resblock's);
- * hist* as in hilc_resblock_stream (each optional).  streaming must be 1 (offline chains are not instantiated).
+ * hist* as in hilc_resblock_stream (each optional; ignored with streaming = 0: the offline causal model, hilc_resblock).
  * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0,
  * C in {512, 768} with whole streams tiling 32 columns; nblk = 2, or 3 at the decoder's widths (96, 192, 768).  Else
  * HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
@@ -197,7 +197,8 @@ typedef struct hilc_resblock_params {
   float pre_scale, out_scale;
 } hilc_resblock_params;
 int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming);
-int hilc_resblock_chain_row_classes(int C);
+int hilc_resblock_chain_row_classes(int C);           /* streaming form */
+int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming = 0: hilc_resblock semantics, C in {64, 96, 128, 192}) */
 int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
 int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
                         int B, int C, int T, void* stream);

@@ -447,12 +447,36 @@ def test_spec_block_branch_alone(env, n_fft, hop, B, T):
     assert torch.equal(alone + x, full)
 
 
+@pytest.mark.parametrize("C,T,B,n", [(64, 1000, 3, 2), (96, 24000, 2, 3), (128, 124, 5, 2), (192, 600, 2, 3), (96, 120, 70, 2), (64, 24000, 40, 2),
+                                      (192, 12000, 24, 3)])
+def test_resblock_chain_offline_equals_block_by_block(env, C, T, B, n):
+    """hilc_resblock_chain with streaming = 0: the blocks of a stage of the OFFLINE causal model in one launch (contiguous runs
+    with one carry per block; a run that starts inside a clip warms up on the tile in front) == hilc_resblock block by block."""
+    ops, fold, O, dev = env
+    assert ops.resblock_chain_supported(C, T, n, B, streaming=False)
+    blocks = []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        blocks.append(((ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2),
+                       (ops.resblock_chain_pack(w1, False), d1, b1, ops.resblock_chain_pack(w2, False), d2, b2),
+                       (1.0 + j / 3.0) ** -0.5, 0.4 + 0.1 * j))
+    x = rnd(C + T, B, C, T).to(dev)
+    y = ops.resblock_chain(x, [c + (pre, post) for _, c, pre, post in blocks])
+    y2 = x
+    for single, _, pre, post in blocks:
+        y2 = ops.resblock(y2, *single, pre, post)
+    assert torch.equal(y, y2), float((y - y2).abs().max())
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
     assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0
     assert lib.hilc_resblock_chain_supported(96, 320, 1, 1) == 0 and lib.hilc_resblock_chain_supported(96, 320, 4, 1) == 0
-    assert lib.hilc_resblock_chain_supported(96, 320, 3, 0) == 0 and lib.hilc_resblock_chain_supported(96, 322, 3, 1) == 0
+    assert lib.hilc_resblock_chain_supported(96, 320, 3, 0) == 1 and lib.hilc_resblock_chain_supported(96, 322, 3, 1) == 0
+    assert lib.hilc_resblock_chain_supported(768, 8, 3, 0) == 0 and lib.hilc_resblock_chain_supported(64, 320, 3, 0) == 0
     assert lib.hilc_resblock_chain_supported(64, 320, 3, 1) == 0 and lib.hilc_resblock_chain_supported(512, 8, 3, 1) == 0      # 2-block instantiations
     assert not ops.resblock_chain_supported(64, 320, 3, 2) and ops.resblock_chain_supported(64, 320, 2, 2)
     assert not ops.resblock_chain_supported(384, 40, 3, 8) and not ops.resblock_chain_supported(96, 320, 3, 40000)

@@ -16,7 +16,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--model", default="hil_speech")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
-ap.add_argument("--no-chain", action="store_true", help="streaming: one launch per residual block (round 3) instead of one per stage")
+ap.add_argument("--no-chain", action="store_true", help="one launch per residual block (round 3) instead of one per stage")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 mk = synth.model_kwargs(args.model)
@@ -24,6 +24,7 @@ model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
 model.load_state_dict(synth.synth_state_dict(args.model, 7), strict=False)
 for l in model.quantizer.layers:
     l.initted = True
+model.encoder.exec_options.offline_chain_blocks = model.decoder.exec_options.offline_chain_blocks = not args.no_chain
 x = synth.synth_clips(args.batch, 24000).to(dev)
 
 
