@@ -74,6 +74,8 @@ def parse():
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
     ap.add_argument("--no-offline-chain", action="store_true", help="offline mode, A/B: one launch per residual block (round 3) instead of "
                     "one per stage (hilc_resblock_chain, streaming = 0); same arithmetic, bit-identical outputs")
+    ap.add_argument("--no-stage", action="store_true", help="A/B: encoder stages as chain + separate down-sampling layer instead of one launch "
+                    "(hilc_encoder_stage); same arithmetic, bit-identical outputs")
     ap.add_argument("--no-chain", action="store_true", help="streaming mode, A/B: one launch per residual block (round 3) instead "
                     "of one launch per stage (hilc_resblock_chain); same arithmetic, bit-identical outputs")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
@@ -261,7 +263,7 @@ def parity_census(model, sd, nq, z, idx, wav, oracle_out):
 # ---------------------------------------------------------------------------------------------------------------------
 # workloads: each returns (step, audio_seconds_per_step, context)
 # ---------------------------------------------------------------------------------------------------------------------
-def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bool = True):
+def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bool = True, stage: bool = True):
     import hilcodec_amd
     from hilcodec_amd import synth
     mk = synth.model_kwargs(name)
@@ -271,6 +273,7 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bo
     for l in model.quantizer.layers:
         l.initted = True
     model.encoder.exec_options.offline_chain_blocks = model.decoder.exec_options.offline_chain_blocks = chain
+    model.encoder.exec_options.fuse_encoder_stage = stage
     x = synth.synth_clips(n_clips, T, seed=1234, first=first).to(dev)
     last = {}
 
@@ -284,7 +287,8 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bo
     return step, n_clips * T / 24000.0, {"model": model, "sd": sd, "mk": mk, "last": last}
 
 
-def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1, chain: bool = True):
+def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1, chain: bool = True,
+                       stage: bool = True):
     from hilcodec_amd import synth
     from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
     mk = synth.model_kwargs(name)
@@ -295,6 +299,7 @@ def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, 
     model.load_offline_state_dict(sd)
     model.remove_weight_reparameterizations()
     model.encoder.exec_options.stream_chain_blocks = model.decoder.exec_options.stream_chain_blocks = chain
+    model.encoder.exec_options.fuse_encoder_stage = stage
     hop = 320
     nbuf = 8                                           # distinct input hops, cycled
     xs = [synth.synth_clips(n_streams, hop, seed=4321 + 7 * j, first=first).to(dev) for j in range(nbuf)]
@@ -395,9 +400,9 @@ def main():
     lo, hi = D.shard_range(B * shard_world, shard_rank, shard_world)
 
     if args.mode == "offline":
-        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev, not args.no_offline_chain)
+        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev, not args.no_offline_chain, not args.no_stage)
     else:
-        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups, not args.no_chain)
+        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups, not args.no_chain, not args.no_stage)
         if args.graph:
             args.no_launch_timing = True
     model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]

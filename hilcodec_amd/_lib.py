@@ -46,6 +46,8 @@ SIGNATURES = {
     "hilc_resblock_chain_row_classes_offline": [_i],
     "hilc_resblock_pack_weights_rc": [_p, _p, _i, _i, _p],
     "hilc_resblock_chain": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hilc_encoder_stage_supported": [_i, _i, _i, _i, _i],
+    "hilc_encoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     "hilc_dw_conv": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_dw_convtr": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
@@ -68,7 +70,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def source_hash() -> str:
@@ -90,6 +92,12 @@ class ResblockParams(C.Structure):
     """`hilc_resblock_params` of include/hilcodec_amd.h: one residual block of a chain launch"""
     _fields_ = [("w1t", _p), ("dw1_w", _p), ("dw1_b", _p), ("w2t", _p), ("dw2_w", _p), ("dw2_b", _p),
                 ("hist1", _p), ("hist2", _p), ("hist1_out", _p), ("hist2_out", _p), ("pre_scale", _f), ("out_scale", _f)]
+
+
+class DownParams(C.Structure):
+    """`hilc_down_params` of include/hilcodec_amd.h: the down-sampling layer of an encoder stage launch"""
+    _fields_ = [("w_lo", _p), ("w_hi", _p), ("dw_w", _p), ("dw_b", _p), ("hist", _p), ("hist_out", _p), ("res", _p), ("y", _p),
+                ("in_scale", _f), ("stride", _i)]
 
 
 class HilcodecLibraryError(RuntimeError):

@@ -36,15 +36,8 @@ extern "C" int hilc_resblock_chain_row_classes(int C) {
   return C >= 512 ? 8 : (C == 96 ? 1 : (chain_width(C) ? 2 : 0));
 }
 
-extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
-                                   int B, int C, int T, void* stream) {
-  if (!x || !y || !blocks) return HILC_ERR_NULL;
-  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
-  if (!hilc_resblock_chain_supported(C, T, nblk, streaming)) return HILC_ERR_UNSUPPORTED;
-  if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
-  if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
-  ResArgs a;
-  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+namespace {
+int fill_blocks(ResArgs& a, const hilc_resblock_params* blocks, int nblk) {
   for (int i = 0; i < nblk; ++i) {
     const hilc_resblock_params& p = blocks[i];
     if (!p.w1t || !p.dw1_w || !p.dw1_b || !p.w2t || !p.dw2_w || !p.dw2_b) return HILC_ERR_NULL;
@@ -55,6 +48,21 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
     b.pre_scale = p.pre_scale; b.out_scale = p.out_scale;
   }
   for (int i = nblk; i < MAXBLK; ++i) a.blk[i] = a.blk[0];
+  return HILC_OK;
+}
+}  // namespace
+
+extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
+                                   int B, int C, int T, void* stream) {
+  if (!x || !y || !blocks) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_resblock_chain_supported(C, T, nblk, streaming)) return HILC_ERR_UNSUPPORTED;
+  if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
+  if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
+  ResArgs a;
+  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  a.dn = ResDown{};
+  if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (!streaming) {        // offline: the carry form's contiguous runs (hilc_resblock), the blocks of the stage back to back per tile
     switch (C) {
@@ -74,4 +82,37 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
     case 768: return launch_chain<768, true, 3, false>(a, B, s);
     default: return HILC_ERR_UNSUPPORTED;
   }
+}
+
+// ---- an ENCODER STAGE in one launch: its residual blocks and its down-sampling layer -------------------------------------------
+// seanet.py:316-339 (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C (no bias), depthwise conv k = 2r
+// stride r]); streaming.py:497-511.  == hilc_resblock_chain followed by hilc_dws_conv(_stream) with the same arguments, bit for bit.
+extern "C" int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
+  (void)streaming;
+  if (nblk < 1 || nblk > 2 || T <= 0 || T % 4 != 0) return 0;
+  return (C == 64 && stride == 2) || (C == 128 && stride == 4);
+}
+
+extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
+                                  int streaming, int B, int C, int T, void* stream) {
+  if (!x || !blocks || !down) return HILC_ERR_NULL;
+  if (!down->w_lo || !down->w_hi || !down->dw_w || !down->dw_b || !down->y) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_encoder_stage_supported(C, T, nblk, down->stride, streaming)) return HILC_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(down->y) & 15) ||
+      (reinterpret_cast<uintptr_t>(down->res) & 15) || (reinterpret_cast<uintptr_t>(down->hist) & 15) ||
+      (reinterpret_cast<uintptr_t>(down->hist_out) & 15))
+    return HILC_ERR_UNSUPPORTED;
+  if (down->hist && down->hist == down->hist_out) return HILC_ERR_UNSUPPORTED;
+  if (down->res == down->y) return HILC_ERR_UNSUPPORTED;
+  if (streaming && (long)B * 2 * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
+  ResArgs a;
+  a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
+  ResDown& d = a.dn;
+  d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = streaming ? down->hist : nullptr;
+  d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
+  hipStream_t s = (hipStream_t)stream;
+  if (streaming) return C == 64 ? launch_chain<64, true, 2, true, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
+  return C == 64 ? launch_chain<64, false, 2, false, 2>(a, B, s) : launch_chain<128, false, 2, true, 4>(a, B, s);
 }

@@ -84,9 +84,15 @@ constexpr bool wide_shape() {
 // block j + 1, only the last block stores; every block has its own carry slots, tap table, weights and (STREAM) caches.  Needs
 // the carry form (contiguous runs) or whole-stream tiles (NARROW, C >= 512).  W8_: 8 waves also below C = 192 (one workgroup
 // per CU: a streaming hop of 1024 streams is then 256 equal runs of 4 whole streams — no partly filled round).
-template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false>
+// DR_ > 0: the stage's DOWN-SAMPLING layer (seanet.py:330-339: [Scale, ELU, 1x1 conv C -> 2C, depthwise k = 2r stride r]) as the
+// last phase of the launch ("D"): the stage's output never reaches HBM — it goes from the last block's registers through ELU into
+// the LDS tile, two GEMMs (the two halves of the 2C output rows) and the strided depthwise conv, which reads the tile like P3 does
+// (previous 4 columns + own 4 columns per lane) with its own two carry slots.  DR_ = r in {2, 4}: the encoder's first two stages.
+template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0>
 struct Cfg {
   static constexpr int NB = NB_;
+  static constexpr int DR = DR_;
+  static_assert(DR_ == 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
@@ -97,7 +103,7 @@ struct Cfg {
   // there is no halo to recompute.
   static constexpr bool NARROW = STREAM && C >= 256;
   static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
+  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + (DR_ > 0 ? 8 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
   // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
@@ -150,12 +156,26 @@ struct ResBlk {       // one residual block's parameters
   float pre_scale, out_scale;
 };
 
+struct ResDown {      // the stage's down-sampling layer (DR > 0)
+  const float* w_lo;  // packed like a block's matrix: columns [0, C) of the k-major [C][2C] pointwise weight
+  const float* w_hi;  // columns [C, 2C)
+  const float* dw_w;  // [2C][2r]
+  const float* dw_b;  // [2C]
+  const float* hist;  // STREAM: [B][2C][r] last r pointwise outputs of the previous hop (NULL = zeros)
+  float* hist_out;
+  const float* res;   // optional [B][2C][T/r]: added to the output (the next stage's SpecBlock branch)
+  float* y;           // [B][2C][T/r]
+  float in_scale;
+};
+
 constexpr int MAXBLK = 3;
+constexpr int DDS = 12;   // per-row table of the down-sampling taps in LDS: [w_0..3 | w_4..7 | b, -, -, -]
 
 struct ResArgs {
   const float* x;
   ResBlk blk[MAXBLK];
   int nblk;
+  ResDown dn;
   long run_tiles;     // chain launches on the streaming column space: tiles per run (whole streams), 0 = equal split of the grid
   float* y;
   int T, tiles;
@@ -485,9 +505,9 @@ struct Cols {          // (no padding bytes: the struct is copied, and hipcc kee
 };
 static_assert(sizeof(Cols) == 32, "no padding");
 
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false, int NB = 1, bool W8 = false>
-__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, STREAM, X3, SCARRY, NB, W8>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, X3, SCARRY, NB, W8>;
+template <int C, bool STREAM, bool X3 = false, bool SCARRY = false, int NB = 1, bool W8 = false, int DR = 0>
+__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::NT), (Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>;
   using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
@@ -497,6 +517,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
   // block), which reload the one table at the start of every block (a workgroup walks 1-3 tiles there)
   constexpr bool DW_RELOAD = NB > 1 && K::NARROW;
   __shared__ __attribute__((aligned(16))) float DW[(DW_RELOAD ? 1 : NB) * C * DWS];
+  __shared__ __attribute__((aligned(16))) float DWD[DR > 0 ? 2 * C * DDS : 4];
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
   // do not pay one exposed global-load latency per row for the single lane that needs them
   __shared__ __attribute__((aligned(16))) float HS[(STREAM && !K::NARROW) ? 2 * C * 4 : 4];
@@ -529,6 +550,12 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
   };
   if constexpr (!DW_RELOAD) {
     for (int q = 0; q < nblk; ++q) load_taps(a.blk[q], DW + q * C * DWS);
+  }
+  if constexpr (DR > 0) {
+    for (int e = tid; e < 2 * C * DDS; e += NT) {
+      const int m = e / DDS, j = e - m * DDS;
+      DWD[e] = j < 2 * DR ? a.dn.dw_w[m * 2 * DR + j] : (j == 8 ? a.dn.dw_b[m] : 0.f);
+    }
   }
   if (tid < 4) Xbuf[tid] = 0.f;
   // element-wise phases: one half-wave = one row (row = 2*wave + (lane>>5) + 2*NW*i), lane = 4 adjacent
@@ -682,8 +709,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
       // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
       // it two barriers from here).  (STREAM: column group 0 of a stream's first tile is a head and takes the cache.)
       if (tile % a.tiles == 0) {
-        for (int e = tid; e < 2 * NB * C; e += NT)
-          *reinterpret_cast<f32x4*>(X + (e / (2 * NB)) * XS + K::NCOL + (e % (2 * NB)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NSLOT = 2 * NB + (DR > 0 ? 2 : 0);
+        for (int e = tid; e < NSLOT * C; e += NT)
+          *reinterpret_cast<f32x4*>(X + (e / NSLOT) * XS + K::NCOL + (e % NSLOT) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     if constexpr (!K::CARRYMODE) {
@@ -699,7 +727,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
 #pragma nounroll
     for (int blk = 0; blk < nblk; ++blk) {
     const ResBlk& bp = a.blk[NB == 1 ? 0 : blk];
-    const bool last_blk = NB == 1 || blk == nblk - 1;       // uniform
+    const bool final_blk = NB == 1 || blk == nblk - 1;      // uniform
+    const bool last_blk = DR == 0 && final_blk;             // the block whose output leaves the kernel (DR > 0: none, the D phase follows)
     Cols cn = cs;                                           // the next tile's columns: needed by the chain's last block only
     bool have_next = false;
     if constexpr (NB > 1) blk_off = 8 * blk;
@@ -840,7 +869,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
     have_next = next_tile < run1;
     if (last_blk) cn = columns_of(have_next ? next_tile : tile);
     if constexpr (!STREAM) {
-      if (last_blk) {
+      if (final_blk) {
       long nb;
       int nt0;
       if constexpr (STREAM) {   // the next tile's first clip only: a tile that straddles clips is touched in part
@@ -911,7 +940,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
           s = __fmul_rn(__fadd_rn(s, wc[i].w), bp.out_scale);
           o[e] = __fadd_rn(s, xr[i0 + i][e]);
         }
-        if constexpr (NB == 1) {
+        if constexpr (NB == 1 && DR == 0) {
           if (out_ok) *yrow(cs, m) = o;
         } else {
           if (last_blk) {
@@ -934,6 +963,132 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8>::NT), (Cfg<C, S
     lds_barrier();   // the next block's / tile's P0 overwrites X
     if (last_blk) cs = cn;
     }                // blocks of the chain
+    if constexpr (DR > 0) {
+      // ---- D: the stage's down-sampling layer on the tile the last block left in the x registers
+      const ResDown& dn = a.dn;
+      const bool have_next = next_tile < run1;
+      const Cols cn = columns_of(have_next ? next_tile : tile);
+      const float* wd0 = dn.w_lo + (long)wclass * (C * C / K::RH);
+      const float* wd1 = dn.w_hi + (long)wclass * (C * C / K::RH);
+      asm volatile("" : "+s"(wd0), "+s"(wd1));
+      Pipe wp;
+      wp.prefetch(wd0, lane);
+      {                                            // D0: ELU(in_scale * y) -> LDS (P0 on the stage's output)
+        lptr_t xp = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+        for (int i0 = 0; i0 < RW; i0 += RB) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+            *(lvec_t)(xp + i * RSTEP * XS) = prologue4v(zero_unless(cs.t_in, xr[i0 + i]), dn.in_scale, 1);
+          xp += RB * RSTEP * XS;
+          asm volatile("" : "+v"(xp));
+        }
+      }
+      if (have_next) {                             // the x registers are free (no shortcut here): the next tile's rows travel under both GEMMs
+#pragma unroll
+        for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
+      }
+      lds_barrier();
+      f32x16 acc0[CBW], acc1[CBW];
+      gemm_phase<K>(wd0, X, acc0, wp, colblk, lane);
+      wp.prefetch(wd1, lane);
+      gemm_phase<K>(wd1, X, acc1, wp, colblk, lane);
+      const bool out_ok = !warm && (STREAM ? cs.t_in : cs.t < T);
+      const int To = T / DR;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        lds_barrier();
+        acc_to_x<K>(h ? acc1 : acc0, X, rowblk0, colblk, lane);
+        lds_barrier();
+        // strided depthwise conv of the half's C rows: output (t / r) of row m reads columns [t - r, t + r) — the lane's own group and
+        // the one in front of it (left neighbour, the half's carry slot, or the stream's cache), like P3
+        lptr_t xpd = (lptr_t)(X + rsub * XS + c4);
+        lptr_t pbd = lane0 ? (lptr_t)(X + rsub * XS + K::NCOL + 8 * NB + 4 * h) : (lptr_t)(X + rsub * XS + c4 - 4);
+#pragma unroll
+        for (int i0 = 0; i0 < RW; i0 += RB) {
+          f32x4 cur[RB], prev[RB], wa[RB], wb[RB];
+          float bb[RB];
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int m = h * C + rsub + RSTEP * (i0 + i);
+            cur[i] = *(lvec_t)(xpd + i * RSTEP * XS);
+            prev[i] = *(lvec_t)(pbd + i * RSTEP * XS);
+            wa[i] = *reinterpret_cast<const f32x4*>(&DWD[m * DDS]);
+            if constexpr (DR == 4) wb[i] = *reinterpret_cast<const f32x4*>(&DWD[m * DDS + 4]);
+            bb[i] = DWD[m * DDS + 8];
+          }
+          if constexpr (STREAM) {
+            // a stream's first group: the r samples in front of t = 0 are its cache (zeros without one)
+            const unsigned hro = (unsigned)cs.b * (unsigned)(2 * C * DR) + (unsigned)(h * C + rsub + RSTEP * i0) * DR;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+              f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+              if (dn.hist != nullptr) {
+                const float* hp = dn.hist + (cs.t_in ? hro + (unsigned)(RSTEP * i * DR) : 0u);
+                if constexpr (DR == 4) hv = *reinterpret_cast<const f32x4*>(hp);
+                else { const f32x2 h2 = *reinterpret_cast<const f32x2*>(hp); hv = f32x4{0.f, 0.f, h2.x, h2.y}; }
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) prev[i][e] = cs.head ? hv[e] : prev[i][e];
+            }
+          }
+          if (lane_last) {                           // the half's last 4 columns: carry for the run's next tile
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *(lvec_t)(xpd + i * RSTEP * XS + 4 + 8 * NB + 4 * h) = cur[i];
+          }
+          if constexpr (STREAM) {
+            if (cs.tail && !warm && dn.hist_out != nullptr) {       // the stream's last r pointwise outputs: the next hop's cache
+              const unsigned hro = (unsigned)cs.b * (unsigned)(2 * C * DR) + (unsigned)(h * C + rsub + RSTEP * i0) * DR;
+#pragma unroll
+              for (int i = 0; i < RB; ++i) {
+                float* hp = dn.hist_out + hro + (unsigned)(RSTEP * i * DR);
+                if constexpr (DR == 4) *reinterpret_cast<f32x4*>(hp) = cur[i];
+                else *reinterpret_cast<f32x2*>(hp) = f32x2{cur[i].z, cur[i].w};
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int m = h * C + rsub + RSTEP * (i0 + i);
+            const long yo = ((long)cs.b * (2 * C) + m) * (long)To + (cs.t_in ? cs.t / DR : 0);
+            if constexpr (DR == 4) {
+              const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+              const float w[8] = {wa[i].x, wa[i].y, wa[i].z, wa[i].w, wb[i].x, wb[i].y, wb[i].z, wb[i].w};
+              float s0 = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s0 = fmaf(w[j], v[j], s0);
+              s0 = __fadd_rn(s0, bb[i]);
+              if (out_ok) dn.y[yo] = dn.res != nullptr ? __fadd_rn(s0, dn.res[yo]) : s0;
+            } else {
+              const float v[6] = {prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+              const float w[4] = {wa[i].x, wa[i].y, wa[i].z, wa[i].w};
+              f32x2 o2;
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s0 = fmaf(w[j], v[2 * e + j], s0);
+                o2[e] = __fadd_rn(s0, bb[i]);
+              }
+              if (out_ok) {
+                if (dn.res != nullptr) {
+                  const f32x2 r2 = *reinterpret_cast<const f32x2*>(dn.res + yo);
+                  o2[0] = __fadd_rn(o2[0], r2.x);
+                  o2[1] = __fadd_rn(o2[1], r2.y);
+                }
+                *reinterpret_cast<f32x2*>(dn.y + yo) = o2;
+              }
+            }
+          }
+          xpd += RB * RSTEP * XS;
+          pbd += RB * RSTEP * XS;
+          asm volatile("" : "+v"(xpd), "+v"(pbd));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      lds_barrier();   // the next tile's P0 overwrites X
+      cs = cn;
+    }
     tile = next_tile;
   }
   if (!K::CARRYMODE && K::NW == 4 && a.sched != nullptr && tid == 0) {   // last workgroup out re-arms the scheduler for the next launch
@@ -1007,10 +1162,10 @@ inline void set_div_magic(ResArgs& a) {
 // fill whole tiles; runs are made of as many units as it takes for all runs to be resident at once (1024 streams x 320 samples,
 // 256 workgroups: 4 streams = 10 tiles each), the last run may be short.  STREAM NARROW (C >= 512): whole-stream tiles, static
 // stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
-template <int C, bool STREAM, int NB, bool W8>
+template <int C, bool STREAM, int NB, bool W8, int DR = 0>
 int launch_chain(ResArgs a, int B, hipStream_t s) {
   constexpr bool NARROW = STREAM && C >= 256;
-  using K = Cfg<C, STREAM, false, STREAM && !NARROW, NB, W8>;
+  using K = Cfg<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>;
   a.B = B;
   set_div_magic(a);
   constexpr int TO = K::TO;
@@ -1020,7 +1175,7 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
   a.run_tiles = 0;
   static std::atomic<int> resident_cache[64];
   int n_cu = 0;
-  const long resident = resident_workgroups(resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8>, K::NT, resident_cache, n_cu);
+  const long resident = resident_workgroups(resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>, K::NT, resident_cache, n_cu);
   if (resident < 1) return HILC_ERR_LAUNCH;
   long blocks;
   if constexpr (STREAM && !NARROW) {
@@ -1036,7 +1191,7 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
     if constexpr (!STREAM) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

@@ -46,6 +46,7 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
+    fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
     stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
@@ -122,6 +123,8 @@ class EncStageSpec:
     down_dw_w: Tensor
     down_dw_b: Optional[Tensor]
     ratio: int
+    down_lo: Optional[Tensor] = None      # the two column halves of down_pw_wt packed for the one-launch stage (finalize_spec; C = 64 / 128)
+    down_hi: Optional[Tensor] = None
 
 
 @dataclass
@@ -202,6 +205,12 @@ def finalize_spec(spec, streaming: bool = False):
             sb.fused = ops.spec_block_tables(sb.basis_t, sb.wt, sb.n_fft)
         for rb in st.blocks:
             finalize_block(rb, streaming)
+        if (isinstance(st, EncStageSpec) and st.down_lo is None and st.down_pw_wt.device.type in ("cuda", "meta")
+                and st.down_pw_wt.shape[0] in (64, 128) and st.down_pw_wt.shape[1] == 2 * st.down_pw_wt.shape[0]
+                and all(rb.pw1_chain is not None for rb in st.blocks)):
+            c = st.down_pw_wt.shape[0]
+            st.down_lo = ops.resblock_chain_pack(st.down_pw_wt[:, :c].contiguous(), streaming)
+            st.down_hi = ops.resblock_chain_pack(st.down_pw_wt[:, c:].contiguous(), streaming)
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
     return spec
@@ -471,9 +480,30 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
     for si, st in enumerate(es.stages):
         if not (fuse_pre and si == 0) and not (defer and si > 0):
             x = _spec_block(st.spec, x, wav, wav_hist)
+        nxt = later[si] if defer else None
+        nb = len(st.blocks)
+        if (FUSE_RESBLOCK and opts.fuse_encoder_stage and st.down_lo is not None and st.down_dw_b is not None
+                and st.down_dw_w.shape[1] == 2 * st.ratio and x.shape[2] % st.ratio == 0 and (not streaming or FUSE_STREAM)
+                and (opts.stream_chain_blocks if streaming else opts.offline_chain_blocks)
+                and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+                        and rb.dw2_b is not None for rb in st.blocks)
+                and ops.encoder_stage_supported(x.shape[1], x.shape[2], nb, st.ratio, x.shape[0], streaming)):
+            # the whole stage — its residual blocks and its down-sampling layer — is one launch; the stage's output never reaches HBM
+            blocks = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks]
+            down = (st.down_lo, st.down_hi, st.down_dw_w, st.down_dw_b, st.down_in_scale, st.ratio)
+            if streaming:
+                x, cs_, c = ops.encoder_stage(
+                    x, blocks, down, hist=[caches[ci + 2 * i: ci + 2 * i + 2] for i in range(nb)],
+                    hist_out=[caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(nb)] if caches_out is not None else None,
+                    down_hist=caches[ci + 2 * nb], down_hist_out=out(ci + 2 * nb), res=branch_of(nxt) if defer else None)
+                new_caches.extend(cs_)
+                new_caches.append(c)
+            else:
+                x = ops.encoder_stage(x, blocks, down)
+            ci += 2 * nb + 1
+            continue
         x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, False, opts)
         ci += 2 * len(st.blocks)
-        nxt = later[si] if defer else None
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
             x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci], res=branch_of(nxt) if defer else None,
                                        stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))

@@ -484,6 +484,44 @@ _register("resblock_chain", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tenso
           lambda x, params, hist_in, hist_out, pre_scales, out_scales: torch.empty_like(x))
 
 
+def _encoder_stage(x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale,
+                   stride):
+    import ctypes
+    from ._lib import DownParams, ResblockParams
+    B, Cc, T = x.shape
+    n = len(pre_scales)
+    streaming = dhist_out is not None
+    if len(params) != 6 * n or len(out_scales) != n or len(hist_in) != (2 * n if streaming else 0) or len(hist_out) != len(hist_in):
+        raise RuntimeError("encoder_stage: 6 parameter tensors per block, and (streaming) 2 caches in and 2 caches out per block")
+    if T % stride != 0:
+        raise RuntimeError("encoder_stage: T must be a multiple of the stride")
+    blocks = (ResblockParams * n)()
+    for i in range(n):
+        w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
+        h = [_ptr(t) for t in (hist_in[2 * i], hist_in[2 * i + 1], hist_out[2 * i], hist_out[2 * i + 1])] if streaming else [None] * 4
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
+                                   float(pre_scales[i]), float(out_scales[i]))
+    To = T // stride
+    for t, shape in ((dhist, (B, 2 * Cc, stride)), (dhist_out, (B, 2 * Cc, stride)), (dres, (B, 2 * Cc, To))):
+        if t is not None and tuple(t.shape) != shape:
+            raise RuntimeError(f"encoder_stage: expected {shape}, got {tuple(t.shape)}")
+    y = torch.empty(B, 2 * Cc, To, device=x.device, dtype=torch.float32)
+    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y),
+                      float(in_scale), int(stride))
+    tag = f"C{Cc} T{T}" + (" stream" if streaming else "")
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, tag + f" stage x{n} + down s{stride}"):
+        check(lib.hilc_encoder_stage(_ptr(x), ctypes.cast(blocks, ctypes.c_void_p), n, ctypes.cast(ctypes.pointer(down), ctypes.c_void_p),
+                                     int(streaming), B, Cc, T, _stream()), "hilc_encoder_stage")
+    return y
+
+
+_register("encoder_stage", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tensor(a!)[] hist_out, float[] pre_scales, float[] out_scales, "
+          "Tensor w_lo, Tensor w_hi, Tensor ddw_w, Tensor ddw_b, Tensor? dhist, Tensor(b!)? dhist_out, Tensor? dres, float in_scale, "
+          "int stride) -> Tensor", _encoder_stage,
+          lambda x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale, stride:
+          x.new_empty(x.shape[0], 2 * x.shape[1], x.shape[2] // stride))
+
+
 def _resblock_pack_rc(wt, row_classes):
     Cc = wt.shape[0]
     out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
@@ -880,6 +918,39 @@ def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Optional[Sequenc
         hout.extend([_state_out(given[0], x, B, Cc, 4), _state_out(given[1], x, B, Cc, 4)])
     y = _OPS.resblock_chain(x, params, hin, hout, pre, post)
     return y, hout
+
+
+def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:
+    """mirror of hilc_encoder_stage_supported (+ the 32-bit offsets of the streaming form)"""
+    if nblk < 1 or nblk > 2 or T <= 0 or T % 4 != 0 or (streaming and B * 2 * C * T * 4 >= (1 << 32)):
+        return False
+    return (C == 64 and stride == 2) or (C == 128 and stride == 4)
+
+
+def encoder_stage(x: Tensor, blocks: Sequence[Sequence], down: Sequence, hist: Optional[Sequence[Sequence[Tensor]]] = None,
+                  hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None, down_hist: Optional[Tensor] = None,
+                  down_hist_out: Optional[Tensor] = None, res: Optional[Tensor] = None):
+    """An encoder stage in ONE launch (hilc_encoder_stage): its residual blocks (`blocks[i]` as in `resblock_chain`) and its
+    down-sampling layer `down` = (w_lo, w_hi, dw_w `[2C,2r]`, dw_b `[2C]`, in_scale, stride) — w_lo / w_hi = the two column halves
+    of the k-major `[C,2C]` pointwise weight, packed with `resblock_chain_pack`.  Offline (hist None): -> y `[B,2C,T/r]`.
+    Streaming: hist / hist_out per block as in `resblock_chain`, `down_hist` `[B,2C,r]` -> (y, [block caches...], down cache).
+    `res` `[B,2C,T/r]` is added to the output (the next stage's SpecBlock branch)."""
+    B, Cc, _ = x.shape
+    w_lo, w_hi, ddw_w, ddw_b, in_scale, stride = down
+    params, hin, hout, pre, post = [], [], [], [], []
+    for i, blk in enumerate(blocks):
+        params.extend(blk[:6])
+        pre.append(float(blk[6]))
+        post.append(float(blk[7]))
+        if hist is not None:
+            hin.extend(hist[i])
+            given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
+            hout.extend([_state_out(given[0], x, B, Cc, 4), _state_out(given[1], x, B, Cc, 4)])
+    if hist is None:
+        return _OPS.encoder_stage(x, params, [], [], pre, post, w_lo, w_hi, ddw_w, ddw_b, None, None, res, float(in_scale), int(stride))
+    dout = _state_out(down_hist_out, x, B, 2 * Cc, int(stride))
+    y = _OPS.encoder_stage(x, params, hin, hout, pre, post, w_lo, w_hi, ddw_w, ddw_b, down_hist, dout, res, float(in_scale), int(stride))
+    return y, hout, dout
 
 
 def resblock_pack(wt: Tensor) -> Tensor:

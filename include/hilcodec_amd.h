@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 10   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain */
+#define HILC_ABI_VERSION 11   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -202,6 +202,22 @@ int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming
 int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
 int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
                         int B, int C, int T, void* stream);
+
+/* ---- an ENCODER STAGE in one launch (ABI 11): its residual blocks and its down-sampling layer ------------------------------
+ * `seanet.py:316-339` (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C without bias, depthwise conv
+ * k = 2r stride r with bias]); streaming `streaming.py:497-511` with the layer's cache `[B][2C][r]`.  Equals hilc_resblock_chain
+ * followed by hilc_dws_conv / hilc_dws_conv_stream (stride r, in_scale, in_elu = 1, `res`) bit for bit; the stage's output
+ * `[B][C][T]` never reaches HBM.  w_lo / w_hi: columns [0, C) / [C, 2C) of the k-major `[C][2C]` pointwise weight, each packed
+ * like a block's matrix (hilc_resblock_pack_weights_rc with the row classes of the chain form in use).  res (optional): added to
+ * the output, e.g. the next stage's SpecBlock branch.  Stages: C = 64 with r = 2, C = 128 with r = 4; nblk 1..2; T % 4 == 0. */
+typedef struct hilc_down_params {
+  const float* w_lo; const float* w_hi; const float* dw_w; const float* dw_b;
+  const float* hist; float* hist_out; const float* res; float* y;
+  float in_scale; int stride;
+} hilc_down_params;
+int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming);
+int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down, int streaming,
+                       int B, int C, int T, void* stream);
 
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)

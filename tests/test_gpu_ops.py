@@ -470,6 +470,70 @@ def test_resblock_chain_offline_equals_block_by_block(env, C, T, B, n):
     assert torch.equal(y, y2), float((y - y2).abs().max())
 
 
+def _stage_params(ops, dev, C, r, n, streaming):
+    blocks, singles = [], []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        pre, post = (1.0 + j / 3.0) ** -0.5, 0.4 + 0.1 * j
+        singles.append(((ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2), pre, post))
+        blocks.append((ops.resblock_chain_pack(w1, streaming), d1, b1, ops.resblock_chain_pack(w2, streaming), d2, b2, pre, post))
+    wd = (rnd(91, C, 2 * C) / C ** 0.5).to(dev)                       # k-major [C][2C]
+    dw, db = (rnd(92, 2 * C, 2 * r) * 0.4).to(dev), (rnd(93, 2 * C) * 0.2).to(dev)
+    down = (ops.resblock_chain_pack(wd[:, :C].contiguous(), streaming), ops.resblock_chain_pack(wd[:, C:].contiguous(), streaming),
+            dw, db, 0.7746, r)
+    return blocks, singles, wd, dw, db, down
+
+
+@pytest.mark.parametrize("C,r,T,B,n", [(64, 2, 1000, 3, 2), (128, 4, 12000, 2, 2), (64, 2, 24000, 24, 2), (128, 4, 124, 9, 2), (128, 4, 600, 40, 1),
+                                        (64, 2, 8, 5, 2)])
+def test_encoder_stage_offline_equals_blocks_then_down(env, C, r, T, B, n):
+    """hilc_encoder_stage, offline: the stage's residual blocks and its down-sampling layer (`seanet.py:316-339`) in ONE launch ==
+    hilc_resblock per block followed by hilc_dws_conv (stride r), bit for bit — with and without `res`."""
+    ops, fold, O, dev = env
+    assert ops.encoder_stage_supported(C, T, n, r, B, streaming=False)
+    blocks, singles, wd, dw, db, down = _stage_params(ops, dev, C, r, n, False)
+    x = rnd(C + T, B, C, T).to(dev)
+    res = rnd(5, B, 2 * C, T // r).to(dev)
+    y2 = x
+    for single, pre, post in singles:
+        y2 = ops.resblock(y2, *single, pre, post)
+    ref = ops.dws_conv(y2, wd, dw, db, stride=r, in_scale=0.7746, in_elu=True)
+    y = ops.encoder_stage(x, blocks, down)
+    assert torch.equal(y, ref), float((y - ref).abs().max())
+    yr = ops.encoder_stage(x, blocks, down, res=res)
+    assert torch.equal(yr, ref + res)
+
+
+@pytest.mark.parametrize("C,r,T,B,n", [(64, 2, 320, 5, 2), (128, 4, 160, 7, 2), (64, 2, 320, 1024, 2), (128, 4, 160, 1024, 2), (64, 2, 640, 3, 2),
+                                        (128, 4, 8, 21, 2), (64, 2, 12, 70, 1)])
+def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
+    """hilc_encoder_stage, streaming hop (`streaming.py:497-511`): == the blocks one by one (hilc_resblock_stream) followed by
+    hilc_dws_conv_stream with the layer's cache: output, the 2n block caches and the down-sampling cache, bit for bit over three
+    hops; `res` = the next stage's SpecBlock branch added by the epilogue."""
+    ops, fold, O, dev = env
+    assert ops.encoder_stage_supported(C, T, n, r, B)
+    blocks, singles, wd, dw, db, down = _stage_params(ops, dev, C, r, n, True)
+    ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
+    cb = [[c.clone() for c in pair] for pair in ca]
+    da = (rnd(30, B, 2 * C, r) * 0.6).to(dev)
+    db_ = da.clone()
+    for h in range(3):
+        x = rnd(C + T + h, B, C, T).to(dev)
+        res = rnd(40 + h, B, 2 * C, T // r).to(dev) if h != 1 else None
+        y, flat, da = ops.encoder_stage(x, blocks, down, hist=ca, down_hist=da, res=res)
+        ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+        y2 = x
+        for j, (single, pre, post) in enumerate(singles):
+            y2, cb[j] = ops.resblock(y2, *single, pre, post, hist=cb[j])
+        ref, db_ = ops.dws_conv_stream(y2, wd, dw, db, db_, res=res, stride=r, in_scale=0.7746, in_elu=True)
+        assert torch.equal(y, ref), (h, float((y - ref).abs().max()))
+        assert torch.equal(da, db_), h
+        for j in range(n):
+            assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
