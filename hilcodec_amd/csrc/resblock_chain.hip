@@ -30,10 +30,10 @@ extern "C" int hilc_resblock_chain_row_classes_offline(int C) {
 }
 
 extern "C" int hilc_resblock_chain_row_classes(int C) {
-  static_assert(Cfg<64, true, false, true, 2, true>::RH == 2 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
+  static_assert(Cfg<64, true, false, true, 2, false>::RH == 1 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
                 Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
                 Cfg<512, true, false, false, 2, false>::RH == 8 && Cfg<768, true, false, false, 3, false>::RH == 8, "packed layout");
-  return C >= 512 ? 8 : (C == 96 ? 1 : (chain_width(C) ? 2 : 0));
+  return C >= 512 ? 8 : ((C == 96 || C == 64) ? 1 : (chain_width(C) ? 2 : 0));
 }
 
 namespace {
@@ -74,7 +74,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
     }
   }
   switch (C) {
-    case 64: return launch_chain<64, true, 2, true>(a, B, s);          // the encoder's stages hold 2 blocks; 3 fit the same kernel's loop
+    case 64: return launch_chain<64, true, 2, false>(a, B, s);         // four waves, two workgroups per CU (eight waves: 62 instead of 68 TF)
     case 96: return launch_chain<96, true, 3, false>(a, B, s);         // 3 row blocks do not split in two classes: 4 waves, two workgroups per CU
     case 128: return launch_chain<128, true, 2, true>(a, B, s);
     case 192: return launch_chain<192, true, 3, false>(a, B, s);
@@ -113,6 +113,6 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = streaming ? down->hist : nullptr;
   d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
   hipStream_t s = (hipStream_t)stream;
-  if (streaming) return C == 64 ? launch_chain<64, true, 2, true, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
+  if (streaming) return C == 64 ? launch_chain<64, true, 2, false, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
   return C == 64 ? launch_chain<64, false, 2, false, 2>(a, B, s) : launch_chain<128, false, 2, true, 4>(a, B, s);
 }

@@ -887,7 +887,7 @@ def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
     """mirror of hilc_resblock_chain_row_classes(_offline): the row split of the packed weights a chain launch reads"""
     if not streaming:
         return 2 if C in (128, 192) else 1
-    return 8 if C >= 512 else (1 if C == 96 else 2)
+    return 8 if C >= 512 else (1 if C in (64, 96) else 2)
 
 
 def resblock_chain_pack(wt: Tensor, streaming: bool = True) -> Tensor:
