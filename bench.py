@@ -74,6 +74,8 @@ def parse():
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
     ap.add_argument("--no-offline-chain", action="store_true", help="offline mode, A/B: one launch per residual block (round 3) instead of "
                     "one per stage (hilc_resblock_chain, streaming = 0); same arithmetic, bit-identical outputs")
+    ap.add_argument("--exec-opt", action="append", default=[], metavar="NAME=0|1", help="A/B: set a boolean field of engine.ExecOptions on the "
+                    "encoder and the decoder (e.g. stream_batch_tails=0, stream_defer_spec=0); all of them change launches, never results")
     ap.add_argument("--no-stage", action="store_true", help="A/B: encoder stages as chain + separate down-sampling layer instead of one launch "
                     "(hilc_encoder_stage); same arithmetic, bit-identical outputs")
     ap.add_argument("--no-chain", action="store_true", help="streaming mode, A/B: one launch per residual block (round 3) instead "
@@ -407,6 +409,14 @@ def main():
             args.no_launch_timing = True
     model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]
     nq = mk["vq_kwargs"]["num_quantizers"]
+    if args.exec_opt:
+        for item in args.exec_opt:
+            key, val = item.split("=")
+            for half in (model.encoder, model.decoder):
+                assert isinstance(getattr(half.exec_options, key), bool), key
+                setattr(half.exec_options, key, bool(int(val)))
+        if args.mode == "streaming" and args.graph:
+            ctx["hopper"] = ctx["make_hopper"]()                 # captured with the defaults: capture again
 
     numerics = None
     if args.decoder_gemm != "fp32":

@@ -55,6 +55,7 @@ SIGNATURES = {
     "hilc_conv_post": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_stft_logmag": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     "hilc_tail": [_p, _p, _p, C.c_long, _i, _i, _i, _p],
+    "hilc_tail_multi": [_p, _i, _p],
     "hilc_spec_block_supported": [_i, _i, _i, _i],
     "hilc_spec_block_packed_floats": [_i, _i],
     "hilc_spec_block_pack": [_p, _p, _i, _i, _i, _p],
@@ -70,7 +71,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def source_hash() -> str:
@@ -92,6 +93,12 @@ class ResblockParams(C.Structure):
     """`hilc_resblock_params` of include/hilcodec_amd.h: one residual block of a chain launch"""
     _fields_ = [("w1t", _p), ("dw1_w", _p), ("dw1_b", _p), ("w2t", _p), ("dw2_w", _p), ("dw2_b", _p),
                 ("hist1", _p), ("hist2", _p), ("hist1_out", _p), ("hist2_out", _p), ("pre_scale", _f), ("out_scale", _f)]
+
+
+class TailDesc(C.Structure):
+    """`hilc_tail_desc` of include/hilcodec_amd.h: one cache update of a hilc_tail_multi launch"""
+    _fields_ = [("x", _p), ("hist", _p), ("out", _p), ("rows", C.c_long), ("T", _i), ("pad", _i), ("hist_len", _i),
+                ("in_scale", _f), ("in_elu", _i)]
 
 
 class DownParams(C.Structure):

@@ -266,6 +266,54 @@ __global__ __launch_bounds__(64) void l2norm_kernel(const float* x, float* y, in
   }
 }
 
+// Several cache updates in ONE launch (a streaming hop: the four up-sampling layers' caches and conv_post's, each 6-13 us as a
+// launch of its own at 1024 streams — latency, not work): block -> descriptor by prefix sums of the blocks each needs.
+struct TailMulti {
+  int n;
+  hilc_tail_desc d[HILC_TAIL_MAX];
+  unsigned first_block[HILC_TAIL_MAX + 1];
+};
+
+__global__ __launch_bounds__(256) void tail_multi_kernel(TailMulti m) {
+  int q = 0;
+  while (q + 1 < m.n && blockIdx.x >= m.first_block[q + 1]) ++q;       // uniform
+  const hilc_tail_desc& d = m.d[q];
+  const long g = (long)(blockIdx.x - m.first_block[q]) * 256 + threadIdx.x;
+  if (g >= d.rows * d.pad) return;
+  const long row = g / d.pad;
+  const int i = (int)(g - row * d.pad);
+  const int t = d.T - d.pad + i;
+  float v;
+  if (t >= 0) v = prologue(d.x[row * (long)d.T + t], d.in_scale, d.in_elu);
+  else v = d.hist ? d.hist[row * (long)d.hist_len + d.hist_len + t] : 0.f;
+  d.out[row * (long)d.pad + i] = v;
+}
+
+extern "C" int hilc_tail_multi(const hilc_tail_desc* descs, int n, void* stream) {
+  if (!descs) return HILC_ERR_NULL;
+  if (n < 1 || n > HILC_TAIL_MAX) return HILC_ERR_SHAPE;
+  TailMulti m;
+  m.n = n;
+  unsigned blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const hilc_tail_desc& d = descs[i];
+    if (!d.x || !d.out) return HILC_ERR_NULL;
+    if (d.rows <= 0 || d.T <= 0 || d.pad <= 0) return HILC_ERR_SHAPE;
+    if (d.hist != nullptr && d.hist_len < d.pad - d.T) return HILC_ERR_SHAPE;      // (no history: zeros in front of t = 0)
+    if (d.out == d.hist || d.out == d.x) return HILC_ERR_UNSUPPORTED;
+    const long nb = (d.rows * d.pad + 255) / 256;
+    if (nb + blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
+    m.d[i] = d;
+    m.first_block[i] = blocks;
+    blocks += (unsigned)nb;
+  }
+  m.first_block[n] = blocks;
+  HILC_CLEAR_ERROR();
+  hipLaunchKernelGGL(tail_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
+  HILC_CHECK_LAUNCH();
+  return HILC_OK;
+}
+
 int launch_hist_out(const float* x, const float* hist, float* hist_out, long rows, int T, int pad, int hist_len,
                     float in_scale, int in_elu, hipStream_t s) {
   if (pad <= 0) return HILC_OK;

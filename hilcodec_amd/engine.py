@@ -48,6 +48,7 @@ class ExecOptions:
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
+    stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
     stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
     stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
 
@@ -446,9 +447,14 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
 
     wav_hist = None
     ci = 0
+    # the cache updates that are a launch of their own (waveform tail, conv_post's depthwise cache) go out as ONE launch at the end
+    tails = ops.DeferredTails() if streaming and opts.stream_batch_tails and not torch.compiler.is_compiling() else None
     if streaming:
         wav_hist = caches[0]
-        new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
+        if tails is not None:
+            new_caches.append(tails.add(wav, wav_hist, es.wav_cache_len, 1.0, False, out=out(0)))
+        else:
+            new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
         ci = 1
     sb0 = es.stages[0].spec
     fuse_pre = (FUSE_SPECBLOCK and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
@@ -522,7 +528,10 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         ci += 1
     if not defer:
         x = _spec_block(es.spec_post, x, wav, wav_hist)
-    if streaming:
+    if streaming and tails is not None:
+        h = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci])
+        new_caches.append(tails.add(x, caches[ci], es.post_dw_w.shape[1] - 1, 1.0, True, out=out(ci)))
+    elif streaming:
         h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)
     else:
@@ -532,6 +541,8 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         z = ops.l2norm(h, eps=1e-12, scale=float(es.dim) ** 0.5, channel_last_out=channel_last_out)
     else:
         z = h.transpose(1, 2).contiguous() if channel_last_out else h
+    if tails is not None:
+        tails.flush()
     return (z, new_caches) if streaming else z
 
 
@@ -556,6 +567,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     if opts.decoder_gemm != "fp32" and torch.compiler.is_compiling():
         raise RuntimeError("decoder_gemm = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
     x3 = opts.decoder_gemm == "bf16x3"
+    tails = ops.DeferredTails() if streaming and opts.stream_batch_tails and not x3 and not torch.compiler.is_compiling() else None
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
@@ -577,6 +589,10 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
                                   hist=caches[ci], want_hist=True, hist_out=out(ci))
             new_caches.append(c)
+        elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0 and tails is not None:
+            # (the transposed conv's new cache = its last ACTIVATED input frame: with the other stages' and conv_post's in one launch)
+            new_caches.append(tails.add(x, None, 1, st.in_scale, True, out=out(ci)))
+            x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True, hist=caches[ci], taps=st.taps)
         elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
             x, c = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True,
                                hist=caches[ci], want_hist=True, taps=st.taps, hist_out=out(ci))
@@ -597,6 +613,12 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         ci += 1
         x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, x3, opts)
         ci += 2 * len(st.blocks)
+    if streaming and tails is not None:
+        wav = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True, out_scale=ds.post_out_scale,
+                            do_tanh=ds.tanh, hist=caches[ci])
+        new_caches.append(tails.add(x, caches[ci], ds.post_w.shape[1] - 1, ds.post_in_scale, True, out=out(ci)))
+        tails.flush()
+        return wav, new_caches
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
                                out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True,

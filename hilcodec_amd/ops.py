@@ -679,6 +679,28 @@ def _tail(x, hist, out):
 _register("tail", "(Tensor x, Tensor? hist, Tensor(a!) out) -> ()", _tail, lambda x, hist, out: None)
 
 
+def _tail_multi(xs, hists, outs, in_scales, in_elus):
+    import ctypes
+    from ._lib import TailDesc
+    n = len(xs)
+    if not (len(hists) == len(outs) == len(in_scales) == len(in_elus) == n) or n < 1:
+        raise RuntimeError("tail_multi: one (x, hist, out, in_scale, in_elu) per cache")
+    descs = (TailDesc * n)()
+    for i in range(n):
+        x, out = xs[i], outs[i]
+        hist = hists[i] if hists[i].numel() > 0 else None           # (an empty tensor stands for "no history": Tensor?[] is not a schema type)
+        B, Cc, T = x.shape
+        if tuple(out.shape[:2]) != (B, Cc) or (hist is not None and tuple(hist.shape[:2]) != (B, Cc)):
+            raise RuntimeError("tail_multi: x, hist and out must agree in [B, C]")
+        descs[i] = TailDesc(_ptr(x), _ptr(hist), _ptr(out), B * Cc, T, out.shape[-1], hist.shape[-1] if hist is not None else 0,
+                            float(in_scales[i]), int(in_elus[i]))
+    check(lib.hilc_tail_multi(ctypes.cast(descs, ctypes.c_void_p), n, _stream()), "hilc_tail_multi")
+
+
+_register("tail_multi", "(Tensor[] xs, Tensor[] hists, Tensor(a!)[] outs, float[] in_scales, bool[] in_elus) -> ()", _tail_multi,
+          lambda xs, hists, outs, in_scales, in_elus: None)
+
+
 def _l2norm(x, eps, scale, channel_last_out):
     B, Cc, T = x.shape
     y = _new(x, *((B, T, Cc) if channel_last_out else (B, Cc, T)))
@@ -1067,6 +1089,25 @@ def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = No
     out = _state_out(out, x, x.shape[0], x.shape[1], pad)
     _OPS.tail(x, hist, out)
     return out
+
+
+class DeferredTails:
+    """Cache updates of a streaming hop collected and issued as ONE launch (hilc_tail_multi): `add` = what the op's own
+    `hist_out` would have written — the last `pad` samples of [hist | pro(x)] — `flush` launches them (at most 8 per launch)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, x: Tensor, hist: Optional[Tensor], pad: int, in_scale: float, in_elu: bool, out: Optional[Tensor] = None) -> Tensor:
+        out = _state_out(out, x, x.shape[0], x.shape[1], pad)
+        self.items.append((x, hist if hist is not None else x.new_empty(0), out, float(in_scale), bool(in_elu)))
+        return out
+
+    def flush(self) -> None:
+        for i in range(0, len(self.items), 8):
+            part = self.items[i:i + 8]
+            _OPS.tail_multi([p[0] for p in part], [p[1] for p in part], [p[2] for p in part], [p[3] for p in part], [p[4] for p in part])
+        self.items = []
 
 
 def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: bool = False) -> Tensor:

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 11   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage */
+#define HILC_ABI_VERSION 12   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: hilc_tail_multi */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -202,6 +202,22 @@ int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming
 int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
 int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
                         int B, int C, int T, void* stream);
+
+/* ---- several cache updates in one launch (ABI 12) ----------------------------------------------------------------------
+ * out[row][i] = last `pad` samples of [hist | pro(x)] per row (pro = in_scale, then ELU if in_elu) — what hilc_tail,
+ * hilc_up_conv_stream (its `hist_out`: the transposed conv's cache = the last ACTIVATED input frame, `causal_layers.py:168-188`)
+ * and hilc_conv_post (`hist_out`) each do in a launch of their own; a streaming decoder hop has five of them.  Same values. */
+#define HILC_TAIL_MAX 8
+typedef struct hilc_tail_desc {
+  const float* x;      /* [rows][T] */
+  const float* hist;   /* [rows][hist_len] or NULL (zeros) */
+  float* out;          /* [rows][pad] */
+  long rows;
+  int T, pad, hist_len;
+  float in_scale;
+  int in_elu;
+} hilc_tail_desc;
+int hilc_tail_multi(const hilc_tail_desc* descs, int n, void* stream);
 
 /* ---- an ENCODER STAGE in one launch (ABI 11): its residual blocks and its down-sampling layer ------------------------------
  * `seanet.py:316-339` (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C without bias, depthwise conv

@@ -228,6 +228,38 @@ def test_tail(env):
     assert torch.equal(ops.tail(x.to(dev), None, 9).cpu(), torch.cat([torch.zeros(2, 3, 2), x], 2))
 
 
+def test_tail_multi_equals_the_ops_own_cache_updates(env):
+    """hilc_tail_multi: the cache updates of a decoder hop (four up-sampling layers: last ACTIVATED input frame; conv_post: last 4
+    activated samples) and of the encoder (waveform tail, no activation) in one launch == each op's own `hist_out`."""
+    ops, fold, O, dev = env
+    B = 37
+    t = ops.DeferredTails()
+    want = []
+    for i, (K, Tin, r) in enumerate(((1536, 1, 8), (768, 8, 5), (384, 40, 4), (192, 160, 2))):
+        x = rnd(10 + i, B, K, Tin).to(dev)
+        tw, wt, b = (rnd(20 + i, K, 2 * r) * 0.3).to(dev), (rnd(30 + i, K, K // 2) / K ** 0.5).to(dev), (rnd(40 + i, K // 2) * 0.1).to(dev)
+        cache = (rnd(50 + i, B, K, 1) * 0.5).to(dev)
+        y, c = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=cache, want_hist=True)
+        y2 = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=cache)
+        assert torch.equal(y, y2)
+        want.append((c, t.add(x, None, 1, 0.7071, True)))
+    x = rnd(60, B, 96, 320).to(dev)
+    w, b = (rnd(61, 96, 5) * 0.2).to(dev), (rnd(62, 1) * 0.1).to(dev)
+    cache = (rnd(63, B, 96, 4) * 0.5).to(dev)
+    y, c = ops.conv_post(x, w, b, in_scale=0.7071, in_elu=True, out_scale=0.1122, do_tanh=True, hist=cache, want_hist=True)
+    want.append((c, t.add(x, cache, 4, 0.7071, True)))
+    wav, wh = rnd(70, B, 1, 320).to(dev), rnd(71, B, 1, 1023).to(dev)
+    want.append((ops.tail(wav, wh, 1023), t.add(wav, wh, 1023, 1.0, False)))
+    short = rnd(72, B, 8, 2).to(dev)                        # fewer samples than the cache is long: the rest comes from the old cache
+    sh = rnd(73, B, 8, 4).to(dev)
+    h, c = ops.dw_conv(short, (rnd(74, 8, 5) * 0.3).to(dev), None, in_elu=True, hist=sh, want_hist=True)
+    want.append((c, t.add(short, sh, 4, 1.0, True)))
+    assert len(t.items) == 7
+    t.flush()
+    for a, b_ in want:
+        assert a.shape == b_.shape and torch.equal(a, b_)
+
+
 def test_errors(env):
     ops, fold, O, dev = env
     x = torch.zeros(1, 8, 16, device=dev)

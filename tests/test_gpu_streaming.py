@@ -446,16 +446,22 @@ def test_stream_block_options_reach_both_halves():
         one, k_one, c_one = run(False, True)
         two, k_two, c_two = run(False, False)
         inline, _, c_inline = run(True, True, defer=False)          # SpecBlock branches added in-line (round 3) instead of by the down-sampling epilogues
+        for half in (model.encoder, model.decoder):
+            half.exec_options.stream_batch_tails = True              # the cache updates of each half as ONE launch (hilc_tail_multi; off by default: no gain measured)
+        separate, _, c_separate = run(True, True)
     finally:
         model.encoder.exec_options.stream_defer_spec = True
         for half in (model.encoder, model.decoder):
+            half.exec_options.stream_batch_tails = False
             half.exec_options.stream_chain_blocks = True
             half.exec_options.stream_wide_blocks = True
     # launches of the fused-block kernel per hop: encoder 4 stages x 2 blocks, decoder 4 x 3.  Chains: every stage but C = 256
     # (encoder) / C = 384 (decoder) is one launch; without the wide forms the 4 + 6 wide blocks are two GEMM launches each instead.
     assert k_one == (8, 12) and k_two == (4, 6), (k_one, k_two)
     assert k_chain == (3 + 2, 3 + 3), k_chain
-    for ref, other in ((chained, one), (chained, two), (chained, inline)):
+    for a, b in zip(c_chain, c_separate):
+        assert torch.equal(a, b)
+    for ref, other in ((chained, one), (chained, two), (chained, inline), (chained, separate)):
         for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
             assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
     for a, b, c, d in zip(c_chain, c_one, c_two, c_inline):
