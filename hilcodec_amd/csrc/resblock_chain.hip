@@ -62,6 +62,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   ResArgs a;
   a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
   a.dn = ResDown{};
+  a.up = ResUp{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (!streaming) {        // offline: the carry form's contiguous runs (hilc_resblock), the blocks of the stage back to back per tile
@@ -109,10 +110,38 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   ResArgs a;
   a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
+  a.up = ResUp{};
   ResDown& d = a.dn;
   d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = streaming ? down->hist : nullptr;
   d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
   hipStream_t s = (hipStream_t)stream;
   if (streaming) return C == 64 ? launch_chain<64, true, 2, false, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
   return C == 64 ? launch_chain<64, false, 2, false, 2>(a, B, s) : launch_chain<128, false, 2, true, 4>(a, B, s);
+}
+
+// ---- a DECODER STAGE of a streaming hop in one launch: its up-sampling layer and its residual blocks -----------------------------
+// seanet.py:431-452 (`[Scale, ELU, SConvTranspose1d (depthwise, k = 2r, stride r), 1x1 conv 2C -> C + bias]`, then the stage's three
+// SEANetResnetBlocks); streaming.py:629-639 with the transposed conv's cache.  == hilc_up_conv_stream followed by hilc_resblock_chain,
+// bit for bit.  The widest stage only (C = 768, r = 8: a hop is 1-4 frames of 1536 channels per stream, whole streams per 32-column tile).
+extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
+  return streaming && C == 768 && stride == 8 && nblk >= 1 && nblk <= 3 && T > 0 && T % 8 == 0 && 32 % T == 0;
+}
+
+extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, int streaming,
+                                  int B, int C, int T, void* stream) {
+  if (!up || !blocks || !y) return HILC_ERR_NULL;
+  if (!up->x || !up->tr_w || !up->w_lo || !up->w_hi) return HILC_ERR_NULL;
+  if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_decoder_stage_supported(C, T, nblk, up->stride, streaming)) return HILC_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(up->tr_w) & 15)) return HILC_ERR_UNSUPPORTED;
+  if (up->hist && up->hist == up->hist_out) return HILC_ERR_UNSUPPORTED;
+  if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
+  ResArgs a;
+  a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  a.dn = ResDown{};
+  if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
+  ResUp& u = a.up;
+  u.xin = up->x; u.tr_w = up->tr_w; u.w_lo = up->w_lo; u.w_hi = up->w_hi; u.bias = up->bias; u.hist = up->hist;
+  u.hist_out = up->hist_out; u.in_scale = up->in_scale;
+  return launch_chain<768, true, 3, false, -8>(a, B, (hipStream_t)stream);
 }

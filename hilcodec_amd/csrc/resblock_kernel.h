@@ -91,8 +91,15 @@ constexpr bool wide_shape() {
 template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0>
 struct Cfg {
   static constexpr int NB = NB_;
-  static constexpr int DR = DR_;
-  static_assert(DR_ == 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
+  static constexpr int DR = DR_ > 0 ? DR_ : 0;
+  // DR_ < 0: the stage's UP-SAMPLING layer (seanet.py:431-436: [Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C
+  // with bias]) as the FIRST phase of the launch ("U", r = -DR_): the tile's x is not read but computed — the up-sampled operand of
+  // the 2C rows is built in the LDS tile one half (C rows) at a time from the input frames, their cache and the 2r taps (two FMAs per
+  // element, like the loader of hilc_up_conv), two GEMMs accumulate over the 2C rows in k order, + bias -> the x registers.  The
+  // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
+  static constexpr int UR = DR_ < 0 ? -DR_ : 0;
+  static_assert(DR_ <= 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
+  static_assert(DR_ >= 0 || (DR_ == -8 && STREAM && C >= 512 && !X3_), "up-sampling phase: whole-stream tiles, r = 8");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
@@ -156,6 +163,17 @@ struct ResBlk {       // one residual block's parameters
   float pre_scale, out_scale;
 };
 
+struct ResUp {        // the stage's up-sampling layer (UR > 0)
+  const float* xin;   // [B][2C][T/r]
+  const float* tr_w;  // [2C][2r] taps of the depthwise transposed conv
+  const float* w_lo;  // rows [0, C) of the k-major [2C][C] pointwise weight, packed like a block's matrix
+  const float* w_hi;  // rows [C, 2C)
+  const float* bias;  // [C]
+  const float* hist;  // [B][2C] the ACTIVATED last input frame of the previous hop (NULL = zeros)
+  float* hist_out;
+  float in_scale;
+};
+
 struct ResDown {      // the stage's down-sampling layer (DR > 0)
   const float* w_lo;  // packed like a block's matrix: columns [0, C) of the k-major [C][2C] pointwise weight
   const float* w_hi;  // columns [C, 2C)
@@ -176,6 +194,7 @@ struct ResArgs {
   ResBlk blk[MAXBLK];
   int nblk;
   ResDown dn;
+  ResUp up;
   long run_tiles;     // chain launches on the streaming column space: tiles per run (whole streams), 0 = equal split of the grid
   float* y;
   int T, tiles;
@@ -315,7 +334,7 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
 // The same phase ROLLED, for the wide channel counts of the NARROW stream shapes (C = 768: 96 register sets of 12 MFMAs —
 // fully unrolled that is 25 KB of code per phase): a loop over groups of DEPTH sets, so that the register-set indices stay
 // compile-time; issue order, products and k order are those of gemm_phase.
-template <class K>
+template <class K, bool ZERO = true>
 __device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
                                                   WeightPipe<K>& wp, int colblk, int lane) {
   constexpr int C = K::CH, XS = K::XS;
@@ -336,10 +355,12 @@ __device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, 
   }
   constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
   const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
+  if constexpr (ZERO) {
 #pragma unroll
-  for (int i = 0; i < CBW; ++i)
+    for (int i = 0; i < CBW; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
   auto one_set = [&](auto dc, bool more) {
     constexpr int cur = decltype(dc)::value, nxt = (cur + DEPTH - 1) % DEPTH;
 #pragma unroll
@@ -505,9 +526,10 @@ struct Cols {          // (no padding bytes: the struct is copied, and hipcc kee
 };
 static_assert(sizeof(Cols) == 32, "no padding");
 
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false, int NB = 1, bool W8 = false, int DR = 0>
-__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::NT), (Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>;
+template <int C, bool STREAM, bool X3 = false, bool SCARRY = false, int NB = 1, bool W8 = false, int DRU = 0>
+__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>;
+  constexpr int DR = K::DR, UR = K::UR;
   using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
@@ -697,7 +719,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::NT), (Cfg<
   }
   cs = columns_of(tile < run1 ? tile : 0);
   f32x4 xr[RW];
-  if (tile < run1) {
+  if (UR == 0 && tile < run1) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, rsub + RSTEP * i);
   }
@@ -724,6 +746,74 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::NT), (Cfg<
 #endif
     STAMP(0);
     long next_tile = K::CARRYMODE ? tile + 1 : tile + gridDim.x;       // (tickets: s_next, read after P0's barrier)
+    if constexpr (UR > 0) {
+      // ---- U: x = W_up * u + bias; u[k][t] = w[k][t mod r] * a[k][t / r] + w[k][r + t mod r] * a[k][t / r - 1], a = ELU(in_scale * x_in),
+      //      a[.][-1] = the stream's cache (activated).  Same expression and the same k order as hilc_up_conv: bit-identical.
+      const ResUp& up = a.up;
+      const int Tin = T / UR;
+      const int q0 = cs.t / UR, p0 = cs.t - q0 * UR;             // input frame / phase of this lane's 4 columns (they share q0: r = 8)
+      f32x16 acc[CBW];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* wu = (h ? up.w_hi : up.w_lo) + (long)wclass * (C * C / K::RH);
+        asm volatile("" : "+s"(wu));
+        {
+          // the operands of UB rows first (one exposed round trip per batch, not one per row), then their arithmetic
+          constexpr int UB = RW % 6 == 0 ? 6 : RB;
+          lptr_t xp = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+          for (int i0 = 0; i0 < RW; i0 += UB) {
+            float xc[UB], xq[UB];
+            f32x4 wa[UB], wb[UB];
+#pragma unroll
+            for (int i = 0; i < UB; ++i) {
+              const int k = h * C + rsub + RSTEP * (i0 + i);
+              const long row = (long)cs.b * (2 * C) + k;
+              const float* xi = up.xin + (cs.t_in ? row * Tin + q0 : 0);
+              xc[i] = xi[0];
+              const float* pp = q0 >= 1 ? xi - 1 : (up.hist != nullptr && cs.t_in ? up.hist + row : xi);
+              xq[i] = pp[0];
+              wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + p0);
+              wb[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + UR + p0);
+            }
+#pragma unroll
+            for (int i = 0; i < UB; ++i) {
+              const float a1 = prologue(xc[i], up.in_scale, 1);
+              const float a0 = q0 >= 1 ? prologue(xq[i], up.in_scale, 1) : (up.hist != nullptr ? xq[i] : 0.f);   // the cache holds activated samples
+              f32x4 u;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[e] = fmaf(wa[i][e], a1, wb[i][e] * a0);
+              *(lvec_t)(xp + i * RSTEP * XS) = zero_unless(cs.t_in, u);
+              if (cs.tail && up.hist_out != nullptr)            // the stream's last group: its input frame is the next hop's cache
+                up.hist_out[(long)cs.b * (2 * C) + h * C + rsub + RSTEP * (i0 + i)] = a1;
+            }
+            xp += UB * RSTEP * XS;
+            asm volatile("" : "+v"(xp));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        Pipe wp;
+        wp.prefetch(wu, lane);
+        lds_barrier();
+        if (h == 0) gemm_phase_rolled<K, true>(wu, X, acc, wp, colblk, lane);
+        else gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
+        lds_barrier();
+      }
+      acc_to_x<K>(acc, X, rowblk0, colblk, lane);
+      lds_barrier();
+      {
+        lptr_t xp = (lptr_t)(X + rsub * XS + c4);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const float bv = up.bias != nullptr ? up.bias[rsub + RSTEP * i] : 0.f;
+          f32x4 v = *(lvec_t)(xp + i * RSTEP * XS);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = up.bias != nullptr ? __fadd_rn(v[e], bv) : v[e];
+          xr[i] = v;
+        }
+      }
+      lds_barrier();       // block 0's P0 overwrites X
+    }
 #pragma nounroll
     for (int blk = 0; blk < nblk; ++blk) {
     const ResBlk& bp = a.blk[NB == 1 ? 0 : blk];
@@ -950,7 +1040,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DR>::NT), (Cfg<
           }
         }
       }
-      if (last_blk && have_next) {
+      if (UR == 0 && last_blk && have_next) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) xr[i0 + i] = *xrow(cn, rsub + RSTEP * (i0 + i));
       }
@@ -1162,7 +1252,7 @@ inline void set_div_magic(ResArgs& a) {
 // fill whole tiles; runs are made of as many units as it takes for all runs to be resident at once (1024 streams x 320 samples,
 // 256 workgroups: 4 streams = 10 tiles each), the last run may be short.  STREAM NARROW (C >= 512): whole-stream tiles, static
 // stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
-template <int C, bool STREAM, int NB, bool W8, int DR = 0>
+template <int C, bool STREAM, int NB, bool W8, int DR = 0>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR)
 int launch_chain(ResArgs a, int B, hipStream_t s) {
   constexpr bool NARROW = STREAM && C >= 256;
   using K = Cfg<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>;

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 12   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: hilc_tail_multi */
+#define HILC_ABI_VERSION 13   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: hilc_tail_multi; 13: hilc_decoder_stage */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -202,6 +202,22 @@ int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming
 int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
 int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
                         int B, int C, int T, void* stream);
+
+/* ---- a DECODER STAGE of a streaming hop in one launch (ABI 13): its up-sampling layer and its residual blocks -----------------
+ * `seanet.py:431-452` ([Scale, ELU, depthwise SConvTranspose1d k = 2r stride r, 1x1 conv 2C -> C + bias], then the stage's
+ * SEANetResnetBlocks); streaming `streaming.py:629-639`, the transposed conv's cache `[B][2C][1]` = its last ACTIVATED input frame
+ * (`causal_layers.py:168-188`).  Equals hilc_up_conv_stream followed by hilc_resblock_chain bit for bit; the `[B][C][T]` tensor
+ * between them never exists.  x `[B][2C][T/r]`, tr_w `[2C][2r]`, w_lo / w_hi: rows [0, C) / [C, 2C) of the k-major `[2C][C]`
+ * pointwise weight, each packed with hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C)).
+ * The widest stage only: C = 768, r = 8, whole streams per 32-column tile (T in {8, 16, 32}), nblk 1..3, streaming = 1. */
+typedef struct hilc_up_params {
+  const float* x; const float* tr_w; const float* w_lo; const float* w_hi; const float* bias;
+  const float* hist; float* hist_out;
+  float in_scale; int stride;
+} hilc_up_params;
+int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming);
+int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, int streaming,
+                       int B, int C, int T, void* stream);
 
 /* ---- several cache updates in one launch (ABI 12) ----------------------------------------------------------------------
  * out[row][i] = last `pad` samples of [hist | pro(x)] per row (pro = in_scale, then ELU if in_elu) — what hilc_tail,
