@@ -46,6 +46,8 @@ SIGNATURES = {
     "hilc_resblock_chain_row_classes_offline": [_i],
     "hilc_resblock_pack_weights_rc": [_p, _p, _i, _i, _p],
     "hilc_resblock_chain": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hilc_decoder_stage_supported": [_i, _i, _i, _i, _i],
+    "hilc_decoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_encoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_encoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
@@ -71,7 +73,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def source_hash() -> str:
@@ -99,6 +101,12 @@ class TailDesc(C.Structure):
     """`hilc_tail_desc` of include/hilcodec_amd.h: one cache update of a hilc_tail_multi launch"""
     _fields_ = [("x", _p), ("hist", _p), ("out", _p), ("rows", C.c_long), ("T", _i), ("pad", _i), ("hist_len", _i),
                 ("in_scale", _f), ("in_elu", _i)]
+
+
+class UpParams(C.Structure):
+    """`hilc_up_params` of include/hilcodec_amd.h: the up-sampling layer of a decoder stage launch"""
+    _fields_ = [("x", _p), ("tr_w", _p), ("w_lo", _p), ("w_hi", _p), ("bias", _p), ("hist", _p), ("hist_out", _p),
+                ("in_scale", _f), ("stride", _i)]
 
 
 class DownParams(C.Structure):

@@ -754,6 +754,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
       const int q0 = cs.t / UR, p0 = cs.t - q0 * UR;             // input frame / phase of this lane's 4 columns (they share q0: r = 8)
       f32x16 acc[CBW];
 #pragma unroll
+      for (int i = 0; i < CBW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma nounroll
       for (int h = 0; h < 2; ++h) {
         const float* wu = (h ? up.w_hi : up.w_lo) + (long)wclass * (C * C / K::RH);
         asm volatile("" : "+s"(wu));
@@ -795,8 +799,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
         Pipe wp;
         wp.prefetch(wu, lane);
         lds_barrier();
-        if (h == 0) gemm_phase_rolled<K, true>(wu, X, acc, wp, colblk, lane);
-        else gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
+        gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
         lds_barrier();
       }
       acc_to_x<K>(acc, X, rowblk0, colblk, lane);

@@ -46,6 +46,7 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
+    fuse_decoder_stage: bool = True        # streaming hop: the widest decoder stage (C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
@@ -152,6 +153,8 @@ class DecStageSpec:
     pw_b: Optional[Tensor]
     blocks: List[ResBlockSpec]
     taps: Optional[Tensor] = None         # expanded tap table for strides without a vector tap path (finalize_spec)
+    up_lo: Optional[Tensor] = None        # the two row halves of pw_wt packed for the one-launch stage (streaming plans, C = 768)
+    up_hi: Optional[Tensor] = None
 
 
 @dataclass
@@ -214,6 +217,11 @@ def finalize_spec(spec, streaming: bool = False):
             st.down_hi = ops.resblock_chain_pack(st.down_pw_wt[:, c:].contiguous(), streaming)
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
+            c = st.pw_wt.shape[1]
+            if (streaming and st.up_lo is None and c == 768 and st.pw_wt.shape[0] == 2 * c and st.ratio == 8
+                    and all(rb.pw1_chain is not None for rb in st.blocks)):
+                st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous())
+                st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous())
     return spec
 
 
@@ -589,6 +597,22 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
                                   hist=caches[ci], want_hist=True, hist_out=out(ci))
             new_caches.append(c)
+        elif (streaming and not x3 and FUSE_STREAM and FUSE_RESBLOCK and opts.fuse_decoder_stage and opts.stream_chain_blocks and opts.stream_wide_blocks
+              and st.up_lo is not None and st.pw_b is not None
+              and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+                      and rb.dw2_b is not None for rb in st.blocks)
+              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0])):
+            # the whole stage — up-sampling layer and residual blocks — is one launch; the tensor between them never exists
+            nb = len(st.blocks)
+            x, cs_, c = ops.decoder_stage(
+                x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks],
+                [caches[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)], caches[ci],
+                [caches_out[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)] if caches_out is not None else None, out(ci))
+            new_caches.append(c)
+            new_caches.extend(cs_)
+            ci += 1 + 2 * nb
+            continue
         elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0 and tails is not None:
             # (the transposed conv's new cache = its last ACTIVATED input frame: with the other stages' and conv_post's in one launch)
             new_caches.append(tails.add(x, None, 1, st.in_scale, True, out=out(ci)))

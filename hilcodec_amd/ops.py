@@ -522,6 +522,38 @@ _register("encoder_stage", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tensor
           x.new_empty(x.shape[0], 2 * x.shape[1], x.shape[2] // stride))
 
 
+def _decoder_stage(xin, tr_w, w_lo, w_hi, bias, uhist, uhist_out, in_scale, stride, params, hist_in, hist_out, pre_scales, out_scales):
+    import ctypes
+    from ._lib import ResblockParams, UpParams
+    B, K2, Tin = xin.shape
+    Cc, T = K2 // 2, Tin * stride
+    n = len(pre_scales)
+    if len(params) != 6 * n or len(out_scales) != n or len(hist_in) != 2 * n or len(hist_out) != 2 * n:
+        raise RuntimeError("decoder_stage: 6 parameter tensors, 2 caches in and 2 caches out per block")
+    for h in (uhist, uhist_out):
+        if h is not None and h.numel() != B * K2:
+            raise RuntimeError(f"decoder_stage: the up-sampling cache must be [{B},{K2},1], got {tuple(h.shape)}")
+    blocks = (ResblockParams * n)()
+    for i in range(n):
+        w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), _ptr(hist_in[2 * i]),
+                                   _ptr(hist_in[2 * i + 1]), _ptr(hist_out[2 * i]), _ptr(hist_out[2 * i + 1]),
+                                   float(pre_scales[i]), float(out_scales[i]))
+    up = UpParams(_ptr(xin), _ptr(tr_w), _ptr(w_lo), _ptr(w_hi), _ptr(bias), _ptr(uhist), _ptr(uhist_out), float(in_scale), int(stride))
+    y = torch.empty(B, Cc, T, device=xin.device, dtype=torch.float32)
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} stream up r{stride} + stage x{n}"):
+        check(lib.hilc_decoder_stage(ctypes.cast(ctypes.pointer(up), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n, _ptr(y), 1,
+                                     B, Cc, T, _stream()), "hilc_decoder_stage")
+    return y
+
+
+_register("decoder_stage", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, Tensor? bias, Tensor? uhist, Tensor(a!)? uhist_out, "
+          "float in_scale, int stride, Tensor[] params, Tensor[] hist_in, Tensor(b!)[] hist_out, float[] pre_scales, float[] out_scales) "
+          "-> Tensor", _decoder_stage,
+          lambda xin, tr_w, w_lo, w_hi, bias, uhist, uhist_out, in_scale, stride, params, hist_in, hist_out, pre_scales, out_scales:
+          xin.new_empty(xin.shape[0], xin.shape[1] // 2, xin.shape[2] * stride))
+
+
 def _resblock_pack_rc(wt, row_classes):
     Cc = wt.shape[0]
     out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
@@ -940,6 +972,33 @@ def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Optional[Sequenc
         hout.extend([_state_out(given[0], x, B, Cc, 4), _state_out(given[1], x, B, Cc, 4)])
     y = _OPS.resblock_chain(x, params, hin, hout, pre, post)
     return y, hout
+
+
+def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1) -> bool:
+    """mirror of hilc_decoder_stage_supported (streaming hop; C = output channels of the stage, T = its samples per stream)"""
+    return C == 768 and stride == 8 and 1 <= nblk <= 3 and T > 0 and T % 8 == 0 and 32 % T == 0 and B * C * T * 4 < (1 << 32)
+
+
+def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: Sequence[Sequence[Tensor]], up_hist: Optional[Tensor],
+                  hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None, up_hist_out: Optional[Tensor] = None):
+    """A decoder stage of a streaming hop in ONE launch (hilc_decoder_stage): its up-sampling layer `up` = (tr_w `[2C,2r]`, w_lo, w_hi,
+    bias `[C]`, in_scale, stride) — w_lo / w_hi = the two ROW halves of the k-major `[2C,C]` pointwise weight packed with
+    `resblock_chain_pack` — and its residual blocks (`blocks[i]`, `hist[i]`, `hist_out[i]` as in `resblock_chain`).
+    xin `[B,2C,T/r]`, up_hist `[B,2C,1]` -> (y `[B,C,T]`, [block caches...], up-sampling cache)."""
+    B, K2, _ = xin.shape
+    Cc = K2 // 2
+    tr_w, w_lo, w_hi, bias, in_scale, stride = up
+    params, hin, hout, pre, post = [], [], [], [], []
+    for i, blk in enumerate(blocks):
+        params.extend(blk[:6])
+        pre.append(float(blk[6]))
+        post.append(float(blk[7]))
+        hin.extend(hist[i])
+        given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
+        hout.extend([_state_out(given[0], xin, B, Cc, 4), _state_out(given[1], xin, B, Cc, 4)])
+    uout = _state_out(up_hist_out, xin, B, K2, 1)
+    y = _OPS.decoder_stage(xin, tr_w, w_lo, w_hi, bias, up_hist, uout, float(in_scale), int(stride), params, hin, hout, pre, post)
+    return y, hout, uout
 
 
 def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:

@@ -566,6 +566,46 @@ def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
             assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
 
 
+@pytest.mark.parametrize("Tin,B,n", [(1, 37, 3), (1, 1024, 3), (2, 9, 3), (4, 5, 2), (1, 3, 1)])
+def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, Tin, B, n):
+    """hilc_decoder_stage (the widest decoder stage of a streaming hop: C = 768, r = 8; `streaming.py:629-639`) == hilc_up_conv_stream
+    followed by the residual blocks (chain), bit for bit over three hops: output, the up-sampling cache and the 2n block caches."""
+    ops, fold, O, dev = env
+    C, r = 768, 8
+    T = Tin * r
+    assert ops.decoder_stage_supported(C, T, n, r, B)
+    blocks = []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        blocks.append((ops.resblock_chain_pack(w1), d1, b1, ops.resblock_chain_pack(w2), d2, b2, 1.0, 0.4 + 0.1 * j))
+    tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
+    wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)                 # k-major [2C][C]
+    bu = (rnd(82, C) * 0.1).to(dev)
+    up = (tw, ops.resblock_chain_pack(wu[:C].contiguous()), ops.resblock_chain_pack(wu[C:].contiguous()), bu, 0.7071, r)
+    ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
+    cb = [[c.clone() for c in pair] for pair in ca]
+    ua = (rnd(30, B, 2 * C, 1) * 0.6).to(dev)
+    ub = ua.clone()
+    for h in range(3):
+        xin = rnd(100 + h, B, 2 * C, Tin).to(dev)
+        y, flat, ua = ops.decoder_stage(xin, up, blocks, ca, ua)
+        ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+        y2, ub = ops.up_conv(xin, tw, wu, bu, r, in_scale=0.7071, in_elu=True, hist=ub, want_hist=True)
+        if n >= 2:
+            y2, f2 = ops.resblock_chain(y2, blocks, cb)
+            cb = [f2[2 * j:2 * j + 2] for j in range(n)]
+        else:
+            blk = blocks[0]
+            y2, cb[0] = ops.resblock(y2, ops.resblock_pack((rnd(1, C, C) / C ** 0.5).to(dev)), blk[1], blk[2],
+                                     ops.resblock_pack((rnd(4, C, C) / C ** 0.5).to(dev)), blk[4], blk[5], 1.0, blk[7], hist=cb[0])
+        assert torch.equal(y, y2), (h, float((y - y2).abs().max()))
+        assert torch.equal(ua, ub), h
+        for j in range(n):
+            assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
