@@ -122,9 +122,12 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
 // ---- a DECODER STAGE of a streaming hop in one launch: its up-sampling layer and its residual blocks -----------------------------
 // seanet.py:431-452 (`[Scale, ELU, SConvTranspose1d (depthwise, k = 2r, stride r), 1x1 conv 2C -> C + bias]`, then the stage's three
 // SEANetResnetBlocks); streaming.py:629-639 with the transposed conv's cache.  == hilc_up_conv_stream followed by hilc_resblock_chain,
-// bit for bit.  The widest stage only (C = 768, r = 8: a hop is 1-4 frames of 1536 channels per stream, whole streams per 32-column tile).
+// bit for bit.  Streaming: C = 768 (r = 8: a hop is 1-4 frames of 1536 channels per stream, whole streams per 32-column tile), and the
+// carry-form stages C = 192 (r = 4) / C = 96 (r = 2), which also take the offline model (streaming = 0).
 extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
-  return streaming && C == 768 && stride == 8 && nblk >= 1 && nblk <= 3 && T > 0 && T % 8 == 0 && 32 % T == 0;
+  if (nblk < 1 || nblk > 3 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
+  if (C == 768) return streaming && stride == 8 && 32 % T == 0;      // whole streams per 32-column tile
+  return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
 extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, int streaming,
@@ -135,13 +138,22 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
   if (!hilc_decoder_stage_supported(C, T, nblk, up->stride, streaming)) return HILC_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(up->tr_w) & 15)) return HILC_ERR_UNSUPPORTED;
   if (up->hist && up->hist == up->hist_out) return HILC_ERR_UNSUPPORTED;
-  if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
+  if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
   ResArgs a;
   a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
   a.dn = ResDown{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   ResUp& u = a.up;
   u.xin = up->x; u.tr_w = up->tr_w; u.w_lo = up->w_lo; u.w_hi = up->w_hi; u.bias = up->bias; u.hist = up->hist;
-  u.hist_out = up->hist_out; u.in_scale = up->in_scale;
-  return launch_chain<768, true, 3, false, -8>(a, B, (hipStream_t)stream);
+  u.hist_out = streaming ? up->hist_out : nullptr; u.in_scale = up->in_scale;
+  if (!streaming) u.hist = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (streaming) {
+    switch (C) {
+      case 768: return launch_chain<768, true, 3, false, -8>(a, B, s);
+      case 192: return launch_chain<192, true, 3, false, -4>(a, B, s);
+      default: return launch_chain<96, true, 3, false, -2>(a, B, s);
+    }
+  }
+  return C == 192 ? launch_chain<192, false, 3, false, -4>(a, B, s) : launch_chain<96, false, 3, false, -2>(a, B, s);
 }

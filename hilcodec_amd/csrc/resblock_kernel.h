@@ -99,7 +99,8 @@ struct Cfg {
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
   static_assert(DR_ <= 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
-  static_assert(DR_ >= 0 || (DR_ == -8 && STREAM && C >= 512 && !X3_), "up-sampling phase: whole-stream tiles, r = 8");
+  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && STREAM && C >= 512) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
+                "up-sampling phase: whole-stream tiles (r = 8) or the carry form (r = 4 / 2)");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
@@ -254,7 +255,7 @@ struct WeightPipe {
 };
 
 // wt: this wave class's part of the packed matrix;  X: LDS tile;  colblk: the wave's 32-column block
-template <class K>
+template <class K, bool ZERO = true>
 __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
                                            WeightPipe<K>& wp, int colblk, int lane) {
   constexpr int C = K::CH, XS = K::XS;
@@ -295,7 +296,7 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
         // -DHILC_RES_ASM_MFMA: the former form, a volatile asm per MFMA (keeps its place among the loads, but hides the
         // instruction's hazards from the compiler).
 #ifndef HILC_RES_ASM_MFMA        // builtin MFMAs, pinned per register set (below); HILC_RES_ASM_MFMA = the former asm form, for A/B
-        if (s == 0 && j == 0) {
+        if (ZERO && s == 0 && j == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
@@ -762,34 +763,56 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
         const float* wu = (h ? up.w_hi : up.w_lo) + (long)wclass * (C * C / K::RH);
         asm volatile("" : "+s"(wu));
         {
-          // the operands of UB rows first (one exposed round trip per batch, not one per row), then their arithmetic
+          // the operands of UB rows first (one exposed round trip per batch, not one per row), then their arithmetic.
+          // r = 8 / 4: the lane's 4 columns share one input frame q0 (phases p0 .. p0 + 3); r = 2: they are frames q0, q0, q0 + 1, q0 + 1
+          // (phases 0, 1, 0, 1) — the same cases as UpB<R> in gemm_lin.h.
           constexpr int UB = RW % 6 == 0 ? 6 : RB;
           lptr_t xp = (lptr_t)(X + rsub * XS + c4);
+          const bool has_prev = cs.t_in && q0 >= 1;        // (offline: a group past the clip's end keeps its t)
 #pragma unroll
           for (int i0 = 0; i0 < RW; i0 += UB) {
             float xc[UB], xq[UB];
-            f32x4 wa[UB], wb[UB];
+            [[maybe_unused]] float xn[UB];
+            f32x4 wa[UB];
+            [[maybe_unused]] f32x4 wb[UB];
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
               const int k = h * C + rsub + RSTEP * (i0 + i);
               const long row = (long)cs.b * (2 * C) + k;
               const float* xi = up.xin + (cs.t_in ? row * Tin + q0 : 0);
               xc[i] = xi[0];
-              const float* pp = q0 >= 1 ? xi - 1 : (up.hist != nullptr && cs.t_in ? up.hist + row : xi);
+              const float* pp = has_prev ? xi - 1 : (up.hist != nullptr && cs.t_in ? up.hist + row : xi);
               xq[i] = pp[0];
-              wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + p0);
-              wb[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + UR + p0);
+              if constexpr (UR == 2) {
+                xn[i] = xi[cs.t_in ? 1 : 0];                       // T % 4 == 0 and r = 2: frame q0 + 1 exists wherever the group does
+                wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * 4);          // (w0, w1 | w2, w3)
+              } else {
+                wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + p0);
+                wb[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + UR + p0);
+              }
             }
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
               const float a1 = prologue(xc[i], up.in_scale, 1);
-              const float a0 = q0 >= 1 ? prologue(xq[i], up.in_scale, 1) : (up.hist != nullptr ? xq[i] : 0.f);   // the cache holds activated samples
+              const float a0 = has_prev ? prologue(xq[i], up.in_scale, 1) : (up.hist != nullptr ? xq[i] : 0.f);   // the cache holds activated samples
               f32x4 u;
+              float a_last = a1;
+              if constexpr (UR == 2) {
+                const float a2 = prologue(xn[i], up.in_scale, 1);
+                u[0] = fmaf(wa[i].x, a1, wa[i].z * a0);
+                u[1] = fmaf(wa[i].y, a1, wa[i].w * a0);
+                u[2] = fmaf(wa[i].x, a2, wa[i].z * a1);
+                u[3] = fmaf(wa[i].y, a2, wa[i].w * a1);
+                a_last = a2;
+              } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) u[e] = fmaf(wa[i][e], a1, wb[i][e] * a0);
+                for (int e = 0; e < 4; ++e) u[e] = fmaf(wa[i][e], a1, wb[i][e] * a0);
+              }
               *(lvec_t)(xp + i * RSTEP * XS) = zero_unless(cs.t_in, u);
-              if (cs.tail && up.hist_out != nullptr)            // the stream's last group: its input frame is the next hop's cache
-                up.hist_out[(long)cs.b * (2 * C) + h * C + rsub + RSTEP * (i0 + i)] = a1;
+              if constexpr (STREAM) {
+                if (cs.tail && !warm && up.hist_out != nullptr)   // the stream's last group: its (last) input frame is the next hop's cache
+                  up.hist_out[(long)cs.b * (2 * C) + h * C + rsub + RSTEP * (i0 + i)] = a_last;
+              }
             }
             xp += UB * RSTEP * XS;
             asm volatile("" : "+v"(xp));
@@ -799,7 +822,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
         Pipe wp;
         wp.prefetch(wu, lane);
         lds_barrier();
-        gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
+        if constexpr (K::NARROW) gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
+        else gemm_phase<K, false>(wu, X, acc, wp, colblk, lane);
         lds_barrier();
       }
       acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -961,7 +985,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     have_next = next_tile < run1;
     if (last_blk) cn = columns_of(have_next ? next_tile : tile);
-    if constexpr (!STREAM) {
+    if constexpr (!STREAM && UR == 0) {      // (UR > 0: x is computed, not read — nothing to touch, and a.x has another shape)
       if (final_blk) {
       long nb;
       int nt0;

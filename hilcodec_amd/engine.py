@@ -46,7 +46,9 @@ class ExecOptions:
     x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
     x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
     stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
-    fuse_decoder_stage: bool = True        # streaming hop: the widest decoder stage (C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
+    fuse_decoder_stage_narrow: bool = True  # ... the carry-form stages (C = 192 / 96) too.  PipelinedHop captures with False: next to a second chain the long
+                                            # one-workgroup-per-CU launches leave it nothing to co-reside with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90)
+    fuse_decoder_stage: bool = True        # decoder stages with C = 192 / 96 (a streaming hop: also C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
@@ -60,6 +62,28 @@ _DEFAULT_OPTIONS = ExecOptions()
 # (graph_step).  A context variable like ops._TIMER / ops._SCHED_WS: it belongs to the schedule being built on THIS thread,
 # not to the model — two schedules built concurrently on one model from different threads do not see each other's stream.
 _SIDE_STREAM: contextvars.ContextVar = contextvars.ContextVar("hilcodec_side_stream", default=None)
+
+
+# Per-schedule overrides of a model's ExecOptions (a schedule object that wants another launch structure for ITS capture —
+# PipelinedHop — says so here instead of writing into the module's options: context-local, like the side stream)
+_OPT_OVERRIDES: contextvars.ContextVar = contextvars.ContextVar("hilcodec_exec_overrides", default=None)
+
+
+@contextlib.contextmanager
+def exec_overrides(**fields):
+    token = _OPT_OVERRIDES.set(dict(_OPT_OVERRIDES.get() or {}, **fields))
+    try:
+        yield
+    finally:
+        _OPT_OVERRIDES.reset(token)
+
+
+def _effective(opts: "ExecOptions") -> "ExecOptions":
+    over = None if torch.compiler.is_compiling() else _OPT_OVERRIDES.get()
+    if not over:
+        return opts
+    import dataclasses
+    return dataclasses.replace(opts, **over)
 
 
 @contextlib.contextmanager
@@ -153,7 +177,7 @@ class DecStageSpec:
     pw_b: Optional[Tensor]
     blocks: List[ResBlockSpec]
     taps: Optional[Tensor] = None         # expanded tap table for strides without a vector tap path (finalize_spec)
-    up_lo: Optional[Tensor] = None        # the two row halves of pw_wt packed for the one-launch stage (streaming plans, C = 768)
+    up_lo: Optional[Tensor] = None        # the two row halves of pw_wt packed for the one-launch stage (C = 192 / 96; streaming plans also C = 768)
     up_hi: Optional[Tensor] = None
 
 
@@ -218,10 +242,10 @@ def finalize_spec(spec, streaming: bool = False):
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
             c = st.pw_wt.shape[1]
-            if (streaming and st.up_lo is None and c == 768 and st.pw_wt.shape[0] == 2 * c and st.ratio == 8
+            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8 if streaming else 0, 192: 4, 96: 2}.get(c, 0) == st.ratio
                     and all(rb.pw1_chain is not None for rb in st.blocks)):
-                st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous())
-                st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous())
+                st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous(), streaming)
+                st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous(), streaming)
     return spec
 
 
@@ -441,6 +465,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
     reference's protocol (`streaming.py:482-517`: cache_out never aliases cache_in)."""
     if wav.dim() != 3 or wav.shape[1] != 1:
         raise RuntimeError(f"expected [B,1,T] waveform, got {tuple(wav.shape)}")
+    opts = _effective(opts)
     wav = wav.contiguous().float()
     streaming = caches is not None
     if not streaming and not torch.compiler.is_compiling():
@@ -559,6 +584,7 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     """q `[B,dim,F]` (channel-major) -> wav `[B,1,F*hop]`, and the new cache list if streaming (`caches_out` as in
     run_encoder)."""
     streaming = caches is not None
+    opts = _effective(opts)
     caches = _contig(caches)
     new_caches: Optional[list] = [] if streaming else None
 
@@ -597,11 +623,12 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
                                   hist=caches[ci], want_hist=True, hist_out=out(ci))
             new_caches.append(c)
-        elif (streaming and not x3 and FUSE_STREAM and FUSE_RESBLOCK and opts.fuse_decoder_stage and opts.stream_chain_blocks and opts.stream_wide_blocks
+        elif (streaming and not x3 and FUSE_STREAM and FUSE_RESBLOCK and opts.fuse_decoder_stage and opts.stream_chain_blocks
               and st.up_lo is not None and st.pw_b is not None
               and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                       and rb.dw2_b is not None for rb in st.blocks)
-              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0])):
+              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0])
+              and (opts.fuse_decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.stream_wide_blocks)):
             # the whole stage — up-sampling layer and residual blocks — is one launch; the tensor between them never exists
             nb = len(st.blocks)
             x, cs_, c = ops.decoder_stage(
@@ -626,6 +653,15 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
                                  in_scale=st.in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
+        elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_chain_blocks
+              and st.up_lo is not None and st.pw_b is not None and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
+                                                                 and rb.dw1_b is not None and rb.dw2_b is not None for rb in st.blocks)
+              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0], streaming=False)):
+            x = ops.decoder_stage(
+                x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks])
+            ci += 1 + 2 * len(st.blocks)
+            continue
         elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0]):
             x = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps)
         elif fused_up:

@@ -528,22 +528,23 @@ def _decoder_stage(xin, tr_w, w_lo, w_hi, bias, uhist, uhist_out, in_scale, stri
     B, K2, Tin = xin.shape
     Cc, T = K2 // 2, Tin * stride
     n = len(pre_scales)
-    if len(params) != 6 * n or len(out_scales) != n or len(hist_in) != 2 * n or len(hist_out) != 2 * n:
-        raise RuntimeError("decoder_stage: 6 parameter tensors, 2 caches in and 2 caches out per block")
+    streaming = len(hist_in) > 0 or uhist_out is not None        # no caches at all: the offline causal model
+    if len(params) != 6 * n or len(out_scales) != n or len(hist_in) != (2 * n if streaming else 0) or len(hist_out) != len(hist_in):
+        raise RuntimeError("decoder_stage: 6 parameter tensors per block, and (streaming) 2 caches in and 2 caches out per block")
     for h in (uhist, uhist_out):
         if h is not None and h.numel() != B * K2:
             raise RuntimeError(f"decoder_stage: the up-sampling cache must be [{B},{K2},1], got {tuple(h.shape)}")
     blocks = (ResblockParams * n)()
     for i in range(n):
         w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
-        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), _ptr(hist_in[2 * i]),
-                                   _ptr(hist_in[2 * i + 1]), _ptr(hist_out[2 * i]), _ptr(hist_out[2 * i + 1]),
+        h = [_ptr(t) for t in (hist_in[2 * i], hist_in[2 * i + 1], hist_out[2 * i], hist_out[2 * i + 1])] if streaming else [None] * 4
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
                                    float(pre_scales[i]), float(out_scales[i]))
     up = UpParams(_ptr(xin), _ptr(tr_w), _ptr(w_lo), _ptr(w_hi), _ptr(bias), _ptr(uhist), _ptr(uhist_out), float(in_scale), int(stride))
     y = torch.empty(B, Cc, T, device=xin.device, dtype=torch.float32)
-    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} stream up r{stride} + stage x{n}"):
-        check(lib.hilc_decoder_stage(ctypes.cast(ctypes.pointer(up), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n, _ptr(y), 1,
-                                     B, Cc, T, _stream()), "hilc_decoder_stage")
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}" + (" stream" if streaming else "") + f" up r{stride} + stage x{n}"):
+        check(lib.hilc_decoder_stage(ctypes.cast(ctypes.pointer(up), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n, _ptr(y),
+                                     int(streaming), B, Cc, T, _stream()), "hilc_decoder_stage")
     return y
 
 
@@ -974,21 +975,32 @@ def resblock_chain(x: Tensor, blocks: Sequence[Sequence], hist: Optional[Sequenc
     return y, hout
 
 
-def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1) -> bool:
-    """mirror of hilc_decoder_stage_supported (streaming hop; C = output channels of the stage, T = its samples per stream)"""
-    return C == 768 and stride == 8 and 1 <= nblk <= 3 and T > 0 and T % 8 == 0 and 32 % T == 0 and B * C * T * 4 < (1 << 32)
+def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:
+    """mirror of hilc_decoder_stage_supported (C = output channels of the stage, T = its samples per stream / clip)"""
+    if not 1 <= nblk <= 3 or T <= 0 or T % 4 != 0 or stride <= 0 or T % stride != 0 or (streaming and B * C * T * 4 >= (1 << 32)):
+        return False
+    if C == 768:
+        return streaming and stride == 8 and 32 % T == 0
+    return (C == 192 and stride == 4) or (C == 96 and stride == 2)
 
 
-def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: Sequence[Sequence[Tensor]], up_hist: Optional[Tensor],
-                  hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None, up_hist_out: Optional[Tensor] = None):
+def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: Optional[Sequence[Sequence[Tensor]]] = None,
+                  up_hist: Optional[Tensor] = None, hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None,
+                  up_hist_out: Optional[Tensor] = None):
     """A decoder stage of a streaming hop in ONE launch (hilc_decoder_stage): its up-sampling layer `up` = (tr_w `[2C,2r]`, w_lo, w_hi,
     bias `[C]`, in_scale, stride) — w_lo / w_hi = the two ROW halves of the k-major `[2C,C]` pointwise weight packed with
     `resblock_chain_pack` — and its residual blocks (`blocks[i]`, `hist[i]`, `hist_out[i]` as in `resblock_chain`).
-    xin `[B,2C,T/r]`, up_hist `[B,2C,1]` -> (y `[B,C,T]`, [block caches...], up-sampling cache)."""
+    xin `[B,2C,T/r]`, up_hist `[B,2C,1]` -> (y `[B,C,T]`, [block caches...], up-sampling cache); hist None: the offline model -> y."""
     B, K2, _ = xin.shape
     Cc = K2 // 2
     tr_w, w_lo, w_hi, bias, in_scale, stride = up
     params, hin, hout, pre, post = [], [], [], [], []
+    if hist is None:                 # offline: y only
+        for blk in blocks:
+            params.extend(blk[:6])
+            pre.append(float(blk[6]))
+            post.append(float(blk[7]))
+        return _OPS.decoder_stage(xin, tr_w, w_lo, w_hi, bias, None, None, float(in_scale), int(stride), params, [], [], pre, post)
     for i, blk in enumerate(blocks):
         params.extend(blk[:6])
         pre.append(float(blk[6]))

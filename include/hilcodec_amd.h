@@ -209,7 +209,8 @@ int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* bl
  * (`causal_layers.py:168-188`).  Equals hilc_up_conv_stream followed by hilc_resblock_chain bit for bit; the `[B][C][T]` tensor
  * between them never exists.  x `[B][2C][T/r]`, tr_w `[2C][2r]`, w_lo / w_hi: rows [0, C) / [C, 2C) of the k-major `[2C][C]`
  * pointwise weight, each packed with hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C)).
- * The widest stage only: C = 768, r = 8, whole streams per 32-column tile (T in {8, 16, 32}), nblk 1..3, streaming = 1. */
+ * Stages: C = 768 with r = 8 (streaming only: whole streams per 32-column tile, T in {8, 16, 32}), C = 192 with r = 4 and C = 96 with
+ * r = 2 (streaming hops and, with streaming = 0, the offline model: hist* ignored); nblk 1..3. */
 typedef struct hilc_up_params {
   const float* x; const float* tr_w; const float* w_lo; const float* w_hi; const float* bias;
   const float* hist; float* hist_out;

@@ -566,12 +566,14 @@ def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
             assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
 
 
-@pytest.mark.parametrize("Tin,B,n", [(1, 37, 3), (1, 1024, 3), (2, 9, 3), (4, 5, 2), (1, 3, 1)])
-def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, Tin, B, n):
-    """hilc_decoder_stage (the widest decoder stage of a streaming hop: C = 768, r = 8; `streaming.py:629-639`) == hilc_up_conv_stream
-    followed by the residual blocks (chain), bit for bit over three hops: output, the up-sampling cache and the 2n block caches."""
+@pytest.mark.parametrize("C,r,Tin,B,n", [(768, 8, 1, 37, 3), (768, 8, 1, 1024, 3), (768, 8, 2, 9, 3), (768, 8, 4, 5, 2), (768, 8, 1, 3, 1),
+                                          (192, 4, 40, 7, 3), (192, 4, 40, 1024, 3), (96, 2, 160, 5, 3), (96, 2, 160, 1024, 3), (192, 4, 80, 3, 2),
+                                          (96, 2, 2, 70, 3), (192, 4, 1, 33, 3)])
+def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n):
+    """hilc_decoder_stage (a decoder stage of a streaming hop — `streaming.py:629-639` — in one launch: C = 768 / r = 8 on whole-stream
+    tiles, C = 192 / r = 4 and C = 96 / r = 2 in the carry form) == hilc_up_conv_stream followed by the residual blocks (chain), bit
+    for bit over three hops: output, the up-sampling cache and the 2n block caches."""
     ops, fold, O, dev = env
-    C, r = 768, 8
     T = Tin * r
     assert ops.decoder_stage_supported(C, T, n, r, B)
     blocks = []
@@ -604,6 +606,33 @@ def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, Tin, B, n):
         assert torch.equal(ua, ub), h
         for j in range(n):
             assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
+
+
+@pytest.mark.parametrize("C,r,Tin,B", [(192, 4, 3000, 3), (96, 2, 12000, 2), (192, 4, 31, 40), (96, 2, 300, 70), (96, 2, 12000, 24)])
+def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
+    """hilc_decoder_stage with streaming = 0 (`seanet.py:431-452`): the up-sampling layer and the three residual blocks of a narrow
+    decoder stage of the OFFLINE model in one launch == hilc_up_conv followed by hilc_resblock block by block."""
+    ops, fold, O, dev = env
+    n = 3
+    assert ops.decoder_stage_supported(C, Tin * r, n, r, B, streaming=False)
+    blocks, singles = [], []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        pre, post = (1.0 + j / 3.0) ** -0.5, 0.4 + 0.1 * j
+        blocks.append((ops.resblock_chain_pack(w1, False), d1, b1, ops.resblock_chain_pack(w2, False), d2, b2, pre, post))
+        singles.append(((ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2), pre, post))
+    tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
+    wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)
+    bu = (rnd(82, C) * 0.1).to(dev)
+    up = (tw, ops.resblock_chain_pack(wu[:C].contiguous(), False), ops.resblock_chain_pack(wu[C:].contiguous(), False), bu, 0.7071, r)
+    xin = rnd(100, B, 2 * C, Tin).to(dev)
+    y = ops.decoder_stage(xin, up, blocks)
+    y2 = ops.up_conv(xin, tw, wu, bu, r, in_scale=0.7071, in_elu=True)
+    for single, pre, post in singles:
+        y2 = ops.resblock(y2, *single, pre, post)
+    assert torch.equal(y, y2), float((y - y2).abs().max())
 
 
 def test_resblock_chain_shapes_it_does_not_take(env):
