@@ -141,3 +141,35 @@ def test_whole_model_weight_standardization(golden):
     # remove_weight_reparameterizations leaves a weight-standardised model alone (models.py:121: weight_norm only)
     model.remove_weight_reparameterizations()
     assert "encoder.conv_pre.1.conv.conv.weight_g" in model.state_dict()
+
+
+def test_offline_launch_structure_options_change_no_bit():
+    """`exec_options.offline_chain_blocks` / `fuse_encoder_stage` / `fuse_decoder_stage` (whole stages per launch, round 4) against one
+    launch per residual block and per down- / up-sampling layer (round 3): z, indices and wav bit for bit, on clips long enough for
+    several tiles per run and ragged against the tile width."""
+    from hilcodec_amd import ops
+    model, mk, sd = build("hil_speech")
+    dev = torch.device("cuda:0")
+    x = synth.synth_clips(5, 9280, seed=31).to(dev)
+
+    def run(chain, stages):
+        for half in (model.encoder, model.decoder):
+            half.exec_options.offline_chain_blocks = chain
+            half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = stages
+        with torch.no_grad(), ops.timed_launches() as t:
+            z = model.encoder(x)
+            q, _, _, idx = model.quantizer(z, None, return_indices=True)
+            wav = model.decoder(q)
+        return z, idx, wav, sum(r[0] == "resblock" for r in t.records), len(t.records)
+
+    try:
+        a = run(True, True)
+        b = run(True, False)
+        c = run(False, False)
+    finally:
+        for half in (model.encoder, model.decoder):
+            half.exec_options.offline_chain_blocks = half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
+    # fused-kernel launches: 4 stages / 4 chains / 2 * 2 + 2 * 3 blocks; and the stage form saves the four down- / up-sampling launches
+    assert (a[3], b[3], c[3]) == (4, 4, 10) and b[4] - a[4] == 4, (a[3:], b[3:], c[3:])
+    for other in (b, c):
+        assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
