@@ -86,6 +86,11 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
     case 96: return launch_res<96, false>(a, B, (hipStream_t)stream);
     case 128: return launch_res<128, false>(a, B, (hipStream_t)stream);
     case 192: return launch_res<192, false>(a, B, (hipStream_t)stream);
+    // the wide blocks (NARROW shapes, carry form): one launch instead of two hilc_dws_conv — the first half's output stays in LDS
+    case 256: return launch_res<256, false>(a, B, (hipStream_t)stream);
+    case 384: return launch_res<384, false>(a, B, (hipStream_t)stream);
+    case 512: return launch_res<512, false>(a, B, (hipStream_t)stream);
+    case 768: return launch_res<768, false>(a, B, (hipStream_t)stream);
     default: return HILC_ERR_UNSUPPORTED;
   }
 }
@@ -97,6 +102,7 @@ extern "C" int hilc_resblock_pack_weights(const float* wt, float* packed, int C,
   if (wt == packed) return HILC_ERR_UNSUPPORTED;
   const int RH = C >= 512 ? 8 : (C >= 256 ? 4 : (C == 192 ? 2 : 1));     // row classes of the one shape each width has
   static_assert(Cfg<256, true>::RH == 4 && Cfg<384, true>::RH == 4 && Cfg<512, true>::RH == 8 && Cfg<768, true>::RH == 8, "packed layout");
+  static_assert(Cfg<256, false>::RH == 4 && Cfg<384, false>::RH == 4 && Cfg<512, false>::RH == 8 && Cfg<768, false>::RH == 8, "packed layout");
   static_assert(Cfg<64, false>::RH == 1 && Cfg<96, false>::RH == 1 && Cfg<128, false>::RH == 1 && Cfg<192, false>::RH == 2 &&
                 Cfg<64, true>::RH == 1 && Cfg<96, true>::RH == 1 && Cfg<128, true>::RH == 1 && Cfg<192, true>::RH == 2, "packed layout");
   HILC_CLEAR_ERROR();
@@ -165,7 +171,7 @@ extern "C" void hilc_debug_set_stamp_buffer(unsigned long long* p) { g_dbg = p; 
 #endif
 
 extern "C" int hilc_resblock_supported(int C, int T) {
-  return (C == 64 || C == 96 || C == 128 || C == 192) && T % 4 == 0;
+  return (C == 64 || C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512 || C == 768) && T > 0 && T % 4 == 0;
 }
 
 // widths and hop lengths hilc_resblock_stream / hilc_resblock_sched(streaming = 1) take: the offline widths, plus the wide

@@ -15,17 +15,24 @@ constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C =
 extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming) {
   if (nblk < 2 || nblk > MAXBLK || T <= 0 || T % 4 != 0) return 0;
   // the instantiations hold the carry slots / tap tables of 2 blocks at the encoder's widths and of 3 at the decoder's
-  const int max_blocks = (C == 96 || C == 192 || C == 768) ? 3 : 2;
+  // (offline C = 768: the carry slots of a second block do not fit beside the 32-column tile — 768 x (32 + 16) x 4 B + 36 KB of taps)
+  const int max_blocks = (C == 96 || C == 192 || (streaming ? C == 768 : C == 384)) ? 3 : 2;
   if (nblk > max_blocks) return 0;
   if (chain_width(C)) return 1;
-  return streaming && (C == 512 || C == 768) && 32 % T == 0;
+  if (!streaming) return C == 256 || C == 384 || C == 512;          // the wide blocks in the carry form (NARROW shapes)
+  return (C == 512 || C == 768) && 32 % T == 0;
 }
 
 // packed pointwise weights of a chain launch: the 8-wave shapes split the rows in two classes also below C = 192
 // (offline: C = 64 keeps four waves = one row class; the other widths as in the streaming form)
 extern "C" int hilc_resblock_chain_row_classes_offline(int C) {
   static_assert(Cfg<64, false, false, false, 2, false>::RH == 1 && Cfg<96, false, false, false, 3, false>::RH == 1 &&
-                Cfg<128, false, false, false, 2, true>::RH == 2 && Cfg<192, false, false, false, 3, false>::RH == 2, "packed layout");
+                Cfg<128, false, false, false, 2, true>::RH == 2 && Cfg<192, false, false, false, 3, false>::RH == 2 &&
+                Cfg<256, false, false, false, 2, false>::RH == 4 && Cfg<384, false, false, false, 3, false>::RH == 4 &&
+                Cfg<512, false, false, false, 2, false>::RH == 8, "packed layout");
+  static_assert(Cfg<768, false, false, false, 1, false, -8>::RH == 8, "packed layout");
+  if (C == 256 || C == 384) return 4;
+  if (C == 512 || C == 768) return 8;
   return C == 128 || C == 192 ? 2 : (chain_width(C) ? 1 : 0);
 }
 
@@ -71,6 +78,9 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
       case 96: return launch_chain<96, false, 3, false>(a, B, s);
       case 128: return launch_chain<128, false, 2, true>(a, B, s);
       case 192: return launch_chain<192, false, 3, false>(a, B, s);
+      case 256: return launch_chain<256, false, 2, false>(a, B, s);
+      case 384: return launch_chain<384, false, 3, false>(a, B, s);
+      case 512: return launch_chain<512, false, 2, false>(a, B, s);
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
@@ -126,7 +136,7 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
 // carry-form stages C = 192 (r = 4) / C = 96 (r = 2), which also take the offline model (streaming = 0).
 extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
   if (nblk < 1 || nblk > 3 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
-  if (C == 768) return streaming && stride == 8 && 32 % T == 0;      // whole streams per 32-column tile
+  if (C == 768) return stride == 8 && (streaming ? 32 % T == 0 : nblk == 1);      // whole streams per 32-column tile; offline: carry form, up-sampling layer + FIRST block (LDS)
   return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
@@ -155,5 +165,6 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
       default: return launch_chain<96, true, 3, false, -2>(a, B, s);
     }
   }
+  if (C == 768) return launch_chain<768, false, 1, false, -8>(a, B, s);
   return C == 192 ? launch_chain<192, false, 3, false, -4>(a, B, s) : launch_chain<96, false, 3, false, -2>(a, B, s);
 }

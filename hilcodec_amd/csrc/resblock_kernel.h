@@ -99,17 +99,18 @@ struct Cfg {
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
   static_assert(DR_ <= 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
-  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && STREAM && C >= 512) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
-                "up-sampling phase: whole-stream tiles (r = 8) or the carry form (r = 4 / 2)");
+  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && C >= 512) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
+                "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form) or the carry form (r = 4 / 2)");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
   static constexpr bool WIDE = !STREAM && wide_shape<C>();
-  // NARROW (STREAM, C >= 256: the wide blocks of a streaming hop, 8 or 40 frames per stream): the whole channel range of a
-  // 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).  At 32 columns a tile is
-  // whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the previous samples, so
-  // there is no halo to recompute.
-  static constexpr bool NARROW = STREAM && C >= 256;
+  // NARROW (C >= 256: the wide blocks — of a streaming hop, 8 or 40 frames per stream, and since round 4 of the offline model): the
+  // whole channel range of a 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).
+  // STREAM: at 32 columns a tile is whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the
+  // previous samples, so there is no halo to recompute; 64-column tiles walk the flat column space with an 8-column halo.
+  // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
+  static constexpr bool NARROW = C >= 256;
   static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
   static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + (DR_ > 0 ? 8 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise

@@ -50,6 +50,7 @@ class ExecOptions:
                                             # one-workgroup-per-CU launches leave it nothing to co-reside with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90)
     fuse_decoder_stage: bool = True        # decoder stages with C = 192 / 96 (a streaming hop: also C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
+    offline_wide_blocks: bool = True       # offline: the wide residual blocks (C = 256 ... 768) as ONE carry-form launch each / per stage (False: two hilc_dws_conv launches per block, as until round 4)
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
     stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
@@ -205,18 +206,18 @@ class RvqSpec:
         return self.codebooks.shape[0]
 
 
-STREAM_WIDE_C = (256, 384, 512, 768)     # widths only the streaming form of the fused block takes (csrc/resblock.hip: NARROW shapes)
+STREAM_WIDE_C = (256, 384, 512, 768)     # the wide blocks (csrc/resblock_kernel.h: NARROW shapes)
 
 
 def finalize_block(rb: "ResBlockSpec", streaming: bool = False) -> "ResBlockSpec":
     c = rb.pw1_wt.shape[0]
     narrow = c <= FUSE_RESBLOCK_MAX_C and ops.resblock_supported(c, 4)
     if (rb.pw1_packed is None and rb.pw1_wt.device.type in ("cuda", "meta") and rb.pw1_wt.shape[1] == c
-            and (narrow or (streaming and c in STREAM_WIDE_C))):
+            and (narrow or c in STREAM_WIDE_C)):
         rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
         rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
-    if rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or (streaming and c in (512, 768))):
-        same = ops.resblock_chain_row_classes(c, streaming) == (8 if c >= 512 else (2 if c == 192 else 1))     # hilc_resblock_pack_weights' own split
+    if rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or c in ((512, 768) if streaming else STREAM_WIDE_C)):
+        same = ops.resblock_chain_row_classes(c, streaming) == (8 if c >= 512 else (4 if c >= 256 else (2 if c == 192 else 1)))     # hilc_resblock_pack_weights' own split
         rb.pw1_chain = rb.pw1_packed if same else ops.resblock_chain_pack(rb.pw1_wt, streaming)
         rb.pw2_chain = rb.pw2_packed if same else ops.resblock_chain_pack(rb.pw2_wt, streaming)
     return rb
@@ -242,7 +243,7 @@ def finalize_spec(spec, streaming: bool = False):
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
             c = st.pw_wt.shape[1]
-            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8 if streaming else 0, 192: 4, 96: 2}.get(c, 0) == st.ratio
+            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8, 192: 4, 96: 2}.get(c, 0) == st.ratio
                     and all(rb.pw1_chain is not None for rb in st.blocks)):
                 st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous(), streaming)
                 st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous(), streaming)
@@ -268,10 +269,12 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
-def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False, wide: bool = True) -> bool:
+def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False, wide: Optional[bool] = None) -> bool:
+    if wide is None:
+        wide = streaming
     return (FUSE_RESBLOCK and rb.pw1_packed is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
             and rb.dw1_b is not None and rb.dw2_b is not None
-            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or (streaming and wide))
+            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or wide)
             and ops.resblock_supported(x.shape[1], x.shape[2], x.shape[0], streaming))
 
 
@@ -289,7 +292,7 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
     if (x3 and opts.x3_fused_blocks and caches is None and _fusable(rb, x) and ops.resblock_x3_supported(x.shape[1], x.shape[2], x.shape[0])):
         return ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
                                _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)
-    if caches is None and _fusable(rb, x):
+    if caches is None and _fusable(rb, x, False, opts.offline_wide_blocks and not x3):
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
@@ -362,7 +365,7 @@ def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Se
         new_caches.extend(cs)
         return y
     if (not streaming and not x3 and FUSE_RESBLOCK and opts.offline_chain_blocks and n >= 2
-            and all(rb.pw1_chain is not None and _fusable(rb, x) for rb in blocks)
+            and all(rb.pw1_chain is not None and _fusable(rb, x, False, opts.offline_wide_blocks) for rb in blocks)
             and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0], streaming=False)):
         return ops.resblock_chain(
             x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks])
@@ -660,6 +663,18 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             x = ops.decoder_stage(
                 x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
                 [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks])
+            ci += 1 + 2 * len(st.blocks)
+            continue
+        elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_wide_blocks
+              and st.up_lo is not None and st.pw_b is not None and len(st.blocks) >= 1 and st.blocks[0].pw1_chain is not None
+              and st.blocks[0].dw1_w.shape[1] == 5 and st.blocks[0].dw2_w.shape[1] == 5 and st.blocks[0].dw1_b is not None
+              and st.blocks[0].dw2_b is not None
+              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, 1, st.ratio, x.shape[0], streaming=False)):
+            # the widest stage (C = 768): its carry slots leave LDS room for ONE block behind the up-sampling phase; the other blocks follow
+            rb = st.blocks[0]
+            x = ops.decoder_stage(x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                                  [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)])
+            x = _stage_blocks(st.blocks[1:], x, None, 0, None, None, x3, opts)
             ci += 1 + 2 * len(st.blocks)
             continue
         elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0]):

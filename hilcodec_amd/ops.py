@@ -921,7 +921,7 @@ def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> b
     if T <= 0 or T % 4 != 0:
         return False
     if not streaming:
-        return C in (64, 96, 128, 192)
+        return C in (64, 96, 128, 192, 256, 384, 512, 768)
     if B * C * T * 4 >= (1 << 32):
         return False
     return C in (64, 96, 128, 192, 256, 384) or (C in (512, 768) and 32 % T == 0)
@@ -929,10 +929,10 @@ def resblock_supported(C: int, T: int, B: int = 1, streaming: bool = False) -> b
 
 def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1, streaming: bool = True) -> bool:
     """mirror of hilc_resblock_chain_supported: the blocks of one stage in one launch"""
-    if nblk < 2 or nblk > (3 if C in (96, 192, 768) else 2) or T <= 0 or T % 4 != 0:
+    if nblk < 2 or nblk > (3 if C in (96, 192) or C == (768 if streaming else 384) else 2) or T <= 0 or T % 4 != 0:
         return False
     if not streaming:
-        return C in (64, 96, 128, 192)
+        return C in (64, 96, 128, 192, 256, 384, 512)
     if B * C * T * 4 >= (1 << 32):
         return False
     return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
@@ -941,7 +941,7 @@ def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1, streaming: b
 def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
     """mirror of hilc_resblock_chain_row_classes(_offline): the row split of the packed weights a chain launch reads"""
     if not streaming:
-        return 2 if C in (128, 192) else 1
+        return 8 if C in (512, 768) else (4 if C in (256, 384) else (2 if C in (128, 192) else 1))
     return 8 if C >= 512 else (1 if C in (64, 96) else 2)
 
 
@@ -980,7 +980,7 @@ def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
     if not 1 <= nblk <= 3 or T <= 0 or T % 4 != 0 or stride <= 0 or T % stride != 0 or (streaming and B * C * T * 4 >= (1 << 32)):
         return False
     if C == 768:
-        return streaming and stride == 8 and 32 % T == 0
+        return stride == 8 and (32 % T == 0 if streaming else nblk == 1)
     return (C == 192 and stride == 4) or (C == 96 and stride == 2)
 
 

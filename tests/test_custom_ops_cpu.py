@@ -41,7 +41,7 @@ def _meta_model(name):
 def test_offline_plan_on_meta_tensors(name):
     model, mk, es, ds = _meta_model(name)
     nq = mk["vq_kwargs"]["num_quantizers"]
-    assert es.stages[0].blocks[0].pw1_packed is not None and es.stages[3].blocks[0].pw1_packed is None   # C=64 / C=512
+    assert es.stages[0].blocks[0].pw1_packed is not None and es.stages[3].blocks[0].pw1_packed is not None   # C=64 / C=512 (round 4: the wide blocks too)
     assert ds.stages[1].taps is not None and ds.stages[0].taps is None                                    # stride 5 / 8
     assert es.stages[0].spec.fused is not None and es.stages[2].spec.fused is not None and es.stages[3].spec.fused is None
     assert es.stages[0].spec.fused[0].shape == (64 * 64,) and es.stages[1].spec.fused[2].numel() % (128 * 8) == 0

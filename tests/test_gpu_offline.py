@@ -152,10 +152,11 @@ def test_offline_launch_structure_options_change_no_bit():
     dev = torch.device("cuda:0")
     x = synth.synth_clips(5, 9280, seed=31).to(dev)
 
-    def run(chain, stages):
+    def run(chain, stages, wide=True):
         for half in (model.encoder, model.decoder):
             half.exec_options.offline_chain_blocks = chain
             half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = stages
+            half.exec_options.offline_wide_blocks = wide
         with torch.no_grad(), ops.timed_launches() as t:
             z = model.encoder(x)
             q, _, _, idx = model.quantizer(z, None, return_indices=True)
@@ -166,10 +167,18 @@ def test_offline_launch_structure_options_change_no_bit():
         a = run(True, True)
         b = run(True, False)
         c = run(False, False)
+        d = run(True, True, False)
+        e = run(True, False, False)
+        f = run(False, False, False)
     finally:
         for half in (model.encoder, model.decoder):
             half.exec_options.offline_chain_blocks = half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
-    # fused-kernel launches: 4 stages / 4 chains / 2 * 2 + 2 * 3 blocks; and the stage form saves the four down- / up-sampling launches
-    assert (a[3], b[3], c[3]) == (4, 4, 10) and b[4] - a[4] == 4, (a[3:], b[3:], c[3:])
-    for other in (b, c):
+            half.exec_options.offline_wide_blocks = True
+    # without the wide blocks' fused form (round 3 + the narrow stages of round 4) — fused-kernel launches: 4 stages / 4 chains / 2 * 2 +
+    # 2 * 3 blocks; and the stage form saves the four down- / up-sampling launches
+    assert (d[3], e[3], f[3]) == (4, 4, 10) and e[4] - d[4] == 4, (d[3:], e[3:], f[3:])
+    # with them: encoder 4 stages / chains, decoder C = 768: (up-sampling layer +) first block, two blocks; C = 384 / 192 / 96: one launch each;
+    # block by block: 4 * 2 + 4 * 3; the stage form saves five down- / up-sampling launches; every wide block is one launch less than two
+    assert (a[3], b[3], c[3]) == (10, 10, 20) and b[4] - a[4] == 5 and f[4] - c[4] == 10, (a[3:], b[3:], c[3:], f[3:])
+    for other in (b, c, d, e, f):
         assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])

@@ -312,7 +312,8 @@ def test_dws_conv_strided_vs_oracle(env, K, M, Tn, r):
     close(y, ref, 2e-5, "dws strided")
 
 
-@pytest.mark.parametrize("C,Tn,B", [(64, 1000, 2), (96, 360, 3), (128, 124, 2), (192, 600, 1), (96, 120, 1), (64, 8, 2)])
+@pytest.mark.parametrize("C,Tn,B", [(64, 1000, 2), (96, 360, 3), (128, 124, 2), (192, 600, 1), (96, 120, 1), (64, 8, 2),
+                                     (256, 600, 2), (384, 300, 3), (512, 124, 2), (768, 76, 2)])
 def test_fused_resblock_vs_oracle(env, C, Tn, B):
     """hilc_resblock (whole residual block in one launch) against the oracle's resblock()"""
     ops, fold, O, dev = env
@@ -480,7 +481,8 @@ def test_spec_block_branch_alone(env, n_fft, hop, B, T):
 
 
 @pytest.mark.parametrize("C,T,B,n", [(64, 1000, 3, 2), (96, 24000, 2, 3), (128, 124, 5, 2), (192, 600, 2, 3), (96, 120, 70, 2), (64, 24000, 40, 2),
-                                      (192, 12000, 24, 3)])
+                                      (192, 12000, 24, 3), (256, 3000, 3, 2), (384, 3000, 5, 3), (512, 600, 7, 2), (384, 124, 300, 3), (256, 600, 70, 2),
+                                      (384, 3000, 2, 2)])
 def test_resblock_chain_offline_equals_block_by_block(env, C, T, B, n):
     """hilc_resblock_chain with streaming = 0: the blocks of a stage of the OFFLINE causal model in one launch (contiguous runs
     with one carry per block; a run that starts inside a clip warms up on the tile in front) == hilc_resblock block by block."""
@@ -499,6 +501,24 @@ def test_resblock_chain_offline_equals_block_by_block(env, C, T, B, n):
     y2 = x
     for single, _, pre, post in blocks:
         y2 = ops.resblock(y2, *single, pre, post)
+    assert torch.equal(y, y2), float((y - y2).abs().max())
+
+
+@pytest.mark.parametrize("C,T,B", [(256, 3000, 3), (384, 3000, 2), (512, 600, 5), (768, 600, 3), (384, 3000, 40), (768, 600, 300), (256, 44, 700),
+                                   (512, 4, 9)])
+def test_wide_resblock_offline_equals_two_launches(env, C, T, B):
+    """The wide blocks of the OFFLINE model (C = 256 ... 768) as ONE carry-form launch (round 4: 32- / 64-column tiles, the eight waves
+    split the rows; runs of one workgroup per CU, warm-up tile where a run starts inside a clip) == the two hilc_dws_conv launches
+    they replace, bit for bit — few clips (every run starts inside a clip), many clips, clips shorter than a tile."""
+    ops, fold, O, dev = env
+    w1, w2 = (rnd(1, C, C) / C ** 0.5).to(dev), (rnd(4, C, C) / C ** 0.5).to(dev)
+    d1, b1 = (rnd(2, C, 5) * 0.5).to(dev), (rnd(3, C) * 0.2).to(dev)
+    d2, b2 = (rnd(5, C, 5) * 0.5).to(dev), (rnd(6, C) * 0.2).to(dev)
+    x = rnd(C + T, B, C, T).to(dev)
+    assert ops.resblock_supported(C, T, B)
+    y = ops.resblock(x, ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2, 0.9, 0.4)
+    g = ops.dws_conv(x, w1, d1, b1, in_scale=0.9, in_elu=True, out_elu=True)
+    y2 = ops.dws_conv(g, w2, d2, b2, res=x, out_scale=0.4)
     assert torch.equal(y, y2), float((y - y2).abs().max())
 
 
@@ -608,12 +628,14 @@ def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n
             assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
 
 
-@pytest.mark.parametrize("C,r,Tin,B", [(192, 4, 3000, 3), (96, 2, 12000, 2), (192, 4, 31, 40), (96, 2, 300, 70), (96, 2, 12000, 24)])
+@pytest.mark.parametrize("C,r,Tin,B", [(192, 4, 3000, 3), (96, 2, 12000, 2), (192, 4, 31, 40), (96, 2, 300, 70), (96, 2, 12000, 24),
+                                       (768, 8, 75, 3), (768, 8, 75, 300), (768, 8, 2, 50), (768, 8, 301, 2)])
 def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
     """hilc_decoder_stage with streaming = 0 (`seanet.py:431-452`): the up-sampling layer and the three residual blocks of a narrow
-    decoder stage of the OFFLINE model in one launch == hilc_up_conv followed by hilc_resblock block by block."""
+    decoder stage of the OFFLINE model in one launch == hilc_up_conv followed by hilc_resblock block by block.  The widest stage
+    (C = 768, r = 8): the up-sampling layer and the FIRST block (the carry slots of a second one do not fit LDS)."""
     ops, fold, O, dev = env
-    n = 3
+    n = 1 if C == 768 else 3
     assert ops.decoder_stage_supported(C, Tin * r, n, r, B, streaming=False)
     blocks, singles = [], []
     for j in range(n):
@@ -653,7 +675,7 @@ def test_wide_stream_block_shapes_it_does_not_take(env):
     from hilcodec_amd._lib import lib
     assert lib.hilc_resblock_stream_supported(768, 8) == 1 and lib.hilc_resblock_stream_supported(768, 40) == 0
     assert lib.hilc_resblock_stream_supported(384, 40) == 1 and lib.hilc_resblock_stream_supported(640, 8) == 0
-    assert not ops.resblock_supported(768, 40, 4, streaming=True) and not ops.resblock_supported(768, 8, 4, streaming=False)
+    assert not ops.resblock_supported(768, 40, 4, streaming=True) and not ops.resblock_supported(1024, 8, 4, streaming=False)
     C, T, B = 768, 40, 2
     w = (rnd(1, C, C) / C ** 0.5).to(dev)
     d, b = (rnd(2, C, 5) * 0.5).to(dev), (rnd(3, C) * 0.2).to(dev)
