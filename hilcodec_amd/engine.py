@@ -121,7 +121,7 @@ class ResBlockSpec:
     dw2_b: Optional[Tensor]
     pre_scale: float        # (1 + idx*res_scale^2)^-1/2  (seanet.py:84), 1.0 in the streaming decoder
     out_scale: float        # res_scale * res_scale_param (seanet.py:144-148); 1.0 when merged into dw2
-    pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec): C <= 192, streaming plans also 256 ... 768
+    pw1_packed: Optional[Tensor] = None   # MFMA-lane-order copies for the fused block (finalize_spec): C = 64 ... 768
     pw2_packed: Optional[Tensor] = None
     pw1_chain: Optional[Tensor] = None    # the same for a chain launch (streaming plans; another row split below C = 192, else the tensors above)
     pw2_chain: Optional[Tensor] = None

@@ -103,7 +103,7 @@ int hilc_dws_conv_stream(const float* x, const float* wt, const float* dw_w, con
                          float* hist_out, const float* res, float* y, int B, int K, int M, int T, int ksize,
                          int stride, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
 
-/* ---- fully fused residual block (narrow, long layers: C in {64, 96, 128, 192}, T % 4 == 0) --------
+/* ---- fully fused residual block (C in {64, 96, 128, 192} and — narrow-tile shapes — {256, 384, 512, 768}; T % 4 == 0) --------
  * y = x + out_scale * (dw2(pw2(ELU(dw1(pw1(ELU(pre_scale * x))) + dw1_b))) + dw2_b)
  * One HBM read of x and one write of y per block; both pointwise outputs and the mid activation
  * stay in LDS.  w1t / w2t are the two `[C][C]` pointwise matrices in the PACKED layout written by
@@ -187,9 +187,10 @@ int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w,
  * blocks[i]: that block's parameters; w1t / w2t PACKED by hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C))
  * (the chain's 8-wave shapes split the rows in two classes also below C = 192, so the layout differs from hilc_resblock's);
  * hist* as in hilc_resblock_stream (each optional; ignored with streaming = 0: the offline causal model, hilc_resblock).
- * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0,
- * C in {512, 768} with whole streams tiling 32 columns; nblk = 2, or 3 at the decoder's widths (96, 192, 768).  Else
- * HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
+ * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0;
+ * streaming: C in {512, 768} with whole streams tiling 32 columns; offline: C in {256, 384, 512} (C = 768: one block per launch,
+ * the carry slots of a second do not fit LDS); nblk = 2, or 3 at the decoder's widths (96, 192, streaming 768, offline 384).
+ * Else HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
 typedef struct hilc_resblock_params {
   const float* w1t; const float* dw1_w; const float* dw1_b;
   const float* w2t; const float* dw2_w; const float* dw2_b;
@@ -198,7 +199,7 @@ typedef struct hilc_resblock_params {
 } hilc_resblock_params;
 int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming);
 int hilc_resblock_chain_row_classes(int C);           /* streaming form */
-int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming = 0: hilc_resblock semantics, C in {64, 96, 128, 192}) */
+int hilc_resblock_chain_row_classes_offline(int C);   /* offline form (streaming = 0: hilc_resblock semantics, C in {64 ... 768}) */
 int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int C, int row_classes, void* stream);
 int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* blocks, int nblk, int streaming,
                         int B, int C, int T, void* stream);
@@ -209,7 +210,8 @@ int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* bl
  * (`causal_layers.py:168-188`).  Equals hilc_up_conv_stream followed by hilc_resblock_chain bit for bit; the `[B][C][T]` tensor
  * between them never exists.  x `[B][2C][T/r]`, tr_w `[2C][2r]`, w_lo / w_hi: rows [0, C) / [C, 2C) of the k-major `[2C][C]`
  * pointwise weight, each packed with hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C)).
- * Stages: C = 768 with r = 8 (streaming only: whole streams per 32-column tile, T in {8, 16, 32}), C = 192 with r = 4 and C = 96 with
+ * Stages: C = 768 with r = 8 (streaming: whole streams per 32-column tile, T in {8, 16, 32}, nblk 1..3; offline: nblk = 1 — the
+ * up-sampling layer and the stage's FIRST block, the carry slots of a second do not fit LDS), C = 192 with r = 4 and C = 96 with
  * r = 2 (streaming hops and, with streaming = 0, the offline model: hist* ignored); nblk 1..3. */
 typedef struct hilc_up_params {
   const float* x; const float* tr_w; const float* w_lo; const float* w_hi; const float* bias;
