@@ -40,6 +40,7 @@ extern "C" int hilc_resblock_chain_row_classes(int C) {
   static_assert(Cfg<64, true, false, true, 2, false>::RH == 1 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
                 Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
                 Cfg<512, true, false, false, 2, false>::RH == 8 && Cfg<768, true, false, false, 3, false>::RH == 8, "packed layout");
+  if (C == 256 || C == 384) return 4;       // (no chain of theirs in a hop; the stage entry points' packed up- / down-sampling halves)
   return C >= 512 ? 8 : ((C == 96 || C == 64) ? 1 : (chain_width(C) ? 2 : 0));
 }
 
@@ -137,6 +138,7 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
 extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
   if (nblk < 1 || nblk > 3 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
   if (C == 768) return stride == 8 && (streaming ? 32 % T == 0 : nblk == 1);      // whole streams per 32-column tile; offline: carry form, up-sampling layer + FIRST block (LDS)
+  if (C == 384) return stride == 5 && !streaming;      // offline carry form (r = 5: up->tr_w = the EXPANDED tap table of hilc_up_conv_expand_taps)
   return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
@@ -166,5 +168,6 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
     }
   }
   if (C == 768) return launch_chain<768, false, 1, false, -8>(a, B, s);
+  if (C == 384) return launch_chain<384, false, 3, false, -5>(a, B, s);
   return C == 192 ? launch_chain<192, false, 3, false, -4>(a, B, s) : launch_chain<96, false, 3, false, -2>(a, B, s);
 }

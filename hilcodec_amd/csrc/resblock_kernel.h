@@ -99,8 +99,8 @@ struct Cfg {
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
   static_assert(DR_ <= 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
-  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && C >= 512) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
-                "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form) or the carry form (r = 4 / 2)");
+  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && C >= 512) || (DR_ == -5 && C == 384) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
+                "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form), the C = 384 stage (r = 5) or the carry form (r = 4 / 2)");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
@@ -768,8 +768,13 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
           // r = 8 / 4: the lane's 4 columns share one input frame q0 (phases p0 .. p0 + 3); r = 2: they are frames q0, q0, q0 + 1, q0 + 1
           // (phases 0, 1, 0, 1) — the same cases as UpB<R> in gemm_lin.h.
           constexpr int UB = RW % 6 == 0 ? 6 : RB;
+          // r = 5 (any stride that does not divide 4 columns into whole frames): the EXPANDED tap table of hilc_up_conv_expand_taps,
+          // `[2C][r][8]` — for the phase p0 = t mod r of a 4-column group its eight taps as two 16-B words — and three input frames per
+          // row (q0 - 1, q0, q0 + 1): column e belongs to frame q0 + 1 where p0 + e >= r.  The expression of UpB<1> (gemm_lin.h).
+          constexpr bool UEXP = UR == 5;
           lptr_t xp = (lptr_t)(X + rsub * XS + c4);
           const bool has_prev = cs.t_in && q0 >= 1;        // (offline: a group past the clip's end keeps its t)
+          [[maybe_unused]] const bool has_next = cs.t_in && q0 + 1 < Tin;
 #pragma unroll
           for (int i0 = 0; i0 < RW; i0 += UB) {
             float xc[UB], xq[UB];
@@ -787,6 +792,11 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
               if constexpr (UR == 2) {
                 xn[i] = xi[cs.t_in ? 1 : 0];                       // T % 4 == 0 and r = 2: frame q0 + 1 exists wherever the group does
                 wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * 4);          // (w0, w1 | w2, w3)
+              } else if constexpr (UEXP) {
+                xn[i] = xi[has_next ? 1 : 0];
+                const float* tw = up.tr_w + ((long)k * UR + p0) * 8;
+                wa[i] = *reinterpret_cast<const f32x4*>(tw);
+                wb[i] = *reinterpret_cast<const f32x4*>(tw + 4);
               } else {
                 wa[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + p0);
                 wb[i] = *reinterpret_cast<const f32x4*>(up.tr_w + k * (2 * UR) + UR + p0);
@@ -805,6 +815,14 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
                 u[2] = fmaf(wa[i].x, a2, wa[i].z * a1);
                 u[3] = fmaf(wa[i].y, a2, wa[i].w * a1);
                 a_last = a2;
+              } else if constexpr (UEXP) {
+                const float a2 = has_next ? prologue(xn[i], up.in_scale, 1) : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const bool nx = p0 + e >= UR;
+                  u[e] = fmaf(wa[i][e], nx ? a2 : a1, wb[i][e] * (nx ? a1 : a0));
+                }
+                a_last = p0 + 3 >= UR ? a2 : a1;
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u[e] = fmaf(wa[i][e], a1, wb[i][e] * a0);

@@ -243,7 +243,7 @@ def finalize_spec(spec, streaming: bool = False):
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
             c = st.pw_wt.shape[1]
-            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8, 192: 4, 96: 2}.get(c, 0) == st.ratio
+            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8, 384: 0 if streaming else 5, 192: 4, 96: 2}.get(c, 0) == st.ratio
                     and all(rb.pw1_chain is not None for rb in st.blocks)):
                 st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous(), streaming)
                 st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous(), streaming)
@@ -659,9 +659,10 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_chain_blocks
               and st.up_lo is not None and st.pw_b is not None and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
                                                                  and rb.dw1_b is not None and rb.dw2_b is not None for rb in st.blocks)
-              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0], streaming=False)):
+              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0], streaming=False)
+              and (st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.offline_wide_blocks)):
             x = ops.decoder_stage(
-                x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                x, (st.tr_w if st.taps is None else st.taps, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
                 [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks])
             ci += 1 + 2 * len(st.blocks)
             continue

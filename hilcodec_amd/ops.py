@@ -942,7 +942,7 @@ def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
     """mirror of hilc_resblock_chain_row_classes(_offline): the row split of the packed weights a chain launch reads"""
     if not streaming:
         return 8 if C in (512, 768) else (4 if C in (256, 384) else (2 if C in (128, 192) else 1))
-    return 8 if C >= 512 else (1 if C in (64, 96) else 2)
+    return 8 if C >= 512 else (4 if C in (256, 384) else (1 if C in (64, 96) else 2))
 
 
 def resblock_chain_pack(wt: Tensor, streaming: bool = True) -> Tensor:
@@ -981,13 +981,16 @@ def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
         return False
     if C == 768:
         return stride == 8 and (32 % T == 0 if streaming else nblk == 1)
+    if C == 384:
+        return stride == 5 and not streaming
     return (C == 192 and stride == 4) or (C == 96 and stride == 2)
 
 
 def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: Optional[Sequence[Sequence[Tensor]]] = None,
                   up_hist: Optional[Tensor] = None, hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None,
                   up_hist_out: Optional[Tensor] = None):
-    """A decoder stage of a streaming hop in ONE launch (hilc_decoder_stage): its up-sampling layer `up` = (tr_w `[2C,2r]`, w_lo, w_hi,
+    """A decoder stage in ONE launch (hilc_decoder_stage): its up-sampling layer `up` = (tr_w `[2C,2r]` — stride 5: the EXPANDED table of
+    `up_conv_taps` —, w_lo, w_hi,
     bias `[C]`, in_scale, stride) — w_lo / w_hi = the two ROW halves of the k-major `[2C,C]` pointwise weight packed with
     `resblock_chain_pack` — and its residual blocks (`blocks[i]`, `hist[i]`, `hist_out[i]` as in `resblock_chain`).
     xin `[B,2C,T/r]`, up_hist `[B,2C,1]` -> (y `[B,C,T]`, [block caches...], up-sampling cache); hist None: the offline model -> y."""

@@ -629,7 +629,8 @@ def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n
 
 
 @pytest.mark.parametrize("C,r,Tin,B", [(192, 4, 3000, 3), (96, 2, 12000, 2), (192, 4, 31, 40), (96, 2, 300, 70), (96, 2, 12000, 24),
-                                       (768, 8, 75, 3), (768, 8, 75, 300), (768, 8, 2, 50), (768, 8, 301, 2)])
+                                       (768, 8, 75, 3), (768, 8, 75, 300), (768, 8, 2, 50), (768, 8, 301, 2),
+                                       (384, 5, 600, 3), (384, 5, 600, 40), (384, 5, 4, 300), (384, 5, 232, 5), (384, 5, 8, 1)])
 def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
     """hilc_decoder_stage with streaming = 0 (`seanet.py:431-452`): the up-sampling layer and the three residual blocks of a narrow
     decoder stage of the OFFLINE model in one launch == hilc_up_conv followed by hilc_resblock block by block.  The widest stage
@@ -648,7 +649,8 @@ def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
     tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
     wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)
     bu = (rnd(82, C) * 0.1).to(dev)
-    up = (tw, ops.resblock_chain_pack(wu[:C].contiguous(), False), ops.resblock_chain_pack(wu[C:].contiguous(), False), bu, 0.7071, r)
+    taps = ops.up_conv_taps(tw, r)                       # r = 5: the expanded table
+    up = (tw if taps is None else taps, ops.resblock_chain_pack(wu[:C].contiguous(), False), ops.resblock_chain_pack(wu[C:].contiguous(), False), bu, 0.7071, r)
     xin = rnd(100, B, 2 * C, Tin).to(dev)
     y = ops.decoder_stage(xin, up, blocks)
     y2 = ops.up_conv(xin, tw, wu, bu, r, in_scale=0.7071, in_elu=True)
