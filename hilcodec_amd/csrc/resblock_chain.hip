@@ -138,7 +138,9 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
 extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
   if (nblk < 1 || nblk > 3 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
   if (C == 768) return stride == 8 && (streaming ? 32 % T == 0 : nblk == 1);      // whole streams per 32-column tile; offline: carry form, up-sampling layer + FIRST block (LDS)
-  if (C == 384) return stride == 5 && !streaming;      // offline carry form (r = 5: up->tr_w = the EXPANDED tap table of hilc_up_conv_expand_taps)
+  // r = 5: up->tr_w = the EXPANDED tap table of hilc_up_conv_expand_taps.  Offline: carry form, the whole stage; a streaming hop: the
+  // halo form of the wide blocks (64-column flat tiles), the up-sampling layer + the stage's FIRST block
+  if (C == 384) return stride == 5 && (!streaming || nblk == 1);
   return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
@@ -163,6 +165,7 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
   if (streaming) {
     switch (C) {
       case 768: return launch_chain<768, true, 3, false, -8>(a, B, s);
+      case 384: return launch_chain<384, true, 1, false, -5>(a, B, s);
       case 192: return launch_chain<192, true, 3, false, -4>(a, B, s);
       default: return launch_chain<96, true, 3, false, -2>(a, B, s);
     }

@@ -49,6 +49,7 @@ class ExecOptions:
     fuse_decoder_stage_narrow: bool = True  # ... the carry-form stages (C = 192 / 96) too.  PipelinedHop captures with False: next to a second chain the long
                                             # one-workgroup-per-CU launches leave it nothing to co-reside with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90)
     fuse_decoder_stage: bool = True        # decoder stages with C = 192 / 96 (a streaming hop: also C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
+    fuse_decoder_stage_partial: bool = True  # ... and where LDS holds one block only behind the up-sampling phase (offline C = 768, streaming C = 384): up-sampling layer + FIRST block
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_wide_blocks: bool = True       # offline: the wide residual blocks (C = 256 ... 768) as ONE carry-form launch each / per stage (False: two hilc_dws_conv launches per block, as until round 4)
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
@@ -216,7 +217,7 @@ def finalize_block(rb: "ResBlockSpec", streaming: bool = False) -> "ResBlockSpec
             and (narrow or c in STREAM_WIDE_C)):
         rb.pw1_packed = ops.resblock_pack(rb.pw1_wt)
         rb.pw2_packed = ops.resblock_pack(rb.pw2_wt)
-    if rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or c in ((512, 768) if streaming else STREAM_WIDE_C)):
+    if rb.pw1_packed is not None and rb.pw1_chain is None and (c <= FUSE_RESBLOCK_MAX_C or c in STREAM_WIDE_C):
         same = ops.resblock_chain_row_classes(c, streaming) == (8 if c >= 512 else (4 if c >= 256 else (2 if c == 192 else 1)))     # hilc_resblock_pack_weights' own split
         rb.pw1_chain = rb.pw1_packed if same else ops.resblock_chain_pack(rb.pw1_wt, streaming)
         rb.pw2_chain = rb.pw2_packed if same else ops.resblock_chain_pack(rb.pw2_wt, streaming)
@@ -243,7 +244,7 @@ def finalize_spec(spec, streaming: bool = False):
         if isinstance(st, DecStageSpec) and st.tr_w.device.type in ("cuda", "meta"):
             st.taps = ops.up_conv_taps(st.tr_w, st.ratio)
             c = st.pw_wt.shape[1]
-            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8, 384: 0 if streaming else 5, 192: 4, 96: 2}.get(c, 0) == st.ratio
+            if (st.up_lo is None and st.pw_wt.shape[0] == 2 * c and {768: 8, 384: 5, 192: 4, 96: 2}.get(c, 0) == st.ratio
                     and all(rb.pw1_chain is not None for rb in st.blocks)):
                 st.up_lo = ops.resblock_chain_pack(st.pw_wt[:c].contiguous(), streaming)
                 st.up_hi = ops.resblock_chain_pack(st.pw_wt[c:].contiguous(), streaming)
@@ -373,6 +374,21 @@ def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Se
         x = _resblock(rb, x, caches[ci + 2 * i: ci + 2 * i + 2] if streaming else None, new_caches,
                       caches_out[ci + 2 * i: ci + 2 * i + 2] if caches_out is not None else None, x3=x3, opts=opts)
     return x
+
+
+def _stage_fusable_blocks(st: "DecStageSpec", x: Tensor, streaming: bool, partial: bool = True) -> int:
+    """How many of a decoder stage's residual blocks run in ONE launch with its up-sampling layer (`ops.decoder_stage`): all of them, the
+    first one (where LDS holds the carry slots / the halo form of one block only), or 0 = no stage launch for this shape."""
+    if st.up_lo is None or st.pw_b is None or not st.blocks:
+        return 0
+    if not all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+               and rb.dw2_b is not None for rb in st.blocks):
+        return 0
+    c, t = st.pw_wt.shape[1], x.shape[2] * st.ratio
+    for nb in ((len(st.blocks), 1) if partial else (len(st.blocks),)):
+        if ops.decoder_stage_supported(c, t, nb, st.ratio, x.shape[0], streaming=streaming):
+            return nb
+    return 0
 
 
 def _spec_fused(sb: SpecBlockSpec, wav: Tensor, wav_hist: Optional[Tensor]) -> bool:
@@ -627,21 +643,23 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
                                   hist=caches[ci], want_hist=True, hist_out=out(ci))
             new_caches.append(c)
         elif (streaming and not x3 and FUSE_STREAM and FUSE_RESBLOCK and opts.fuse_decoder_stage and opts.stream_chain_blocks
-              and st.up_lo is not None and st.pw_b is not None
-              and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
-                      and rb.dw2_b is not None for rb in st.blocks)
-              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0])
-              and (opts.fuse_decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.stream_wide_blocks)):
+              and (opts.fuse_decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.stream_wide_blocks)
+              and _stage_fusable_blocks(st, x, True, opts.fuse_decoder_stage_partial) > 0):
             # the whole stage — up-sampling layer and residual blocks — is one launch; the tensor between them never exists
-            nb = len(st.blocks)
+            # (C = 384: the up-sampling layer and the FIRST block; the other two follow as launches of their own)
+            nb = _stage_fusable_blocks(st, x, True, opts.fuse_decoder_stage_partial)
+            up_w = st.tr_w if st.taps is None else st.taps
             x, cs_, c = ops.decoder_stage(
-                x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
-                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks],
+                x, (up_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks[:nb]],
                 [caches[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)], caches[ci],
                 [caches_out[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)] if caches_out is not None else None, out(ci))
             new_caches.append(c)
             new_caches.extend(cs_)
             ci += 1 + 2 * nb
+            if nb < len(st.blocks):
+                x = _stage_blocks(st.blocks[nb:], x, caches, ci, new_caches, caches_out, x3, opts)
+                ci += 2 * (len(st.blocks) - nb)
             continue
         elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0 and tails is not None:
             # (the transposed conv's new cache = its last ACTIVATED input frame: with the other stages' and conv_post's in one launch)
@@ -657,25 +675,14 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             new_caches.append(c)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
         elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_chain_blocks
-              and st.up_lo is not None and st.pw_b is not None and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-                                                                 and rb.dw1_b is not None and rb.dw2_b is not None for rb in st.blocks)
-              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, len(st.blocks), st.ratio, x.shape[0], streaming=False)
-              and (st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.offline_wide_blocks)):
+              and (st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.offline_wide_blocks) and _stage_fusable_blocks(st, x, False, opts.fuse_decoder_stage_partial) > 0):
+            # (the widest stage, C = 768: its carry slots leave LDS room for ONE block behind the up-sampling phase; the other blocks follow)
+            nb = _stage_fusable_blocks(st, x, False, opts.fuse_decoder_stage_partial)
             x = ops.decoder_stage(
                 x, (st.tr_w if st.taps is None else st.taps, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
-                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks])
-            ci += 1 + 2 * len(st.blocks)
-            continue
-        elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_wide_blocks
-              and st.up_lo is not None and st.pw_b is not None and len(st.blocks) >= 1 and st.blocks[0].pw1_chain is not None
-              and st.blocks[0].dw1_w.shape[1] == 5 and st.blocks[0].dw2_w.shape[1] == 5 and st.blocks[0].dw1_b is not None
-              and st.blocks[0].dw2_b is not None
-              and ops.decoder_stage_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, 1, st.ratio, x.shape[0], streaming=False)):
-            # the widest stage (C = 768): its carry slots leave LDS room for ONE block behind the up-sampling phase; the other blocks follow
-            rb = st.blocks[0]
-            x = ops.decoder_stage(x, (st.tr_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
-                                  [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)])
-            x = _stage_blocks(st.blocks[1:], x, None, 0, None, None, x3, opts)
+                [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks[:nb]])
+            if nb < len(st.blocks):
+                x = _stage_blocks(st.blocks[nb:], x, None, 0, None, None, x3, opts)
             ci += 1 + 2 * len(st.blocks)
             continue
         elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0]):

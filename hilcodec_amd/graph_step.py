@@ -261,8 +261,8 @@ class PipelinedHop:
         # beside the encoder's chain the narrow decoder stages stay chain + separate up-sampling launch (same results): their
         # one-launch form holds every CU with one long workgroup and leaves the other chain nothing to co-reside with (measured:
         # pipelined 4.72 ms without, 4.82 with; the plain graph gains 0.15 ms from it).  Context-local override, nothing is written
-        # into the model's options.
-        with ops.sched_workspace(self.sched_dec[g]), engine.exec_overrides(fuse_decoder_stage_narrow=False):
+        # into the model's options.  The same holds for the C = 384 stage's up-sampling layer + first block (4.716 vs 4.73 - 4.76 ms).
+        with ops.sched_workspace(self.sched_dec[g]), engine.exec_overrides(fuse_decoder_stage_narrow=False, fuse_decoder_stage_partial=False):
             wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1][:, lo:hi].contiguous(), self.n), *st[p ^ 1].dec,
                                cache_out=st[p].dec)
         return wav

@@ -982,7 +982,7 @@ def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
     if C == 768:
         return stride == 8 and (32 % T == 0 if streaming else nblk == 1)
     if C == 384:
-        return stride == 5 and not streaming
+        return stride == 5 and (not streaming or nblk == 1)
     return (C == 192 and stride == 4) or (C == 96 and stride == 2)
 
 

@@ -588,10 +588,12 @@ def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
 
 @pytest.mark.parametrize("C,r,Tin,B,n", [(768, 8, 1, 37, 3), (768, 8, 1, 1024, 3), (768, 8, 2, 9, 3), (768, 8, 4, 5, 2), (768, 8, 1, 3, 1),
                                           (192, 4, 40, 7, 3), (192, 4, 40, 1024, 3), (96, 2, 160, 5, 3), (96, 2, 160, 1024, 3), (192, 4, 80, 3, 2),
-                                          (96, 2, 2, 70, 3), (192, 4, 1, 33, 3)])
+                                          (96, 2, 2, 70, 3), (192, 4, 1, 33, 3), (384, 5, 8, 19, 1), (384, 5, 8, 1024, 1), (384, 5, 8, 1, 1), (384, 5, 16, 5, 1),
+                                          (384, 5, 4, 3, 1)])
 def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n):
     """hilc_decoder_stage (a decoder stage of a streaming hop — `streaming.py:629-639` — in one launch: C = 768 / r = 8 on whole-stream
-    tiles, C = 192 / r = 4 and C = 96 / r = 2 in the carry form) == hilc_up_conv_stream followed by the residual blocks (chain), bit
+    tiles, C = 192 / r = 4 and C = 96 / r = 2 in the carry form, C = 384 / r = 5: the up-sampling layer + the first block on 64-column flat
+    tiles with a halo) == hilc_up_conv_stream followed by the residual blocks (chain), bit
     for bit over three hops: output, the up-sampling cache and the 2n block caches."""
     ops, fold, O, dev = env
     T = Tin * r
@@ -605,7 +607,8 @@ def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n
     tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
     wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)                 # k-major [2C][C]
     bu = (rnd(82, C) * 0.1).to(dev)
-    up = (tw, ops.resblock_chain_pack(wu[:C].contiguous()), ops.resblock_chain_pack(wu[C:].contiguous()), bu, 0.7071, r)
+    taps = ops.up_conv_taps(tw, r)                      # r = 5: the expanded table
+    up = (tw if taps is None else taps, ops.resblock_chain_pack(wu[:C].contiguous()), ops.resblock_chain_pack(wu[C:].contiguous()), bu, 0.7071, r)
     ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
     cb = [[c.clone() for c in pair] for pair in ca]
     ua = (rnd(30, B, 2 * C, 1) * 0.6).to(dev)
