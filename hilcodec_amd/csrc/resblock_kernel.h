@@ -537,9 +537,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
   // plain base + constant address instead of a select
   __shared__ __attribute__((aligned(16))) float Xbuf[4 + C * XS];
-  // tap tables: all blocks of a chain resident (loaded once per workgroup), except for the NARROW shapes (C >= 256: 12 - 36 KB per
-  // block), which reload the one table at the start of every block (a workgroup walks 1-3 tiles there)
-  constexpr bool DW_RELOAD = NB > 1 && K::NARROW;
+  // tap tables: all blocks of a chain resident (loaded once per workgroup) — except where the NARROW shapes' tables (C >= 256: 12 - 36 KB
+  // per block) do not fit beside the tile (C = 384 x 3 offline, C = 768 x 3 in a hop): those reload the one table at the start of every block
+  constexpr bool DW_RELOAD = NB > 1 && K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024;
   __shared__ __attribute__((aligned(16))) float DW[(DW_RELOAD ? 1 : NB) * C * DWS];
   __shared__ __attribute__((aligned(16))) float DWD[DR > 0 ? 2 * C * DDS : 4];
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
@@ -562,14 +562,40 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
   const int nblk = NB == 1 ? 1 : a.nblk;                 // uniform; NB == 1: the block loop below folds away
   // depthwise taps / biases -> LDS once per workgroup (read back as half-wave broadcasts in P3 / P6)
   auto load_taps = [&](const ResBlk& bq, float* dst) {
-    for (int e = tid; e < C * DWS; e += NT) {
-      const int m = e / DWS, j = e - m * DWS;
-      float v;
-      if (j < 5) v = bq.dw1_w[m * 5 + j];
-      else if (j == 5) v = bq.dw1_b[m];
-      else if (j < 11) v = bq.dw2_w[m * 5 + (j - 6)];
-      else v = bq.dw2_b[m];
-      dst[e] = v;
+    if constexpr (DW_RELOAD && !STREAM) {
+      // (inside the tile loop) one load per element through a SELECTED address — four branches are four exec-mask regions with a load
+      // and a wait each — and a compile-time trip count: all of a thread's loads are in flight together.  (Only here: in the streaming
+      // instantiations, which sit at 256 registers, the loads in flight spill.)
+      constexpr int NE = C * DWS;
+      static_assert(NE % NT == 0, "whole rounds");
+#pragma unroll
+      for (int i = 0; i < NE / NT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / DWS, j = e - m * DWS;
+        const float* src = j < 5 ? bq.dw1_w + (m * 5 + j) : (j == 5 ? bq.dw1_b + m : (j < 11 ? bq.dw2_w + (m * 5 + (j - 6)) : bq.dw2_b + m));
+        dst[e] = *src;
+      }
+    } else if constexpr (DW_RELOAD) {
+      // (the streaming reload kernels sit at 256 registers: the same selected address, three loads in flight)
+      constexpr int NE = C * DWS;
+      static_assert(NE % NT == 0, "whole rounds");
+#pragma unroll 3
+      for (int i = 0; i < NE / NT; ++i) {
+        const int e = tid + i * NT;
+        const int m = e / DWS, j = e - m * DWS;
+        const float* src = j < 5 ? bq.dw1_w + (m * 5 + j) : (j == 5 ? bq.dw1_b + m : (j < 11 ? bq.dw2_w + (m * 5 + (j - 6)) : bq.dw2_b + m));
+        dst[e] = *src;
+      }
+    } else {
+      for (int e = tid; e < C * DWS; e += NT) {
+        const int m = e / DWS, j = e - m * DWS;
+        float v;
+        if (j < 5) v = bq.dw1_w[m * 5 + j];
+        else if (j == 5) v = bq.dw1_b[m];
+        else if (j < 11) v = bq.dw2_w[m * 5 + (j - 6)];
+        else v = bq.dw2_b[m];
+        dst[e] = v;
+      }
     }
   };
   if constexpr (!DW_RELOAD) {
