@@ -185,6 +185,160 @@ __global__ __launch_bounds__(NTH) void rvq_encode_kernel(RvqArgs a) {
   }
 }
 
+// ---- large batches: the scores on the matrix pipe --------------------------------------------------------------------------------
+// One workgroup (4 waves) owns 32 frames; per stage the score matrix <e_k, r_f> is a [1024 codes] x [32 frames] GEMM over the 128
+// channels on v_mfma_f32_32x32x2_f32: wave w scores codes 256 w .. 256 w + 255 as eight 32-row tiles, tile i's row m = code
+// 256 w + 8 m + i — so the A operand of a k-pair (channels 2p, 2p + 1) is two 16-B words per lane straight from the TRANSPOSED
+// codebook `[C][K]` (a half-wave reads 1 KB contiguous), no packed copy — and the B operand is the residual tile in LDS.
+// The fp32 MFMA accumulates exactly like an fmaf chain over k in ascending order, the products commute: every score has the bits
+// of rvq_encode_kernel's `fmaf(r, e, acc)` chain, so distances, arg-mins and therefore indices are identical (tests/test_gpu_rvq.py).
+// The arg-min visits a lane's 128 codes in ascending order (strict <), then combines lexicographically (distance, index) across the
+// two half-waves and the four waves: the lowest index among equal distances, like torch's `min(dim)`.
+template <int C>
+__global__ __launch_bounds__(256, 2) void rvq_encode_mfma_kernel(RvqArgs a) {
+  constexpr int FR = 32, NTH = 256, NWV = 4, XS = 33, DEPTH = 4;     // XS: row stride of the [c][frame] tiles (column accesses conflict-free)
+  __shared__ float res[C * XS];
+  __shared__ float qsum[C * XS];
+  __shared__ float wbest[NWV][FR];
+  __shared__ int widx[NWV][FR];
+  __shared__ int sel[FR];
+  __shared__ int nfr[FR];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long nframes = (long)a.B * a.T;
+  const long g0 = (long)blockIdx.x * FR;
+
+  for (int e = tid; e < FR * C; e += NTH) {
+    int f, c;
+    if (a.channel_last) { c = e % C; f = e / C; } else { f = e % FR; c = e / FR; }      // coalesced either way
+    const long g = g0 + f;
+    res[c * XS + f] = g < nframes ? a.z[zoff(a, g, c)] : 0.f;
+    qsum[c * XS + f] = 0.f;
+  }
+  if (tid < FR) {
+    const long g = g0 + tid;
+    int nf = a.n;
+    if (a.n_clip != nullptr && g < nframes) {
+      nf = a.n_clip[g / a.T];
+      nf = nf < 1 ? 1 : (nf > a.n ? a.n : nf);
+    }
+    nfr[tid] = nf;
+  }
+  __syncthreads();
+
+  typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+  for (int s = 0; s < a.n; ++s) {
+    const float* cb = a.cb + (long)s * a.K * C;
+    const float* nrm = a.norms + (long)s * a.K + 256 * wave;
+    // this lane's eight codes of channel row 2p + h: cbt[s][2p + h][256 w + 8 l31 .. + 7]
+    const float* ap = a.cbt + (long)s * C * a.K + (long)h * a.K + 256 * wave + 8 * l31;
+    const float* bp = res + h * XS + l31;
+    f32x16 acc[8];
+    f32x4 wa[DEPTH][2];
+    float b[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) {
+      wa[d][0] = *(gvec_t)(ap + (long)(2 * d) * a.K);
+      wa[d][1] = *(gvec_t)(ap + (long)(2 * d) * a.K + 4);
+      b[d] = bp[2 * d * XS];
+    }
+#pragma unroll
+    for (int p = 0; p < C / 2; ++p) {
+      const int cur = p % DEPTH, nxt = (p + DEPTH - 1) % DEPTH;
+      if (p + DEPTH - 1 < C / 2) {
+        wa[nxt][0] = *(gvec_t)(ap + (long)(2 * (p + DEPTH - 1)) * a.K);
+        wa[nxt][1] = *(gvec_t)(ap + (long)(2 * (p + DEPTH - 1)) * a.K + 4);
+        b[nxt] = bp[2 * (p + DEPTH - 1) * XS];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (p == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][i >> 2][i & 3], b[cur], acc[i], 0, 0, 0);
+      }
+      // pin the k-pair (see gemm_phase in resblock_kernel.h: the builtins are pure and would be sunk below every later load)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
+    }
+
+    // arg-min over this lane's 128 codes, ascending: MFMA row m = 8 (r >> 2) + (r & 3) + 4 h of tile i is code 256 w + 8 m + i
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 8 * (r >> 2) + (r & 3) + 4 * h;
+      const f32x4 n0 = *(gvec_t)(nrm + 8 * m), n1 = *(gvec_t)(nrm + 8 * m + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = fmaf(-2.f, acc[i][r], i < 4 ? n0[i & 3] : n1[i & 3]);
+        const int code = 256 * wave + 8 * m + i;
+        if (r == 0 && i == 0) { best = d; bi = code; }
+        else if (d < best) { best = d; bi = code; }          // ascending index order, strict <
+      }
+    }
+    {
+      const float od = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    if (h == 0) { wbest[wave][l31] = best; widx[wave][l31] = bi; }
+    __syncthreads();
+    if (tid < FR) {
+      float bb = wbest[0][tid];
+      int bj = widx[0][tid];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) {
+        const float od = wbest[w][tid];
+        const int oi = widx[w][tid];
+        if (od < bb || (od == bb && oi < bj)) { bb = od; bj = oi; }
+      }
+      if (s >= nfr[tid]) bj = -1;   // this clip stops before stage s: no code, residual and sum untouched
+      sel[tid] = bj;
+      const long g = g0 + tid;
+      if (g < nframes) {
+        const long bq = g / a.T, t = g - bq * a.T;
+        const long off = a.stage_major ? ((long)s * a.B + bq) * a.T + t : (bq * a.n + s) * (long)a.T + t;
+        a.indices[off] = bj;
+      }
+    }
+    __syncthreads();
+    // residual -= E[idx]; quantized_out += E[idx]   (vector_quantize.py:225-229)
+    for (int e = tid; e < FR * C; e += NTH) {
+      const int c = e % C, f = e / C;
+      const int k = sel[f];
+      if (k >= 0) {
+        const float qv = cb[(long)k * C + c];
+        res[c * XS + f] = res[c * XS + f] - qv;
+        qsum[c * XS + f] = qsum[c * XS + f] + qv;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.q != nullptr) {
+    for (int e = tid; e < FR * C; e += NTH) {
+      int f, c;
+      if (a.channel_last) { c = e % C; f = e / C; } else { f = e % FR; c = e / FR; }
+      const long g = g0 + f;
+      if (g < nframes) a.q[zoff(a, g, c)] = qsum[c * XS + f];
+    }
+  }
+  if (a.frame_err != nullptr && tid < FR) {
+    const long g = g0 + tid;
+    if (g < nframes) {
+      float err = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float d = a.z[zoff(a, g, c)] - qsum[c * XS + tid];
+        err = fmaf(d, d, err);
+      }
+      a.frame_err[g] = err;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void mse_finalize_kernel(const float* frame_err, float* loss, int frames,
                                                            double count) {
   __shared__ double part[256];
@@ -355,7 +509,12 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   // small batches (a streaming hop: 1024 frames): 4 frames per workgroup = one workgroup per CU, 512 threads x 2 codes = two waves per
   // SIMD to hide the L2 round trips of the code words (256 x 4: 143 us, 512 x 2: 96 us, 1024 x 1: 107 us; 8 / 16 frames per
   // workgroup: 240 / 369 us — profiles/r04_experiments.md)
-  if (nframes <= 16 * 512)
+  // large batches: the score GEMM on the matrix pipe, 32 frames per workgroup (two workgroups per CU; HILC_RVQ_VALU=1 in the environment
+  // keeps the VALU form for A/B runs)
+  static const bool valu_only = getenv("HILC_RVQ_VALU") != nullptr;
+  if (nframes >= 32 * 256 && !valu_only)
+    hipLaunchKernelGGL((rvq_encode_mfma_kernel<128>), dim3((unsigned)((nframes + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
+  else if (nframes <= 16 * 512)
     hipLaunchKernelGGL((rvq_encode_kernel<128, 4, 512>), dim3((unsigned)((nframes + 3) / 4)), dim3(512), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((rvq_encode_kernel<128, 16>), dim3((unsigned)((nframes + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);

@@ -101,6 +101,40 @@ def test_rvq_vs_oracle(B, Tn, nq):
         assert abs(float(loss) - float(loss_o)) <= 2e-6 * float(loss_o)
 
 
+@pytest.mark.parametrize("B,Tn,nq,mixed", [(256, 75, 8, False), (120, 75, 12, True), (9, 1001, 8, False), (256, 75, 3, True)])
+def test_rvq_large_batches_on_the_matrix_pipe_equal_small_ones(B, Tn, nq, mixed):
+    """From 8 192 frames on hilc_rvq_encode scores on the matrix pipe (32 frames per workgroup, v_mfma_f32_32x32x2_f32 = the VALU form's
+    fmaf chain over the channels in the same order): indices, quantised sum and loss equal, bit for bit, the same clips encoded in
+    chunks small enough for the VALU form — both layouts, per-clip stage counts, frame counts that are no multiple of 32 — and
+    the oracle on a sample of the clips."""
+    from hilcodec_amd import fold, ops
+    from oracle import hilcodec_oracle as O
+    dev = torch.device("cuda:0")
+    D = 128
+    assert B * Tn >= 8192
+    sd = make_codebooks(23, nq)
+    z = torch.from_numpy(synth.normalish(4242, B * D * Tn)).view(B, D, Tn)
+    z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5
+    cb, cbt, norms = [t.to(dev) for t in fold.codebook_tables([sd[f"quantizer.layers.{i}.embed"] for i in range(nq)])]
+    ns = [1 + (7 * b) % nq for b in range(B)] if mixed else nq
+    zd = z.to(dev)
+    idx, q, loss = ops.rvq_encode(zd, cb, cbt, norms, ns, want_loss=True)
+    chunk = max(1, 4096 // Tn)
+    parts = [ops.rvq_encode(zd[b:b + chunk].contiguous(), cb, cbt, norms, ns[b:b + chunk] if mixed else nq, want_loss=True)
+             for b in range(0, B, chunk)]
+    assert torch.equal(idx, torch.cat([p[0] for p in parts])) and torch.equal(q, torch.cat([p[1] for p in parts]))
+    tot = sum(float(p[2]) * min(chunk, B - i * chunk) for i, p in enumerate(parts)) / B
+    assert abs(float(loss) - tot) <= 2e-6 * tot
+    # streaming layout [B,T,C] -> [n,B,T]
+    ids, qs, _ = ops.rvq_encode(z.transpose(1, 2).contiguous().to(dev), cb, cbt, norms, ns, channel_last=True, stage_major=True)
+    assert torch.equal(ids.permute(1, 0, 2), idx) and torch.equal(qs.transpose(1, 2), q)
+    for b in (0, B // 2, B - 1):
+        n = ns[b] if mixed else nq
+        q_o, _, _, idx_o = O.rvq_forward(sd, z[b:b + 1], n, nq)
+        assert check_indices(O, sd, z[b:b + 1], idx[b:b + 1, :n].cpu(), idx_o) == 0
+        assert torch.equal(q[b:b + 1].cpu(), q_o)
+
+
 def test_rvq_modules_reference_api():
     from hilcodec_amd.models.hilcodec.vector_quantize import ResidualVQ
     from hilcodec_amd.modules.vector_quantize import ResidualVQ as LegacyRVQ
