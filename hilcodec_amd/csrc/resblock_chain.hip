@@ -100,9 +100,10 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
 // seanet.py:316-339 (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C (no bias), depthwise conv k = 2r
 // stride r]); streaming.py:497-511.  == hilc_resblock_chain followed by hilc_dws_conv(_stream) with the same arguments, bit for bit.
 extern "C" int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
-  (void)streaming;
-  if (nblk < 1 || nblk > 2 || T <= 0 || T % 4 != 0) return 0;
-  return (C == 64 && stride == 2) || (C == 128 && stride == 4);
+  if (nblk < 1 || nblk > 2 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
+  if ((C == 64 && stride == 2) || (C == 128 && stride == 4)) return 1;
+  // the wide stages of the OFFLINE model (narrow-tile carry form; the strided conv's outputs do not align with 4-column lanes there)
+  return !streaming && ((C == 256 && stride == 5) || (C == 512 && stride == 8));
 }
 
 extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
@@ -127,7 +128,12 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
   hipStream_t s = (hipStream_t)stream;
   if (streaming) return C == 64 ? launch_chain<64, true, 2, false, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
-  return C == 64 ? launch_chain<64, false, 2, false, 2>(a, B, s) : launch_chain<128, false, 2, true, 4>(a, B, s);
+  switch (C) {
+    case 64: return launch_chain<64, false, 2, false, 2>(a, B, s);
+    case 128: return launch_chain<128, false, 2, true, 4>(a, B, s);
+    case 256: return launch_chain<256, false, 2, false, 5>(a, B, s);
+    default: return launch_chain<512, false, 2, false, 8>(a, B, s);
+  }
 }
 
 // ---- a DECODER STAGE of a streaming hop in one launch: its up-sampling layer and its residual blocks -----------------------------

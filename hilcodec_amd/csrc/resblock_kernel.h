@@ -98,7 +98,11 @@ struct Cfg {
   // element, like the loader of hilc_up_conv), two GEMMs accumulate over the 2C rows in k order, + bias -> the x registers.  The
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
-  static_assert(DR_ <= 0 || ((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && !X3_ && C <= 192), "down-sampling phase: carry form, r = 2 / 4");
+  static_assert(DR_ <= 0 || (!X3_ && (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || (!STREAM && ((DR_ == 5 && C == 256) || (DR_ == 8 && C == 512))))),
+                "down-sampling phase: carry form, r = 2 / 4 (C <= 192) or the wide encoder stages of the offline model (C = 256: r = 5, C = 512: r = 8)");
+  // carry columns of the down-sampling phase per half of its 2C rows: the strided conv reads k - r = r columns in front of its first
+  // output's window; r = 2 / 4: the 4 in front of a lane's group; r = 8: 8; r = 5: up to 9 (a tile does not start on a multiple of 5) -> 12
+  static constexpr int DCAR = DR_ <= 0 ? 0 : (DR_ == 5 ? 12 : (DR_ == 8 ? 8 : 4));
   static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && C >= 512) || (DR_ == -5 && C == 384) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
                 "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form), the C = 384 stage (r = 5) or the carry form (r = 4 / 2)");
   static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
@@ -112,7 +116,7 @@ struct Cfg {
   // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
   static constexpr bool NARROW = C >= 256;
   static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + (DR_ > 0 ? 8 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
+  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
   // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
@@ -541,7 +545,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
   // per block) do not fit beside the tile (C = 384 x 3 offline, C = 768 x 3 in a hop): those reload the one table at the start of every block
   constexpr bool DW_RELOAD = NB > 1 && K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024;
   __shared__ __attribute__((aligned(16))) float DW[(DW_RELOAD ? 1 : NB) * C * DWS];
-  __shared__ __attribute__((aligned(16))) float DWD[DR > 0 ? 2 * C * DDS : 4];
+  constexpr bool DWIDE = DR == 5 || DR == 8;            // the wide stages' down-sampling phase: taps straight from global memory (no LDS left)
+  __shared__ __attribute__((aligned(16))) float DWD[(DR > 0 && !DWIDE) ? 2 * C * DDS : 4];
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
   // do not pay one exposed global-load latency per row for the single lane that needs them
   __shared__ __attribute__((aligned(16))) float HS[(STREAM && !K::NARROW) ? 2 * C * 4 : 4];
@@ -601,7 +606,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
   if constexpr (!DW_RELOAD) {
     for (int q = 0; q < nblk; ++q) load_taps(a.blk[q], DW + q * C * DWS);
   }
-  if constexpr (DR > 0) {
+  if constexpr (DR > 0 && !DWIDE) {
     for (int e = tid; e < 2 * C * DDS; e += NT) {
       const int m = e / DDS, j = e - m * DDS;
       DWD[e] = j < 2 * DR ? a.dn.dw_w[m * 2 * DR + j] : (j == 8 ? a.dn.dw_b[m] : 0.f);
@@ -759,7 +764,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
       // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
       // it two barriers from here).  (STREAM: column group 0 of a stream's first tile is a head and takes the cache.)
       if (tile % a.tiles == 0) {
-        constexpr int NSLOT = 2 * NB + (DR > 0 ? 2 : 0);
+        constexpr int NSLOT = 2 * NB + K::DCAR / 2;      // 4-float slots behind a row: H1 / H2 per block + the down-sampling phase's two halves
         for (int e = tid; e < NSLOT * C; e += NT)
           *reinterpret_cast<f32x4*>(X + (e / NSLOT) * XS + K::NCOL + (e % NSLOT) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -1135,7 +1140,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
       asm volatile("" : "+s"(wd0), "+s"(wd1));
       Pipe wp;
       wp.prefetch(wd0, lane);
-      {                                            // D0: ELU(in_scale * y) -> LDS (P0 on the stage's output)
+      auto d0 = [&]() {                            // D0: ELU(in_scale * y) -> LDS (P0 on the stage's output)
         lptr_t xp = (lptr_t)(X + rsub * XS + c4);
 #pragma unroll
         for (int i0 = 0; i0 < RW; i0 += RB) {
@@ -1145,23 +1150,122 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
           xp += RB * RSTEP * XS;
           asm volatile("" : "+v"(xp));
         }
-      }
-      if (have_next) {                             // the x registers are free (no shortcut here): the next tile's rows travel under both GEMMs
+      };
+      d0();
+      if (!DWIDE && have_next) {                   // the x registers are free (no shortcut here): the next tile's rows travel under both GEMMs
 #pragma unroll
         for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
       }
       lds_barrier();
-      f32x16 acc0[CBW], acc1[CBW];
-      gemm_phase<K>(wd0, X, acc0, wp, colblk, lane);
-      wp.prefetch(wd1, lane);
-      gemm_phase<K>(wd1, X, acc1, wp, colblk, lane);
+      // C <= 192: both halves' accumulators live (one operand tile, two GEMMs back to back).  The wide stages have no registers for
+      // that beside the strided conv's windows: one half at a time — GEMM, conv, the operand tile written AGAIN from the x registers
+      // (one more ELU pass: ~1 % of the two GEMMs), GEMM, conv; the next tile's rows then travel under the second GEMM.
+      f32x16 acc0[CBW];
+      [[maybe_unused]] f32x16 acc1[DWIDE ? 1 : CBW];
+      if constexpr (K::NARROW) gemm_phase_rolled<K>(wd0, X, acc0, wp, colblk, lane);
+      else gemm_phase<K>(wd0, X, acc0, wp, colblk, lane);
+      if constexpr (!DWIDE) {
+        wp.prefetch(wd1, lane);
+        if constexpr (K::NARROW) gemm_phase_rolled<K>(wd1, X, acc1, wp, colblk, lane);
+        else gemm_phase<K>(wd1, X, acc1, wp, colblk, lane);
+      }
       const bool out_ok = !warm && (STREAM ? cs.t_in : cs.t < T);
+      [[maybe_unused]] const bool out_ok_tile = !warm;
       const int To = T / DR;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        if constexpr (DWIDE) {
+          if (h == 1) {
+            lds_barrier();                         // the first half's conv has read the tile
+            wp.prefetch(wd1, lane);
+            d0();
+            if (have_next) {
+#pragma unroll
+              for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
+            }
+            lds_barrier();
+            gemm_phase_rolled<K>(wd1, X, acc0, wp, colblk, lane);
+          }
+        }
         lds_barrier();
-        acc_to_x<K>(h ? acc1 : acc0, X, rowblk0, colblk, lane);
+        if constexpr (DWIDE) acc_to_x<K>(acc0, X, rowblk0, colblk, lane);
+        else acc_to_x<K>(h ? acc1 : acc0, X, rowblk0, colblk, lane);
         lds_barrier();
+        if constexpr (DWIDE) {
+          // The wide stages (r = 5 on 64-column tiles, r = 8 on 32-column tiles): outputs do not align with a lane's 4 columns.  Lane
+          // j of a row's lanes computes the row's j-th output of this tile — output o reads the 2r columns [r o - r, r o + r) and
+          // belongs to the tile that holds its LAST column — from the tile and, left of its first column, from the half's carry
+          // slot (the previous tile's last DCAR columns; zeros at a clip's start = the conv's zero padding).  Taps and bias come
+          // from global memory (the same few rows for every workgroup: L1 / L2), k ascending like DwStrideEpilogue: bit-identical.
+          constexpr int DC = K::DCAR;
+          constexpr int DOFF = K::NCOL + 8 * NB;             // the two halves' carry slots behind a row
+          const int jl = c4 >> 2;
+          const int t0 = cs.t - c4;                          // the tile's first column (offline: cs.t = t0 + c4 for every lane)
+          const int o = t0 / DR + jl;
+          const int base = o * DR - DR - t0;                 // local column of the window's first sample: >= -(2 r - 1)
+          const bool act = out_ok_tile && o < To && o * DR + DR - 1 < t0 + K::NCOL;
+          const int slot = DOFF + DC * h + DC;               // column -k of the tile lives at slot - k
+          // one row per (rolled) iteration — unrolled, hipcc keeps every row's addresses and taps alive (31 spilled registers at C = 512) —
+          // with the NEXT row's taps and bias requested before this row's arithmetic
+          lptr_t rowp = (lptr_t)(X + rsub * XS);
+          const float* wrow = dn.dw_w + (long)(h * C + rsub) * (2 * DR);
+          const float* brow = dn.dw_b + (h * C + rsub);
+          float wn[2 * DR], bn;
+          auto taps_of = [&](const float* wr, const float* br) {
+            if constexpr (DR == 8) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wn[4 * q + e] = w4[e];
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < DR; ++q) {
+                const f32x2 w2 = *reinterpret_cast<const f32x2*>(wr + 2 * q);
+                wn[2 * q] = w2.x; wn[2 * q + 1] = w2.y;
+              }
+            }
+            bn = br[0];
+          };
+          taps_of(wrow, brow);
+          long yo = ((long)cs.b * (2 * C) + h * C + rsub) * (long)To + o;
+#pragma nounroll
+          for (int i0 = 0; i0 < RW; ++i0) {
+            float v[2 * DR], w[2 * DR];
+#pragma unroll
+            for (int j = 0; j < 2 * DR; ++j) w[j] = wn[j];
+            const float bb = bn;
+            wrow += RSTEP * (2 * DR);
+            brow += RSTEP;
+            if (i0 + 1 < RW) taps_of(wrow, brow);
+            if constexpr (DR == 8) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int col = base + 4 * q;
+                const f32x4 x4 = *(lvec_t)(rowp + (col >= 0 ? col : slot + col));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = x4[e];
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 2 * DR; ++j) {
+                const int col = base + j;
+                v[j] = *(rowp + (col >= 0 ? col : slot + col));
+              }
+            }
+            const f32x4 keep = *(lvec_t)(rowp + c4);          // this lane's own group: the tile's last DCAR columns become the carry
+            if (c4 >= K::NCOL - DC)                            // (after every read of the slot: one wave instruction stream per row)
+              *(lvec_t)(rowp + DOFF + DC * h + (c4 - (K::NCOL - DC))) = keep;
+            float s0 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * DR; ++j) s0 = fmaf(w[j], v[j], s0);
+            s0 = __fadd_rn(s0, bb);
+            if (act) dn.y[yo] = dn.res != nullptr ? __fadd_rn(s0, dn.res[yo]) : s0;
+            yo += (long)RSTEP * To;
+            rowp += RSTEP * XS;
+          }
+        } else {
         // strided depthwise conv of the half's C rows: output (t / r) of row m reads columns [t - r, t + r) — the lane's own group and
         // the one in front of it (left neighbour, the half's carry slot, or the stream's cache), like P3
         lptr_t xpd = (lptr_t)(X + rsub * XS + c4);
@@ -1247,6 +1351,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
           asm volatile("" : "+v"(xpd), "+v"(pbd));
           __builtin_amdgcn_sched_barrier(0);
         }
+        }                // narrow / wide strided conv
       }
       lds_barrier();   // the next tile's P0 overwrites X
       cs = cn;

@@ -50,6 +50,7 @@ class ExecOptions:
                                             # one-workgroup-per-CU launches leave it nothing to co-reside with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90)
     fuse_decoder_stage: bool = True        # decoder stages with C = 192 / 96 (a streaming hop: also C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
     fuse_decoder_stage_partial: bool = True  # ... and where LDS holds one block only behind the up-sampling phase (offline C = 768, streaming C = 384): up-sampling layer + FIRST block
+    fuse_encoder_stage_wide: bool = True   # ... and, offline, the wide stages C = 256 (r = 5) / C = 512 (r = 8)
     fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
     offline_wide_blocks: bool = True       # offline: the wide residual blocks (C = 256 ... 768) as ONE carry-form launch each / per stage (False: two hilc_dws_conv launches per block, as until round 4)
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
@@ -236,7 +237,7 @@ def finalize_spec(spec, streaming: bool = False):
         for rb in st.blocks:
             finalize_block(rb, streaming)
         if (isinstance(st, EncStageSpec) and st.down_lo is None and st.down_pw_wt.device.type in ("cuda", "meta")
-                and st.down_pw_wt.shape[0] in (64, 128) and st.down_pw_wt.shape[1] == 2 * st.down_pw_wt.shape[0]
+                and st.down_pw_wt.shape[0] in ((64, 128) if streaming else (64, 128, 256, 512)) and st.down_pw_wt.shape[1] == 2 * st.down_pw_wt.shape[0]
                 and all(rb.pw1_chain is not None for rb in st.blocks)):
             c = st.down_pw_wt.shape[0]
             st.down_lo = ops.resblock_chain_pack(st.down_pw_wt[:, :c].contiguous(), streaming)
@@ -545,6 +546,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                 and (opts.stream_chain_blocks if streaming else opts.offline_chain_blocks)
                 and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                         and rb.dw2_b is not None for rb in st.blocks)
+                and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or (opts.offline_wide_blocks and opts.fuse_encoder_stage_wide))
                 and ops.encoder_stage_supported(x.shape[1], x.shape[2], nb, st.ratio, x.shape[0], streaming)):
             # the whole stage — its residual blocks and its down-sampling layer — is one launch; the stage's output never reaches HBM
             blocks = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks]

@@ -1018,9 +1018,11 @@ def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: O
 
 def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:
     """mirror of hilc_encoder_stage_supported (+ the 32-bit offsets of the streaming form)"""
-    if nblk < 1 or nblk > 2 or T <= 0 or T % 4 != 0 or (streaming and B * 2 * C * T * 4 >= (1 << 32)):
+    if nblk < 1 or nblk > 2 or T <= 0 or T % 4 != 0 or stride <= 0 or T % stride != 0 or (streaming and B * 2 * C * T * 4 >= (1 << 32)):
         return False
-    return (C == 64 and stride == 2) or (C == 128 and stride == 4)
+    if (C == 64 and stride == 2) or (C == 128 and stride == 4):
+        return True
+    return not streaming and ((C == 256 and stride == 5) or (C == 512 and stride == 8))      # the wide stages of the offline model
 
 
 def encoder_stage(x: Tensor, blocks: Sequence[Sequence], down: Sequence, hist: Optional[Sequence[Sequence[Tensor]]] = None,

@@ -178,7 +178,7 @@ def test_offline_launch_structure_options_change_no_bit():
     # 2 * 3 blocks; and the stage form saves the four down- / up-sampling launches
     assert (d[3], e[3], f[3]) == (4, 4, 10) and e[4] - d[4] == 4, (d[3:], e[3:], f[3:])
     # with them: encoder 4 stages / chains, decoder C = 768: (up-sampling layer +) first block, two blocks; C = 384 / 192 / 96: one launch each;
-    # block by block: 4 * 2 + 4 * 3; the stage form saves six down- / up-sampling launches (all but the two wide down-sampling layers); every wide block is one launch less than two
-    assert (a[3], b[3], c[3]) == (10, 10, 20) and b[4] - a[4] == 6 and f[4] - c[4] == 10, (a[3:], b[3:], c[3:], f[3:])
+    # block by block: 4 * 2 + 4 * 3; the stage form saves all eight down- / up-sampling launches; every wide block is one launch less than two
+    assert (a[3], b[3], c[3]) == (10, 10, 20) and b[4] - a[4] == 8 and f[4] - c[4] == 10, (a[3:], b[3:], c[3:], f[3:])
     for other in (b, c, d, e, f):
         assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])

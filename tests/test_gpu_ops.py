@@ -539,10 +539,14 @@ def _stage_params(ops, dev, C, r, n, streaming):
 
 
 @pytest.mark.parametrize("C,r,T,B,n", [(64, 2, 1000, 3, 2), (128, 4, 12000, 2, 2), (64, 2, 24000, 24, 2), (128, 4, 124, 9, 2), (128, 4, 600, 40, 1),
-                                        (64, 2, 8, 5, 2)])
+                                        (64, 2, 8, 5, 2), (256, 5, 3000, 3, 2), (256, 5, 3000, 40, 2), (512, 8, 600, 5, 2), (512, 8, 600, 300, 2),
+                                        (256, 5, 1160, 5, 2), (512, 8, 232, 7, 2), (256, 5, 20, 70, 2), (512, 8, 8, 33, 1), (256, 5, 60, 1, 1),
+                                        (512, 8, 40, 2, 2)])
 def test_encoder_stage_offline_equals_blocks_then_down(env, C, r, T, B, n):
     """hilc_encoder_stage, offline: the stage's residual blocks and its down-sampling layer (`seanet.py:316-339`) in ONE launch ==
-    hilc_resblock per block followed by hilc_dws_conv (stride r), bit for bit — with and without `res`."""
+    hilc_resblock per block followed by hilc_dws_conv (stride r), bit for bit — with and without `res`.  The wide stages (C = 256 /
+    r = 5, C = 512 / r = 8: outputs that do not align with 4-column lanes, windows that reach up to 9 columns into the previous
+    tile) with few clips (runs start inside clips: warm-up tiles), many, and clips shorter than a tile."""
     ops, fold, O, dev = env
     assert ops.encoder_stage_supported(C, T, n, r, B, streaming=False)
     blocks, singles, wd, dw, db, down = _stage_params(ops, dev, C, r, n, False)
