@@ -211,8 +211,9 @@ int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* bl
  * between them never exists.  x `[B][2C][T/r]`, tr_w `[2C][2r]`, w_lo / w_hi: rows [0, C) / [C, 2C) of the k-major `[2C][C]`
  * pointwise weight, each packed with hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C)).
  * Stages: C = 768 with r = 8 (streaming: whole streams per 32-column tile, T in {8, 16, 32}, nblk 1..3; offline: nblk = 1 — the
- * up-sampling layer and the stage's FIRST block, the carry slots of a second do not fit LDS), C = 192 with r = 4 and C = 96 with
- * r = 2 (streaming hops and, with streaming = 0, the offline model: hist* ignored); nblk 1..3. */
+ * up-sampling layer and the stage's FIRST block, the carry slots of a second do not fit LDS), C = 384 with r = 5 (tr_w = the EXPANDED
+ * tap table `[2C][r][8]` of hilc_up_conv_expand_taps; offline: nblk 1..3; streaming: nblk = 1, the halo form of the wide blocks),
+ * C = 192 with r = 4 and C = 96 with r = 2 (streaming hops and, with streaming = 0, the offline model: hist* ignored); nblk 1..3. */
 typedef struct hilc_up_params {
   const float* x; const float* tr_w; const float* w_lo; const float* w_hi; const float* bias;
   const float* hist; float* hist_out;
@@ -244,7 +245,8 @@ int hilc_tail_multi(const hilc_tail_desc* descs, int n, void* stream);
  * followed by hilc_dws_conv / hilc_dws_conv_stream (stride r, in_scale, in_elu = 1, `res`) bit for bit; the stage's output
  * `[B][C][T]` never reaches HBM.  w_lo / w_hi: columns [0, C) / [C, 2C) of the k-major `[C][2C]` pointwise weight, each packed
  * like a block's matrix (hilc_resblock_pack_weights_rc with the row classes of the chain form in use).  res (optional): added to
- * the output, e.g. the next stage's SpecBlock branch.  Stages: C = 64 with r = 2, C = 128 with r = 4; nblk 1..2; T % 4 == 0. */
+ * the output, e.g. the next stage's SpecBlock branch.  Stages: C = 64 with r = 2, C = 128 with r = 4; offline (streaming = 0) also the
+ * wide stages C = 256 with r = 5 and C = 512 with r = 8; nblk 1..2; T % 4 == 0, T % r == 0. */
 typedef struct hilc_down_params {
   const float* w_lo; const float* w_hi; const float* dw_w; const float* dw_b;
   const float* hist; float* hist_out; const float* res; float* y;
@@ -346,7 +348,10 @@ int hilc_l2norm(const float* x, float* y, int B, int C, int T, float eps, float 
  * q (optional) same layout as z.  frame_err (optional) `[B*T]` receives sum_c (z-q)^2 per frame.
  * Replaces: EuclideanCodebook.forward + ResidualVQ.forward eval branch
  * (`models/hilcodec/vector_quantize.py:132-176,199-243`, `modules/vector_quantize.py:141-195,490-516`,
- * `models/hilcodec/streaming.py:51-68,89-100`).  Returns HILC_ERR_RANGE unless 1 <= n <= Nq. */
+ * `models/hilcodec/streaming.py:51-68,89-100`).  Returns HILC_ERR_RANGE unless 1 <= n <= Nq.
+ * Every score is one fp32 fmaf chain over the channels in ascending order, whatever the batch size: small batches on the VALU
+ * (4 or 16 frames per workgroup), 8 192 frames and more on the matrix pipe (v_mfma_f32_32x32x2_f32, 32 frames per workgroup,
+ * the A operand read straight from codebooks_t) — same bits, same indices. */
 int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t, const float* norms,
                     int64_t* indices, float* q, float* frame_err, int B, int C, int T, int K, int Nq, int n,
                     int channel_last, int stage_major, void* stream);
