@@ -144,8 +144,10 @@ struct Cfg {
   static constexpr int KP = HILC_RES_KP;
   static constexpr int DEPTH = HILC_RES_DEPTH;
 #else
-  static constexpr int KP = C >= 128 ? 4 : 8;
-  static constexpr int DEPTH = C >= 192 ? 4 : (C >= 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
+  // (round 4, on a chip that is no longer power-limited — tools/build_variants.py + variant_table.sh, one box: KP = 4 / DEPTH = 2 instead of 4 / 4
+  //  at C = 192: 14.84 -> 14.64 ms per offline stage, instead of 8 / 2 at C = 96: 9.00 -> 8.89; the wide shapes lose with it: C = 768 5.30 -> 5.39)
+  static constexpr int KP = C >= 96 ? 4 : 8;
+  static constexpr int DEPTH = C >= 256 ? 4 : (C == 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
 #endif
 #ifndef HILC_RES_MINW
 #define HILC_RES_MINW 2
