@@ -67,8 +67,10 @@ constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1
 // run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
 // (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
 // 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
+// (round 4, stage launches on the no-longer-power-limited chip, tools/share_sweep_chain.sh: C = 96 stage 0.50 -> 9.16 ms, 0.56 -> 8.89, 0.60 - 0.62 -> 8.70,
+// 0.64 -> 8.84, 0.68 -> 9.10, 0.72 -> 9.43; C = 64 stage 3.44 / 3.39 / 3.30 / 3.38 / 3.42 / 3.54)
 #ifndef HILC_RES_SHARE2_0
-#define HILC_RES_SHARE2_0 0.64
+#define HILC_RES_SHARE2_0 0.61
 #endif
 #ifndef HILC_RES_SHARE3_0
 #define HILC_RES_SHARE3_0 0.44
