@@ -596,14 +596,17 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
         dst[e] = *src;
       }
     } else {
-      for (int e = tid; e < C * DWS; e += NT) {
-        const int m = e / DWS, j = e - m * DWS;
-        float v;
-        if (j < 5) v = bq.dw1_w[m * 5 + j];
-        else if (j == 5) v = bq.dw1_b[m];
-        else if (j < 11) v = bq.dw2_w[m * 5 + (j - 6)];
-        else v = bq.dw2_b[m];
-        dst[e] = v;
+      // (once per workgroup, in front of the tile loop — but a hop is 5 - 10 tiles per workgroup: the branchy form's 5 - 14 serial rounds of
+      //  four exec-mask regions were a visible part of a streaming stage launch)
+      constexpr int NE = C * DWS;
+#pragma unroll 4
+      for (int i = 0; i < (NE + NT - 1) / NT; ++i) {
+        const int e = tid + i * NT;
+        const int ec = (NE % NT == 0 || e < NE) ? e : NE - 1;
+        const int m = ec / DWS, j = ec - m * DWS;
+        const float* src = j < 5 ? bq.dw1_w + (m * 5 + j) : (j == 5 ? bq.dw1_b + m : (j < 11 ? bq.dw2_w + (m * 5 + (j - 6)) : bq.dw2_b + m));
+        const float v = *src;
+        if (NE % NT == 0 || e < NE) dst[ec] = v;
       }
     }
   };
