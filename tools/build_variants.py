@@ -2,8 +2,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g, os, sys
 from concurrent.futures import ThreadPoolExecutor
-V = {"kp8d2": ("HILC_RES_KP=8", "HILC_RES_DEPTH=2"), "kp4d2": ("HILC_RES_KP=4", "HILC_RES_DEPTH=2"), "kp8d3": ("HILC_RES_KP=8", "HILC_RES_DEPTH=3"),
-     "rb2": ("HILC_RES_RB=2",)}
+V = {"wide64": ("HILC_RES_WIDE_MASK=1",), "wide96": ("HILC_RES_WIDE_MASK=2",), "wide128": ("HILC_RES_WIDE_MASK=4",)}
+if len(sys.argv) > 1:      # name=DEF[,DEF...] ...
+    V = {a.split("=", 1)[0]: tuple(a.split("=", 1)[1].split(",")) for a in sys.argv[1:]}
 def one(kv):
     name, defs = kv
     try:
