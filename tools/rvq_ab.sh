@@ -1,7 +1,11 @@
-python -m pytest tests/test_gpu_rvq.py -q 2>&1 | tail -4
+#!/bin/bash
+# RVQ encode of the offline step: two builds of the library (and the VALU form, HILC_RVQ_VALU=1) on one box
+python -m pytest tests/test_gpu_rvq.py -q 2>&1 | tail -3
 for i in 1 2; do
-HILC_RVQ_VALU=1 python tools/layer_profile.py 2>&1 | grep -E "rvq|total"
-python tools/layer_profile.py 2>&1 | grep -E "rvq|total"
-HILC_RVQ_VALU=1 python tools/layer_profile.py --model hil_music 2>&1 | grep -E "rvq|total"
-python tools/layer_profile.py --model hil_music 2>&1 | grep -E "rvq|total"
+ for L in "$@"; do
+  for M in hil_speech hil_music; do
+   HILC_LIB=$PWD/hilcodec_amd/lib/$L python tools/layer_profile.py --model $M 2>&1 | grep -E "rvq" | sed "s/^/$L $M /"
+  done
+ done
 done
+HILC_RVQ_VALU=1 python tools/layer_profile.py 2>&1 | grep -E "rvq" | sed "s/^/VALU form /"
