@@ -46,6 +46,18 @@ def test_error_codes_without_gpu():
         for t in (1, 4, 8, 12, 16, 32, 40, 64, 160, 320):
             assert ops.resblock_supported(c, t, 4, streaming=True) == bool(lib.hilc_resblock_stream_supported(c, t)), (c, t)
     assert not ops.resblock_supported(768, 8, 1 << 18, streaming=True)          # flat 32-bit column space
+    # the stage launches (round 4): chains, encoder / decoder stages, and the row split of their packed weights
+    widths = (32, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
+    for c in widths:
+        assert ops.resblock_chain_row_classes(c, True) == (lib.hilc_resblock_chain_row_classes(c) or 2), c
+        assert ops.resblock_chain_row_classes(c, False) == (lib.hilc_resblock_chain_row_classes_offline(c) or 1), c
+        for t in (4, 8, 20, 40, 75, 160, 320, 600, 3000):
+            for n in (1, 2, 3, 4):
+                for st in (0, 1):
+                    assert ops.resblock_chain_supported(c, t, n, 2, streaming=bool(st)) == bool(lib.hilc_resblock_chain_supported(c, t, n, st)), (c, t, n, st)
+                    for r in (2, 4, 5, 8):
+                        assert ops.encoder_stage_supported(c, t, n, r, 2, streaming=bool(st)) == bool(lib.hilc_encoder_stage_supported(c, t, n, r, st)), (c, t, n, r, st)
+                        assert ops.decoder_stage_supported(c, t, n, r, 2, streaming=bool(st)) == bool(lib.hilc_decoder_stage_supported(c, t, n, r, st)), (c, t, n, r, st)
     assert lib.hilc_resblock(one, one, one, one, one, one, one, one, 1, 96, 16, 1.0, 1.0, None) == -4  # y aliases x
 
 
