@@ -510,9 +510,12 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   // small batches (a streaming hop: 1024 frames): 4 frames per workgroup = one workgroup per CU, 512 threads x 2 codes = two waves per
   // SIMD to hide the L2 round trips of the code words (256 x 4: 143 us, 512 x 2: 96 us, 1024 x 1: 107 us; 8 / 16 frames per
   // workgroup: 240 / 369 us — profiles/r04_experiments.md)
-  // large batches: the score GEMM on the matrix pipe, 32 frames per workgroup (two workgroups per CU; HILC_RVQ_VALU=1 in the environment
-  // keeps the VALU form for A/B runs)
+  // large batches: the score GEMM on the matrix pipe, 32 frames per workgroup (two workgroups per CU)
+#ifdef HILC_RVQ_ENV       // tuning builds only (tools/rvq_ab.sh): HILC_RVQ_VALU=1 in the environment keeps the VALU form
   static const bool valu_only = getenv("HILC_RVQ_VALU") != nullptr;
+#else
+  constexpr bool valu_only = false;
+#endif
   if (nframes >= 32 * 256 && !valu_only)
     hipLaunchKernelGGL((rvq_encode_mfma_kernel<128>), dim3((unsigned)((nframes + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
   else if (nframes <= 16 * 512)

@@ -8,7 +8,7 @@ if len(sys.argv) > 1:      # name=DEF[,DEF...] ...
 def one(kv):
     name, defs = kv
     try:
-        g.compile_library(os.path.join(g.LIBDIR, f"libv_{name}.so"), defines=defs, only=("resblock.hip", "resblock_chain.hip"))
+        g.compile_library(os.path.join(g.LIBDIR, f"libv_{name}.so"), defines=defs, only=("resblock.hip", "resblock_chain.hip", "rvq.hip"))
         return name, "ok"
     except Exception as e:
         return name, "FAILED " + str(e)[:100]
