@@ -20,6 +20,7 @@ extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streami
   if (nblk > max_blocks) return 0;
   if (chain_width(C)) return 1;
   if (!streaming) return C == 256 || C == 384 || C == 512;          // the wide blocks in the carry form (NARROW shapes)
+  if (C == 256) return 1;                                           // a hop: 32-column tiles, four waves, runs of whole streams with carries
   return (C == 512 || C == 768) && 32 % T == 0;
 }
 
@@ -40,7 +41,8 @@ extern "C" int hilc_resblock_chain_row_classes(int C) {
   static_assert(Cfg<64, true, false, true, 2, false>::RH == 1 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
                 Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
                 Cfg<512, true, false, false, 2, false>::RH == 8 && Cfg<768, true, false, false, 3, false>::RH == 8, "packed layout");
-  if (C == 256 || C == 384) return 4;       // (no chain of theirs in a hop; the stage entry points' packed up- / down-sampling halves)
+  static_assert(Cfg<256, true, false, true, 2, false>::RH == 4 && Cfg<384, true, false, false, 1, false, -5>::RH == 4, "packed layout");
+  if (C == 256 || C == 384) return 4;
   return C >= 512 ? 8 : ((C == 96 || C == 64) ? 1 : (chain_width(C) ? 2 : 0));
 }
 
@@ -90,6 +92,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
     case 96: return launch_chain<96, true, 3, false>(a, B, s);         // 3 row blocks do not split in two classes: 4 waves, two workgroups per CU
     case 128: return launch_chain<128, true, 2, true>(a, B, s);
     case 192: return launch_chain<192, true, 3, false>(a, B, s);
+    case 256: return launch_chain<256, true, 2, false>(a, B, s);
     case 512: return launch_chain<512, true, 2, false>(a, B, s);
     case 768: return launch_chain<768, true, 3, false>(a, B, s);
     default: return HILC_ERR_UNSUPPORTED;

@@ -117,7 +117,14 @@ struct Cfg {
   // previous samples, so there is no halo to recompute; 64-column tiles walk the flat column space with an 8-column halo.
   // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
   static constexpr bool NARROW = C >= 256;
-  static constexpr int NCOL = WIDE ? 256 : (NARROW ? (C >= 512 ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
+  // STREAM + SCARRY at C = 256 (the chain of a hop, round 4): 32-column tiles and FOUR waves, one per row class, two workgroups per CU.  A
+  // stream of 40 samples does not tile 64 columns, but 4 streams are exactly 5 tiles of 32: 1 024 streams = 256 runs of whole streams, no
+  // halo (12.5 % of a 64-column flat tile), no partly filled tile, and carries — hence a chain — inside a run.  OPT-IN
+  // (`ExecOptions.stream_wide_chains`, off): the launch alone 0.278 -> 0.249 ms, the hop it sits in 4.861 -> 4.905 ms (graph, same box).
+  // (C = 384 the same way: bit-identical, but its 141 KB of LDS allow one four-wave workgroup per CU — the stage 1.07 -> 1.32 ms; it
+  // keeps the halo form on 64-column tiles with eight waves.)
+  static constexpr bool NARROW4 = NARROW && STREAM && SCARRY_ && C < 512;
+  static constexpr int NCOL = WIDE ? 256 : (NARROW ? ((C >= 512 || NARROW4) ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
   static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
@@ -129,7 +136,7 @@ struct Cfg {
   static constexpr bool CARRYMODE = !STREAM || SCARRY_;
   static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = (WIDE || C >= 192 || W8_) ? 8 : 4;           // waves per workgroup
+  static constexpr int NW = NARROW4 ? 4 : ((WIDE || C >= 192 || W8_) ? 8 : 4);           // waves per workgroup
   static constexpr int NT = 64 * NW;
   static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
   static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
@@ -1438,8 +1445,8 @@ inline void set_div_magic(ResArgs& a) {
 // stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
 template <int C, bool STREAM, int NB, bool W8, int DR = 0>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR)
 int launch_chain(ResArgs a, int B, hipStream_t s) {
-  constexpr bool NARROW = STREAM && C >= 256;
-  using K = Cfg<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>;
+  constexpr bool SC = STREAM && C <= 256;         // runs of whole streams with carries (C = 384: flat tiles with a halo; C >= 512: whole-stream tiles, static stride)
+  using K = Cfg<C, STREAM, false, SC, NB, W8, DR>;
   a.B = B;
   set_div_magic(a);
   constexpr int TO = K::TO;
@@ -1449,10 +1456,10 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
   a.run_tiles = 0;
   static std::atomic<int> resident_cache[64];
   int n_cu = 0;
-  const long resident = resident_workgroups(resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>, K::NT, resident_cache, n_cu);
+  const long resident = resident_workgroups(resblock_kernel<C, STREAM, false, SC, NB, W8, DR>, K::NT, resident_cache, n_cu);
   if (resident < 1) return HILC_ERR_LAUNCH;
   long blocks;
-  if constexpr (STREAM && !NARROW) {
+  if constexpr (SC) {
     long g = a.T, h = K::NCOL;
     while (h != 0) { const long t = g % h; g = h; h = t; }                      // gcd(T, NCOL)
     const long unit = (long)a.T / g;                                              // tiles of the shortest run of whole streams
@@ -1465,7 +1472,7 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
     if constexpr (!STREAM) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, STREAM && !NARROW, NB, W8, DR>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, SC, NB, W8, DR>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

@@ -56,6 +56,7 @@ class ExecOptions:
     offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
     stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
     stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
+    stream_wide_chains: bool = False       # streaming hop: the two C = 256 blocks as a chain on 32-column tiles with four waves and carries (runs of whole streams).  Built, bit-identical, faster alone (0.278 -> 0.249 ms) and SLOWER inside the hop (graph 4.861 -> 4.905 ms, pipelined 4.710 -> 4.721, same box): off (profiles/r04_experiments.md)
     stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
 
 
@@ -359,6 +360,7 @@ def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Se
             and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                     and rb.dw2_b is not None for rb in blocks)
             and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.stream_wide_blocks)
+            and (x.shape[1] != 256 or opts.stream_wide_chains)
             and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0])):
         y, cs = ops.resblock_chain(
             x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks],

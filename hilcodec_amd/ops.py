@@ -935,7 +935,7 @@ def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1, streaming: b
         return C in (64, 96, 128, 192, 256, 384, 512)
     if B * C * T * 4 >= (1 << 32):
         return False
-    return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
+    return C in (64, 96, 128, 192, 256) or (C in (512, 768) and 32 % T == 0)
 
 
 def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:

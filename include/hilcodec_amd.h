@@ -188,7 +188,8 @@ int hilc_resblock_balanced(const float* x, const float* w1t, const float* dw1_w,
  * (the chain's 8-wave shapes split the rows in two classes also below C = 192, so the layout differs from hilc_resblock's);
  * hist* as in hilc_resblock_stream (each optional; ignored with streaming = 0: the offline causal model, hilc_resblock).
  * hilc_resblock_chain_supported tells whether the specialisation exists: C in {64, 96, 128, 192} any T % 4 == 0;
- * streaming: C in {512, 768} with whole streams tiling 32 columns; offline: C in {256, 384, 512} (C = 768: one block per launch,
+ * streaming: C in {512, 768} with whole streams tiling 32 columns, and C = 256 (32-column tiles, four waves, runs of whole streams:
+ * measured slower inside a 1024-stream hop than one launch per block, so the engine leaves it off); offline: C in {256, 384, 512} (C = 768: one block per launch,
  * the carry slots of a second do not fit LDS); nblk = 2, or 3 at the decoder's widths (96, 192, streaming 768, offline 384).
  * Else HILC_ERR_UNSUPPORTED: launch the blocks one by one. */
 typedef struct hilc_resblock_params {

@@ -402,7 +402,8 @@ def test_wide_stream_block_equals_two_launches(env, C, T, B):
 @pytest.mark.parametrize("C,T,B,n", [(64, 320, 5, 2), (64, 320, 1024, 2), (96, 320, 3, 3), (96, 320, 1024, 3), (128, 160, 7, 2), (128, 160, 1024, 2),
                                       (192, 160, 6, 3), (192, 160, 1024, 3), (512, 8, 21, 2), (512, 8, 1024, 2), (768, 8, 37, 3),
                                       (768, 8, 1024, 3), (96, 640, 2, 3), (64, 960, 3, 2), (192, 480, 2, 3), (128, 4, 9, 2), (96, 12, 70, 2),
-                                      (768, 8, 5, 2), (192, 160, 9, 2)])
+                                      (768, 8, 5, 2), (192, 160, 9, 2), (256, 40, 1024, 2), (256, 40, 3, 2), (256, 120, 5, 2), (256, 8, 33, 2), (256, 4, 1, 2),
+                                      (256, 44, 1023, 2)])
 def test_resblock_chain_equals_block_by_block(env, C, T, B, n):
     """The residual blocks of one stage of a streaming hop in ONE launch (hilc_resblock_chain: `streaming.py:497-503,633-639`
     runs them one after the other) against the same blocks launched one by one (hilc_resblock_stream): output and all 2n new
@@ -669,13 +670,13 @@ def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
-    assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0
+    assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(256, 40, 2, 1) == 1
     assert lib.hilc_resblock_chain_supported(96, 320, 1, 1) == 0 and lib.hilc_resblock_chain_supported(96, 320, 4, 1) == 0
     assert lib.hilc_resblock_chain_supported(96, 320, 3, 0) == 1 and lib.hilc_resblock_chain_supported(96, 322, 3, 1) == 0
     assert lib.hilc_resblock_chain_supported(768, 8, 3, 0) == 0 and lib.hilc_resblock_chain_supported(64, 320, 3, 0) == 0
     assert lib.hilc_resblock_chain_supported(64, 320, 3, 1) == 0 and lib.hilc_resblock_chain_supported(512, 8, 3, 1) == 0      # 2-block instantiations
     assert not ops.resblock_chain_supported(64, 320, 3, 2) and ops.resblock_chain_supported(64, 320, 2, 2)
-    assert not ops.resblock_chain_supported(384, 40, 3, 8) and not ops.resblock_chain_supported(96, 320, 3, 40000)
+    assert not ops.resblock_chain_supported(384, 40, 3, 8) and ops.resblock_chain_supported(256, 40, 2, 8) and not ops.resblock_chain_supported(256, 40, 3, 8) and not ops.resblock_chain_supported(96, 320, 3, 40000)
 
 
 def test_wide_stream_block_shapes_it_does_not_take(env):

@@ -454,6 +454,10 @@ def test_stream_block_options_reach_both_halves():
             half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
             half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = False     # chains, but the down- / up-sampling layers as launches of their own
         unstaged, k_unstaged, c_unstaged = run(True, True)
+        for half in (model.encoder, model.decoder):
+            half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
+            half.exec_options.stream_wide_chains = True              # opt-in: the two C = 256 blocks as a chain (32-column tiles, four waves)
+        chain256, k_chain256, c_chain256 = run(True, True)
     finally:
         model.encoder.exec_options.stream_defer_spec = True
         for half in (model.encoder, model.decoder):
@@ -461,15 +465,17 @@ def test_stream_block_options_reach_both_halves():
             half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
             half.exec_options.stream_chain_blocks = True
             half.exec_options.stream_wide_blocks = True
+            half.exec_options.stream_wide_chains = False
     # launches of the fused-block kernel per hop: encoder 4 stages x 2 blocks, decoder 4 x 3.  Chains: every stage but C = 256
     # (encoder) / C = 384 (decoder) is one launch; without the wide forms the 4 + 6 wide blocks are two GEMM launches each instead.
     assert k_one == (8, 12) and k_two == (4, 6), (k_one, k_two)
     # default: the encoder's C = 64 / 128 stages and the decoder's C = 768 / 192 / 96 stages are ONE launch each (blocks + down- / up-sampling
-    # layer), C = 512 is a chain, C = 256 / 384 one launch per block
-    assert k_chain == (3 + 2, 3 + 3) and k_unstaged == k_chain, (k_chain, k_unstaged)
-    for a, b, c in zip(c_chain, c_separate, c_unstaged):
-        assert torch.equal(a, b) and torch.equal(a, c)
-    for ref, other in ((chained, one), (chained, two), (chained, inline), (chained, separate), (chained, unstaged)):
+    # layer), C = 512 is a chain, C = 256 one launch per block, C = 384: up-sampling layer + first block, then one launch per block.
+    # Opt-in `stream_wide_chains` (off: slower inside the hop): the two C = 256 blocks as one chain launch, same bits.
+    assert k_chain == (3 + 2, 3 + 3) and k_unstaged == k_chain and k_chain256 == (3 + 1, 3 + 3), (k_chain, k_unstaged, k_chain256)
+    for a, b, c, d in zip(c_chain, c_separate, c_unstaged, c_chain256):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    for ref, other in ((chained, one), (chained, two), (chained, inline), (chained, separate), (chained, unstaged), (chained, chain256)):
         for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
             assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
     for a, b, c, d in zip(c_chain, c_one, c_two, c_inline):

@@ -39,8 +39,8 @@ for case in range(N):
     B = rng.choice([1, 2, 3, 7, 33, 100, 257, 1024, 1100])
     try:
         if kind == "chain":
-            C = rng.choice([64, 96, 128, 192, 512, 768]); n = rng.choice([2, 3]) if C in (96, 192, 768) else 2
-            T = rng.choice([4, 8, 16, 32]) if C >= 512 else rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640])
+            C = rng.choice([64, 96, 128, 192, 256, 512, 768]); n = rng.choice([2, 3]) if C in (96, 192, 768) else 2
+            T = rng.choice([4, 8, 16, 32]) if C >= 512 else (rng.choice([4, 8, 40, 44, 80, 120]) if C >= 256 else rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640]))
             if not ops.resblock_chain_supported(C, T, n, B):
                 continue
             bls = [block(C, j) for j in range(n)]
@@ -76,7 +76,7 @@ for case in range(N):
                 ok = ok and torch.equal(y, ref) and torch.equal(da, db_) and same_caches(ca, cb)
         else:
             C, r, nmax = rng.choice([(96, 2, 3), (192, 4, 3), (384, 5, 1), (768, 8, 3)]); n = rng.randint(1, nmax)
-            Tin = rng.choice([1, 2, 4]) if C == 768 else rng.choice([1, 2, 4, 8, 30, 40, 41, 80, 160])
+            Tin = rng.choice([1, 2, 4]) if C == 768 else (rng.choice([4, 8, 12, 16, 24]) if C == 384 else rng.choice([1, 2, 4, 8, 30, 40, 41, 80, 160]))
             T = Tin * r
             if T % 4 or not ops.decoder_stage_supported(C, T, n, r, B):
                 continue
