@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense; no xf32/TF32 on gfx950
+HBM_PEAK_TBPS = 8.0                # MI355X_MICROARCH.md: HBM3E spec (6.29 measured with a float4 copy)
 FLOP_PER_AUDIO_SECOND = {"hil_speech": 34.219e9, "hil_music": 34.298e9}
 MFMA_KINDS = ("pw_conv", "dws_conv", "resblock", "up_conv", "spec_block")
 
@@ -55,11 +56,6 @@ def parse():
     ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
     ap.add_argument("--batch", type=int, default=None, help="clips (offline) / streams (streaming) per GPU")
     ap.add_argument("--samples", type=int, default=24000)
-    ap.add_argument("--decoder-gemm", default="fp32", choices=["fp32", "bf16x3"],
-                    help="EXPERIMENTAL: run the decoder's wide GEMMs in the bf16 split-operand mode "
-                         "(csrc/gemm_x3.h).  A separately labelled line; the headline is the fp32 default.")
-    ap.add_argument("--x3-blocks-from", type=int, default=0, help="with --decoder-gemm bf16x3: residual blocks of at least "
-                    "this width leave the fused fp32 kernel for two bf16x3 launches (0 = keep the fused kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 2.5 s sustained clock / power sample")
     ap.add_argument("--no-launch-timing", action="store_true")
@@ -72,21 +68,16 @@ def parse():
                     "(hilcodec_amd/graph_step.py); per-launch timing is not available inside a graph")
     ap.add_argument("--groups", type=int, default=1, help="with --graph: split the streams into this many groups whose "
                     "chains run side by side on separate HIP streams inside the graph (same arithmetic, no added latency)")
-    ap.add_argument("--no-offline-chain", action="store_true", help="offline mode, A/B: one launch per residual block (round 3) instead of "
-                    "one per stage (hilc_resblock_chain, streaming = 0); same arithmetic, bit-identical outputs")
     ap.add_argument("--exec-opt", action="append", default=[], metavar="NAME=0|1", help="A/B: set a boolean field of engine.ExecOptions on the "
-                    "encoder and the decoder (e.g. stream_batch_tails=0, stream_defer_spec=0); all of them change launches, never results")
-    ap.add_argument("--no-stage", action="store_true", help="A/B: encoder stages as chain + separate down-sampling layer instead of one launch "
-                    "(hilc_encoder_stage); same arithmetic, bit-identical outputs")
-    ap.add_argument("--no-chain", action="store_true", help="streaming mode, A/B: one launch per residual block (round 3) instead "
-                    "of one launch per stage (hilc_resblock_chain); same arithmetic, bit-identical outputs")
+                    "encoder and the decoder (stage_launches, wide_blocks, decoder_stage_narrow, stream_defer_spec); all of them change "
+                    "launches, never results")
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips of the bounded CPU-baseline sample (per timed pass)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1")
     ap.add_argument("--emulate-rank", type=int, default=None, help="with --emulate-world W: run rank r's shard of the W-GPU job in this one process")
     ap.add_argument("--emulate-world", type=int, default=None)
     a = ap.parse_args()
     a.is_default = (a.model is None and a.mode == "offline" and a.batch is None and a.samples == 24000 and a.gpus == 1
-                    and a.decoder_gemm == "fp32" and a.emulate_world is None)
+                    and a.emulate_world is None and not a.exec_opt)
     if (a.emulate_rank is None) != (a.emulate_world is None):
         ap.error("--emulate-rank and --emulate-world go together")
     if a.emulate_world is not None and not 0 <= a.emulate_rank < a.emulate_world:
@@ -104,7 +95,7 @@ def parse():
     return a
 
 
-def sustained_clock(step, first_index: int, seconds: float = 2.5):
+def sustained_clock(step, first_index: int, seconds: float = 2.5, device_index: int = 0):
     """Shader clock and socket power while the benchmark's own steps run back to back: `rocm-smi` sampled from a
     thread (≈3 samples per second).  Returns medians, or None where rocm-smi is missing / prints something else."""
     import re
@@ -119,7 +110,7 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5):
     def sampler():
         while not stop[0]:
             try:
-                txt = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True,
+                txt = subprocess.run([smi, "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower"], capture_output=True,
                                      text=True, timeout=10).stdout
             except Exception:
                 return
@@ -265,7 +256,7 @@ def parity_census(model, sd, nq, z, idx, wav, oracle_out):
 # ---------------------------------------------------------------------------------------------------------------------
 # workloads: each returns (step, audio_seconds_per_step, context)
 # ---------------------------------------------------------------------------------------------------------------------
-def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bool = True, stage: bool = True):
+def offline_workload(name: str, n_clips: int, first: int, T: int, dev):
     import hilcodec_amd
     from hilcodec_amd import synth
     mk = synth.model_kwargs(name)
@@ -274,8 +265,6 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bo
     model.load_state_dict(sd, strict=False)
     for l in model.quantizer.layers:
         l.initted = True
-    model.encoder.exec_options.offline_chain_blocks = model.decoder.exec_options.offline_chain_blocks = chain
-    model.encoder.exec_options.fuse_encoder_stage = stage
     x = synth.synth_clips(n_clips, T, seed=1234, first=first).to(dev)
     last = {}
 
@@ -289,8 +278,7 @@ def offline_workload(name: str, n_clips: int, first: int, T: int, dev, chain: bo
     return step, n_clips * T / 24000.0, {"model": model, "sd": sd, "mk": mk, "last": last}
 
 
-def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1, chain: bool = True,
-                       stage: bool = True):
+def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, pipeline: bool, groups: int = 1):
     from hilcodec_amd import synth
     from hilcodec_amd.models.hilcodec.streaming import HILCodec as StreamingHILCodec
     mk = synth.model_kwargs(name)
@@ -300,8 +288,6 @@ def streaming_workload(name: str, n_streams: int, first: int, dev, graph: bool, 
     model = StreamingHILCodec(24000, **smk).eval()
     model.load_offline_state_dict(sd)
     model.remove_weight_reparameterizations()
-    model.encoder.exec_options.stream_chain_blocks = model.decoder.exec_options.stream_chain_blocks = chain
-    model.encoder.exec_options.fuse_encoder_stage = stage
     hop = 320
     nbuf = 8                                           # distinct input hops, cycled
     xs = [synth.synth_clips(n_streams, hop, seed=4321 + 7 * j, first=first).to(dev) for j in range(nbuf)]
@@ -366,7 +352,7 @@ def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
         return d
 
     step, audio, _ctx = offline_workload("hil_music", clips, 0, 24000, dev)
-    out["configs[2]"] = line(f"hil_music, batch={clips}x1 s 24 kHz, Nq=12, offline encode+RVQ+decode", "hil_music", step, audio, 3, 1)
+    out["configs[2]"] = line(f"hil_music, batch={clips}x1 s 24 kHz, Nq=12, offline encode+RVQ+decode", "hil_music", step, audio, 10, 2)
     del step, _ctx
     torch.cuda.empty_cache()
     for key, pipeline, groups in (("configs[3] graph", False, 1), ("configs[3] graph, 2 stream groups", False, 2),
@@ -402,9 +388,9 @@ def main():
     lo, hi = D.shard_range(B * shard_world, shard_rank, shard_world)
 
     if args.mode == "offline":
-        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev, not args.no_offline_chain, not args.no_stage)
+        step, audio_per_step, ctx = offline_workload(name, hi - lo, lo, T, dev)
     else:
-        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups, not args.no_chain, not args.no_stage)
+        step, audio_per_step, ctx = streaming_workload(name, hi - lo, lo, dev, args.graph, args.pipeline, args.groups)
         if args.graph:
             args.no_launch_timing = True
     model, sd, mk = ctx["model"], ctx["sd"], ctx["mk"]
@@ -418,44 +404,17 @@ def main():
         if args.mode == "streaming" and args.graph:
             ctx["hopper"] = ctx["make_hopper"]()                 # captured with the defaults: capture again
 
-    numerics = None
-    if args.decoder_gemm != "fp32":
-        dec_opts = model.decoder.exec_options          # this model's own switch (hilcodec_amd.engine.ExecOptions)
-        if args.mode == "offline":
-            with torch.no_grad():
-                idx_f, wav_f = step(0)                      # the fp32 product path on the same inputs, outside the timed region
-                dec_opts.decoder_gemm = args.decoder_gemm
-                if args.x3_blocks_from > 0:
-                    dec_opts.x3_fused_block_min_c = args.x3_blocks_from
-                idx_x, wav_x = step(0)
-        else:
-            # streaming: one hop from zero caches in both arithmetics (eager, outside the timed region and the state blocks)
-            xs = ctx["xs"]
-            with torch.no_grad():
-                ce, cd = model.initialize_cache(xs[0])
-
-                def one_hop():
-                    z, _ = model.encoder(xs[0], *ce)
-                    i_ = model.quantizer(z, nq)
-                    w_, _ = model.decoder(model.dequantizer(i_, nq), *cd)
-                    return i_, w_
-                idx_f, wav_f = one_hop()
-                dec_opts.decoder_gemm = args.decoder_gemm
-                idx_x, wav_x = one_hop()
-            if args.graph:                                   # the graphs were captured in fp32: capture again in the new mode
-                ctx["hopper"] = ctx["make_hopper"]()
-        numerics = {"mode": args.decoder_gemm, "scope": args.mode + " decoder: up-sampling and depthwise-separable GEMMs, GEMM phases of the fused residual blocks"
-                    + (f", residual blocks of width >= {args.x3_blocks_from}" if args.x3_blocks_from > 0 else "")
-                    + "; encoder and RVQ exact fp32",
-                    "indices_equal_to_fp32_path": bool(torch.equal(idx_f, idx_x)),
-                    "dwav_max_vs_fp32_path": float((wav_f - wav_x).abs().max()),
-                    "operand_bits": 16}
-        del idx_f, wav_f, idx_x, wav_x
-
     dt, idx, wav, timer = timed_region(step, args.steps, args.warmup, D, not args.no_launch_timing)
 
     per_rank = D.gather_counters({"clips": float((hi - lo) * args.steps), "audio_s": audio_per_step * args.steps,
                                   "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)   # the ONLY collective
+    rank_sustained = None
+    if world > 1 and not args.no_clock_probe:
+        # all ranks keep stepping together for 2.5 s (the node's power budget is shared: a sub-linear curve can then be told apart
+        # from eight chips throttling each other) and each samples ITS device; outside the timed region, one more 32-byte gather
+        sus_r = sustained_clock(step, args.warmup + args.steps, device_index=local) or {}
+        rank_sustained = D.gather_counters({"sclk_mhz": sus_r.get("sclk_mhz") or 0.0, "power_w": sus_r.get("power_w") or 0.0,
+                                            "power_cap_w": sus_r.get("power_cap_w") or 0.0}, dev)
     if rank == 0:
         agg = D.aggregate(per_rank)
         value = agg["xrt"]
@@ -491,10 +450,6 @@ def main():
                       "wall_skew_s": max(r["wall_s"] for r in per_rank) - min(r["wall_s"] for r in per_rank)},
             "build": {"csrc_sha16": _lib.source_hash(), "abi": _lib.ABI_VERSION},
         }
-        if numerics is not None:
-            out["metric"] += " — EXPERIMENTAL decoder GEMMs in bf16x3, NOT the fp32 headline"
-            out["dtype"] = "f32 (encoder, RVQ, narrow decoder blocks) + bf16x3 split-operand GEMMs (wide decoder layers)"
-            out["numerics"] = numerics
         whole_tflops = value * FLOP_PER_AUDIO_SECOND[name] / 1e12 / world
         roof = {"bound": "mfma", "achieved": None, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None, "whole_path_tflops_per_gpu": whole_tflops,
@@ -529,19 +484,26 @@ def main():
                 roof["traffic_build"] = {"csrc_sha16": prof.get("csrc_sha16"), "git_sha": prof.get("git_sha"),
                                          "stale": prof.get("csrc_sha16") != _lib.source_hash()}
                 roof["algorithmic_bytes_per_step"] = 196800 * B + 38150404 + nq * 524288 + 5602816
+                # north_star asks for the fraction of the HBM roofline too: measured HBM bytes of the whole step (PMC, all kernels of
+                # the family) over this run's step time against 8 TB/s — a few per cent: the path is matrix-bound, not HBM-bound
+                step_bytes = (prof.get("hbm_read_GB_per_step", 0.0) + prof.get("hbm_write_GB_per_step", 0.0)) * 1e9
+                if step_bytes:
+                    roof["hbm_bytes_per_step"] = step_bytes
+                    roof["hbm_peak_TBps"] = HBM_PEAK_TBPS
+                    roof["hbm_frac"] = step_bytes / (agg["wall_s"] / args.steps) / (HBM_PEAK_TBPS * 1e12)
+                    roof["hbm_frac_algorithmic"] = roof["algorithmic_bytes_per_step"] / (agg["wall_s"] / args.steps) / (HBM_PEAK_TBPS * 1e12)
         except (OSError, KeyError, ValueError):
             pass
+        if rank_sustained is not None:
+            roof["sustained_per_rank"] = rank_sustained
         if world == 1 and not args.no_clock_probe:
             # the fp32-MFMA peak assumes 2.4 GHz; this workload runs at the socket power limit and the clock follows
             # (profiles/r02_experiments.md).  Sampled AFTER the timed region, while the same steps keep running.
-            sus = sustained_clock(step, args.warmup + args.steps)
+            sus = sustained_clock(step, args.warmup + args.steps, device_index=local)
             if sus is not None:
                 sus["peak_at_sclk_tflops"] = FP32_MFMA_PEAK_TFLOPS * sus["sclk_mhz"] / 2400.0
                 sus["whole_path_frac_at_sclk"] = whole_tflops / sus["peak_at_sclk_tflops"]
                 roof["sustained"] = sus
-        if numerics is not None:
-            roof["note"] = ("EXPERIMENTAL line: part of the work runs on the bf16 matrix pipe; every fraction here is "
-                            "fp32-EQUIVALENT flops against the fp32 peak, not a utilisation")
         out["roofline"] = roof
         if world == 1 and not args.no_other_configs and (args.is_default or (args.other_configs and args.mode == "offline")):
             # auxiliary lines: a failure here (it would be a bug) must not cost the headline line its measurement — it is reported

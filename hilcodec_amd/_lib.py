@@ -31,13 +31,6 @@ SIGNATURES = {
     "hilc_resblock_pack_weights": [_p, _p, _i, _p],
     "hilc_dws_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_up_conv_expand_taps": [_p, _p, _i, _i, _p],
-    "hilc_x3_supported": [_i, _i, _i],
-    "hilc_x3_split_weights": [_p, _p, _i, _i, _p],
-    "hilc_dws_conv_x3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
-    "hilc_up_conv_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "hilc_dws_conv_stream_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
-    "hilc_resblock_pack_weights_x3": [_p, _p, _i, _p],
-    "hilc_resblock_x3": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "hilc_up_conv_expanded": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_up_conv_stream": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
     "hilc_resblock_balanced": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
@@ -48,6 +41,8 @@ SIGNATURES = {
     "hilc_resblock_chain": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hilc_decoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_decoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "hilc_decoder_stage_post_supported": [_i, _i, _i, _i, _i],
+    "hilc_decoder_stage_post": [_p, _p, _i, _p, _i, _i, _i, _p],
     "hilc_encoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_encoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
@@ -57,7 +52,6 @@ SIGNATURES = {
     "hilc_conv_post": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _i, _p],
     "hilc_stft_logmag": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     "hilc_tail": [_p, _p, _p, C.c_long, _i, _i, _i, _p],
-    "hilc_tail_multi": [_p, _i, _p],
     "hilc_spec_block_supported": [_i, _i, _i, _i],
     "hilc_spec_block_packed_floats": [_i, _i],
     "hilc_spec_block_pack": [_p, _p, _i, _i, _i, _p],
@@ -73,7 +67,7 @@ SIGNATURES = {
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def source_hash() -> str:
@@ -97,16 +91,15 @@ class ResblockParams(C.Structure):
                 ("hist1", _p), ("hist2", _p), ("hist1_out", _p), ("hist2_out", _p), ("pre_scale", _f), ("out_scale", _f)]
 
 
-class TailDesc(C.Structure):
-    """`hilc_tail_desc` of include/hilcodec_amd.h: one cache update of a hilc_tail_multi launch"""
-    _fields_ = [("x", _p), ("hist", _p), ("out", _p), ("rows", C.c_long), ("T", _i), ("pad", _i), ("hist_len", _i),
-                ("in_scale", _f), ("in_elu", _i)]
-
-
 class UpParams(C.Structure):
     """`hilc_up_params` of include/hilcodec_amd.h: the up-sampling layer of a decoder stage launch"""
     _fields_ = [("x", _p), ("tr_w", _p), ("w_lo", _p), ("w_hi", _p), ("bias", _p), ("hist", _p), ("hist_out", _p),
                 ("in_scale", _f), ("stride", _i)]
+
+
+class PostParams(C.Structure):
+    """`hilc_post_params` of include/hilcodec_amd.h: the decoder's closing conv behind its last stage (hilc_decoder_stage_post)"""
+    _fields_ = [("w", _p), ("bias", _p), ("wav", _p), ("in_scale", _f), ("out_scale", _f), ("do_tanh", _i), ("ksize", _i)]
 
 
 class DownParams(C.Structure):

@@ -181,19 +181,21 @@ __global__ __launch_bounds__(256) void conv_post_kernel(PostArgs a) {
   a.y[b * (long)a.T + t] = acc;
 }
 
-// Fast path (k = 5, T % 4 == 0; offline, or a streaming hop with its [B][C][4] cache): 64 threads x 4 samples = 256 samples per block;
-// the block's 4 waves split the channels (c = wave, wave+4, ...) so 4x more loads are in flight, each
-// lane moves 16 B, each sample's prologue (ELU) is evaluated once; partial sums meet in LDS.  The
-// channel order of the reduction is c ascending within a wave, then wave 0..3 — fixed.
-__global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
-  __shared__ float part[4][256];
+// Fast path (k = 5, T % 4 == 0; offline, or a streaming hop with its [B][C][4] cache): 64 lanes x 4 samples = 256 samples per block;
+// the block's 8 waves split the channels in classes c mod 8 so 8x more loads are in flight, each lane moves 16 B, each sample's
+// prologue (ELU) is evaluated once; partial sums meet in LDS.  The order of the reduction is c ascending within a class, then class
+// 0..7 — fixed, and the same as the closing phase of hilc_decoder_stage_post (csrc/resblock_kernel.h, phase Q), whose half-waves walk
+// exactly these classes: the two forms agree bit for bit.
+__global__ __launch_bounds__(512) void conv_post_k5_kernel(PostArgs a) {
+  constexpr int NCLS = 8;
+  __shared__ float part[NCLS][256];
   const long b = blockIdx.x / a.tblocks;
   const unsigned tb = blockIdx.x - (unsigned)b * a.tblocks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = (tb * 64 + lane) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (t < a.T) {
-    for (int c = wave; c < a.C; c += 4) {
+    for (int c = wave; c < a.C; c += NCLS) {
       const float* xrow = a.x + (b * a.C + c) * (long)a.T;
       const f32x4 cur = prologue4v(*reinterpret_cast<const f32x4*>(xrow + t), a.in_scale, a.in_elu);
       f32x4 prev = {0.f, 0.f, 0.f, 0.f};
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(256) void conv_post_k5_kernel(PostArgs a) {
   for (int e = 0; e < 4; ++e) part[wave][lane * 4 + e] = acc[e];
   __syncthreads();
   const int tt = tb * 256 + threadIdx.x;
-  if (tt < a.T) {
-    float s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+  if (threadIdx.x < 256 && tt < a.T) {
+    float s = part[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < NCLS; ++q) s = __fadd_rn(s, part[q][threadIdx.x]);
     if (a.bias) s = __fadd_rn(s, a.bias[0]);
     s = __fmul_rn(s, a.out_scale);
     if (a.do_tanh) s = tanhf(s);
@@ -264,54 +268,6 @@ __global__ __launch_bounds__(64) void l2norm_kernel(const float* x, float* y, in
     if (channel_last_out) y[f * (long)C + c0] = o;
     else y[b * (long)C * T + (long)c0 * T + t] = o;
   }
-}
-
-// Several cache updates in ONE launch (a streaming hop: the four up-sampling layers' caches and conv_post's, each 6-13 us as a
-// launch of its own at 1024 streams — latency, not work): block -> descriptor by prefix sums of the blocks each needs.
-struct TailMulti {
-  int n;
-  hilc_tail_desc d[HILC_TAIL_MAX];
-  unsigned first_block[HILC_TAIL_MAX + 1];
-};
-
-__global__ __launch_bounds__(256) void tail_multi_kernel(TailMulti m) {
-  int q = 0;
-  while (q + 1 < m.n && blockIdx.x >= m.first_block[q + 1]) ++q;       // uniform
-  const hilc_tail_desc& d = m.d[q];
-  const long g = (long)(blockIdx.x - m.first_block[q]) * 256 + threadIdx.x;
-  if (g >= d.rows * d.pad) return;
-  const long row = g / d.pad;
-  const int i = (int)(g - row * d.pad);
-  const int t = d.T - d.pad + i;
-  float v;
-  if (t >= 0) v = prologue(d.x[row * (long)d.T + t], d.in_scale, d.in_elu);
-  else v = d.hist ? d.hist[row * (long)d.hist_len + d.hist_len + t] : 0.f;
-  d.out[row * (long)d.pad + i] = v;
-}
-
-extern "C" int hilc_tail_multi(const hilc_tail_desc* descs, int n, void* stream) {
-  if (!descs) return HILC_ERR_NULL;
-  if (n < 1 || n > HILC_TAIL_MAX) return HILC_ERR_SHAPE;
-  TailMulti m;
-  m.n = n;
-  unsigned blocks = 0;
-  for (int i = 0; i < n; ++i) {
-    const hilc_tail_desc& d = descs[i];
-    if (!d.x || !d.out) return HILC_ERR_NULL;
-    if (d.rows <= 0 || d.T <= 0 || d.pad <= 0) return HILC_ERR_SHAPE;
-    if (d.hist != nullptr && d.hist_len < d.pad - d.T) return HILC_ERR_SHAPE;      // (no history: zeros in front of t = 0)
-    if (d.out == d.hist || d.out == d.x) return HILC_ERR_UNSUPPORTED;
-    const long nb = (d.rows * d.pad + 255) / 256;
-    if (nb + blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
-    m.d[i] = d;
-    m.first_block[i] = blocks;
-    blocks += (unsigned)nb;
-  }
-  m.first_block[n] = blocks;
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL(tail_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
 }
 
 int launch_hist_out(const float* x, const float* hist, float* hist_out, long rows, int T, int pad, int hist_len,
@@ -405,7 +361,7 @@ extern "C" int hilc_conv_post(const float* x, const float* hist, const float* w,
   const bool fast = ksize == 5 && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (hist == nullptr || (reinterpret_cast<uintptr_t>(hist) & 15) == 0);
   HILC_CLEAR_ERROR();
-  if (fast) hipLaunchKernelGGL(conv_post_k5_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (fast) hipLaunchKernelGGL(conv_post_k5_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   HILC_CHECK_LAUNCH();
   if (hist_out)

@@ -2,20 +2,6 @@
 #include "resblock_kernel.h"
 
 namespace {
-__global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* wt, unsigned short* packed, int C, int RH) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed` (bf16 elements)
-  if (idx >= 2 * C * C) return;
-  const int CBW = C / 32 / RH, WPS = 2 * CBW, KS = C / 16;
-  const int e = idx & 7, lane = (idx >> 3) & 63, w = idx >> 9;
-  const int q = w % WPS, ks = (w / WPS) % KS, h = w / (WPS * KS);
-  const int i = q >> 1, part = q & 1;
-  const int k = ks * 16 + 8 * (lane >> 5) + e, m = 32 * (h * CBW + i) + (lane & 31);
-  const float v = wt[(long)k * C + m];
-  const __bf16 hi = (__bf16)v;
-  const __bf16 lo = (__bf16)(v - (float)hi);
-  packed[idx] = __builtin_bit_cast(unsigned short, part ? lo : hi);
-}
-
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C, int RH) {
   const int idx = blockIdx.x * 256 + threadIdx.x;       // index into `packed`
   if (idx >= C * C) return;
@@ -30,7 +16,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, floa
 }  // namespace
 
 namespace {
-int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
+int resblock_entry(bool streaming, const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                    const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
                    float* hist1_out, float* hist2_out, float* y, int* sched, int B, int C, int T, float pre_scale,
                    float out_scale, void* stream) {
@@ -45,6 +31,7 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
   a.y = y; a.T = T; a.tiles = 0; b0.pre_scale = pre_scale; b0.out_scale = out_scale;
   b0.hist1 = hist1; b0.hist2 = hist2; b0.hist1_out = hist1_out; b0.hist2_out = hist2_out;
   a.nblk = 1; a.run_tiles = 0;
+  a.post = ResPost{};
   a.sched = sched;
 #ifdef HILC_DEBUG_STAMPS
   a.dbg = g_dbg;
@@ -54,13 +41,6 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
   if (streaming) {
     if ((hist1 && hist1 == hist1_out) || (hist2 && hist2 == hist2_out)) return HILC_ERR_UNSUPPORTED;   // first / last tiles of a clip race
     if ((long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
-    if (x3) {
-      switch (C) {
-        case 96: return launch_res<96, true, true>(a, B, (hipStream_t)stream);
-        case 192: return launch_res<192, true, true>(a, B, (hipStream_t)stream);
-        default: return HILC_ERR_UNSUPPORTED;
-      }
-    }
     switch (C) {
       case 64: return launch_res<64, true>(a, B, (hipStream_t)stream);
       case 96: return launch_res<96, true>(a, B, (hipStream_t)stream);
@@ -71,13 +51,6 @@ int resblock_entry(bool streaming, bool x3, const float* x, const float* w1t, co
       case 384: return launch_res<384, true>(a, B, (hipStream_t)stream);
       case 512: return 32 % T == 0 ? launch_res<512, true>(a, B, (hipStream_t)stream) : HILC_ERR_UNSUPPORTED;
       case 768: return 32 % T == 0 ? launch_res<768, true>(a, B, (hipStream_t)stream) : HILC_ERR_UNSUPPORTED;
-      default: return HILC_ERR_UNSUPPORTED;
-    }
-  }
-  if (x3 && !streaming) {            // EXPERIMENTAL bf16x3 GEMM phases: the decoder's widths only
-    switch (C) {
-      case 96: return launch_res<96, false, true>(a, B, (hipStream_t)stream);
-      case 192: return launch_res<192, false, true>(a, B, (hipStream_t)stream);
       default: return HILC_ERR_UNSUPPORTED;
     }
   }
@@ -124,7 +97,7 @@ extern "C" int hilc_resblock_pack_weights_rc(const float* wt, float* packed, int
 extern "C" int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const float* dw1_b,
                              const float* w2t, const float* dw2_w, const float* dw2_b, float* y, int B, int C,
                              int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(false, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, nullptr,
+  return resblock_entry(false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, nullptr, nullptr, nullptr, nullptr, y, nullptr,
                         B, C, T, pre_scale, out_scale, stream);
 }
 
@@ -132,7 +105,7 @@ extern "C" int hilc_resblock_stream(const float* x, const float* w1t, const floa
                                     const float* w2t, const float* dw2_w, const float* dw2_b, const float* hist1,
                                     const float* hist2, float* hist1_out, float* hist2_out, float* y, int B, int C,
                                     int T, float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(true, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, nullptr,
+  return resblock_entry(true, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, nullptr,
                         B, C, T, pre_scale, out_scale, stream);
 }
 
@@ -141,29 +114,8 @@ extern "C" int hilc_resblock_balanced(const float* x, const float* w1t, const fl
                                       const float* hist2, float* hist1_out, float* hist2_out, float* y, int* sched,
                                       int streaming, int B, int C, int T, float pre_scale, float out_scale,
                                       void* stream) {
-  return resblock_entry(streaming != 0, false, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y,
+  return resblock_entry(streaming != 0, x, w1t, dw1_w, dw1_b, w2t, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y,
                         sched, B, C, T, pre_scale, out_scale, stream);
-}
-
-extern "C" int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int C, void* stream) {
-  if (!wt || !packed) return HILC_ERR_NULL;
-  if (!(C == 96 || C == 192)) return HILC_ERR_UNSUPPORTED;
-  if ((const void*)wt == packed) return HILC_ERR_UNSUPPORTED;
-  const int RH = C == 192 ? 2 : 1;
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((2 * C * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wt,
-                     reinterpret_cast<unsigned short*>(packed), C, RH);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
-
-extern "C" int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
-                                const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2,
-                                float* hist1_out, float* hist2_out, float* y, int* sched, int streaming, int B, int C, int T,
-                                float pre_scale, float out_scale, void* stream) {
-  return resblock_entry(streaming != 0, true, x, reinterpret_cast<const float*>(w1s), dw1_w, dw1_b,
-                        reinterpret_cast<const float*>(w2s), dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, y, sched, B, C, T,
-                        pre_scale, out_scale, stream);
 }
 
 #ifdef HILC_DEBUG_STAMPS

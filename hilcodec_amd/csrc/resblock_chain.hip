@@ -12,6 +12,13 @@ namespace {
 constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C == 192; }
 }
 
+#ifdef HILC_DEBUG_STAMPS      // tools/stage_phase_times.py builds its own copy of the library with this; never in the product
+extern "C" void hilc_debug_set_chain_stamp_buffer(unsigned long long* p) { g_dbg = p; }
+#define HILC_CHAIN_DBG g_dbg
+#else
+#define HILC_CHAIN_DBG nullptr
+#endif
+
 extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streaming) {
   if (nblk < 2 || nblk > MAXBLK || T <= 0 || T % 4 != 0) return 0;
   // the instantiations hold the carry slots / tap tables of 2 blocks at the encoder's widths and of 3 at the decoder's
@@ -20,28 +27,27 @@ extern "C" int hilc_resblock_chain_supported(int C, int T, int nblk, int streami
   if (nblk > max_blocks) return 0;
   if (chain_width(C)) return 1;
   if (!streaming) return C == 256 || C == 384 || C == 512;          // the wide blocks in the carry form (NARROW shapes)
-  if (C == 256) return 1;                                           // a hop: 32-column tiles, four waves, runs of whole streams with carries
   return (C == 512 || C == 768) && 32 % T == 0;
 }
 
 // packed pointwise weights of a chain launch: the 8-wave shapes split the rows in two classes also below C = 192
 // (offline: C = 64 keeps four waves = one row class; the other widths as in the streaming form)
 extern "C" int hilc_resblock_chain_row_classes_offline(int C) {
-  static_assert(Cfg<64, false, false, false, 2, false>::RH == 1 && Cfg<96, false, false, false, 3, false>::RH == 1 &&
-                Cfg<128, false, false, false, 2, true>::RH == 2 && Cfg<192, false, false, false, 3, false>::RH == 2 &&
-                Cfg<256, false, false, false, 2, false>::RH == 4 && Cfg<384, false, false, false, 3, false>::RH == 4 &&
-                Cfg<512, false, false, false, 2, false>::RH == 8, "packed layout");
-  static_assert(Cfg<768, false, false, false, 1, false, -8>::RH == 8, "packed layout");
+  static_assert(Cfg<64, false, false, 2, false>::RH == 1 && Cfg<96, false, false, 3, false>::RH == 1 &&
+                Cfg<128, false, false, 2, true>::RH == 2 && Cfg<192, false, false, 3, false>::RH == 2 &&
+                Cfg<256, false, false, 2, false>::RH == 4 && Cfg<384, false, false, 3, false>::RH == 4 &&
+                Cfg<512, false, false, 2, false>::RH == 8, "packed layout");
+  static_assert(Cfg<768, false, false, 1, false, -8>::RH == 8, "packed layout");
   if (C == 256 || C == 384) return 4;
   if (C == 512 || C == 768) return 8;
   return C == 128 || C == 192 ? 2 : (chain_width(C) ? 1 : 0);
 }
 
 extern "C" int hilc_resblock_chain_row_classes(int C) {
-  static_assert(Cfg<64, true, false, true, 2, false>::RH == 1 && Cfg<96, true, false, true, 3, false>::RH == 1 &&
-                Cfg<128, true, false, true, 2, true>::RH == 2 && Cfg<192, true, false, true, 3, false>::RH == 2 &&
-                Cfg<512, true, false, false, 2, false>::RH == 8 && Cfg<768, true, false, false, 3, false>::RH == 8, "packed layout");
-  static_assert(Cfg<256, true, false, true, 2, false>::RH == 4 && Cfg<384, true, false, false, 1, false, -5>::RH == 4, "packed layout");
+  static_assert(Cfg<64, true, true, 2, false>::RH == 1 && Cfg<96, true, true, 3, false>::RH == 1 &&
+                Cfg<128, true, true, 2, true>::RH == 2 && Cfg<192, true, true, 3, false>::RH == 2 &&
+                Cfg<512, true, false, 2, false>::RH == 8 && Cfg<768, true, false, 3, false>::RH == 8, "packed layout");
+  static_assert(Cfg<384, true, false, 1, false, -5>::RH == 4, "packed layout");
   if (C == 256 || C == 384) return 4;
   return C >= 512 ? 8 : ((C == 96 || C == 64) ? 1 : (chain_width(C) ? 2 : 0));
 }
@@ -70,9 +76,10 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
   ResArgs a;
-  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   a.up = ResUp{};
+  a.post = ResPost{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (!streaming) {        // offline: the carry form's contiguous runs (hilc_resblock), the blocks of the stage back to back per tile
@@ -92,7 +99,6 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
     case 96: return launch_chain<96, true, 3, false>(a, B, s);         // 3 row blocks do not split in two classes: 4 waves, two workgroups per CU
     case 128: return launch_chain<128, true, 2, true>(a, B, s);
     case 192: return launch_chain<192, true, 3, false>(a, B, s);
-    case 256: return launch_chain<256, true, 2, false>(a, B, s);
     case 512: return launch_chain<512, true, 2, false>(a, B, s);
     case 768: return launch_chain<768, true, 3, false>(a, B, s);
     default: return HILC_ERR_UNSUPPORTED;
@@ -123,9 +129,10 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   if (down->res == down->y) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * 2 * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
   ResArgs a;
-  a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
+  a.post = ResPost{};
   ResDown& d = a.dn;
   d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = streaming ? down->hist : nullptr;
   d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
@@ -153,8 +160,37 @@ extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, 
   return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
+namespace {
+int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, const hilc_post_params* post, int streaming,
+                        int B, int C, int T, void* stream);
+}
+
 extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, int streaming,
                                   int B, int C, int T, void* stream) {
+  return decoder_stage_entry(up, blocks, nblk, y, nullptr, streaming, B, C, T, stream);
+}
+
+// ---- the decoder's LAST stage AND its closing layer in one launch ----------------------------------------------------------------------
+// seanet.py:453-476 (`[Scale, ELU, SConv1d(C, 1, k = 5)]`, then the model's out_scale / tanh) behind the stage of hilc_decoder_stage: the
+// last block leaves ELU(in_scale * y) in the LDS tile and the launch stores the waveform `[B][1][T]` — the stage's `[B][C][T]` output is
+// never written.  == hilc_decoder_stage followed by hilc_conv_post (k = 5), bit for bit (same row classes, same order of the partial sums).
+// Offline model, C = 96 with r = 2 and three blocks (the hil_speech / hil_music decoders' last stage).
+extern "C" int hilc_decoder_stage_post_supported(int C, int T, int nblk, int stride, int ksize) {
+  return C == 96 && stride == 2 && nblk == 3 && ksize == 5 && T > 0 && T % 4 == 0;
+}
+
+extern "C" int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, const hilc_post_params* post,
+                                       int B, int C, int T, void* stream) {
+  if (!post || !post->w || !post->wav) return HILC_ERR_NULL;
+  if (!up) return HILC_ERR_NULL;
+  if (!hilc_decoder_stage_post_supported(C, T, nblk, up->stride, post->ksize)) return HILC_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(post->wav) & 15) return HILC_ERR_UNSUPPORTED;
+  return decoder_stage_entry(up, blocks, nblk, post->wav, post, 0, B, C, T, stream);
+}
+
+namespace {
+int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, const hilc_post_params* post, int streaming,
+                        int B, int C, int T, void* stream) {
   if (!up || !blocks || !y) return HILC_ERR_NULL;
   if (!up->x || !up->tr_w || !up->w_lo || !up->w_hi) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0) return HILC_ERR_SHAPE;
@@ -163,7 +199,7 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
   if (up->hist && up->hist == up->hist_out) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
   ResArgs a;
-  a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = nullptr;
+  a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   ResUp& u = a.up;
@@ -171,6 +207,12 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
   u.hist_out = streaming ? up->hist_out : nullptr; u.in_scale = up->in_scale;
   if (!streaming) u.hist = nullptr;
   hipStream_t s = (hipStream_t)stream;
+  a.post = ResPost{};
+  if (post != nullptr) {
+    a.post.w = post->w; a.post.bias = post->bias; a.post.wav = post->wav; a.post.in_scale = post->in_scale;
+    a.post.out_scale = post->out_scale; a.post.do_tanh = post->do_tanh;
+    return launch_chain<96, false, 3, false, -2, true>(a, B, s);
+  }
   if (streaming) {
     switch (C) {
       case 768: return launch_chain<768, true, 3, false, -8>(a, B, s);
@@ -183,3 +225,4 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
   if (C == 384) return launch_chain<384, false, 3, false, -5>(a, B, s);
   return C == 192 ? launch_chain<192, false, 3, false, -4>(a, B, s) : launch_chain<96, false, 3, false, -2>(a, B, s);
 }
+}  // namespace

@@ -54,16 +54,9 @@ namespace {
 
 constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1, w2_0, w2_1 | w2_2..4, b2]
 
-// Shape of a workgroup.  Offline: ONE 8-wave workgroup per CU (two waves per SIMD) that moves through the phases in
-// lockstep — co-resident workgroups in different phases do not help each other here: beside another wave's MFMA
-// stream a VALU phase gets a fraction of its stand-alone issue rate while the matrix wave gains nothing (fp32 MFMA and
-// VALU share the pipe), and 4-wave workgroups leave SIMDs idle at every barrier.  Tile width 256 columns where the
-// tile fits LDS (C <= 128: 248 of 256 columns useful instead of 120 of 128; a wave owns one 32-column block and all
-// row blocks), 128 columns for C = 192 (a wave owns a column block and HALF of the row blocks).
-// STREAM: 128-column tiles over the flat clip-major column space (hops are short), 4 waves (8 for C = 192).
-#ifndef HILC_RES_WIDE_MASK
-#define HILC_RES_WIDE_MASK 0   // bit 0: C = 64, bit 1: C = 96, bit 2: C = 128 use the wide lockstep shape (tuning: tools/res_bench.py)
-#endif
+// Shape of a workgroup: 128-column tiles for C <= 192 (8 waves at C = 192 and where W8_ says so, else 4: two or three workgroups per
+// CU), the NARROW shapes for C >= 256.  (A 256-column lockstep shape with one 8-wave workgroup per CU was measured three times,
+// rounds 2-4: 3-6 % slower at every width; tools/ history.)
 // run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
 // (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
 // 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
@@ -76,11 +69,6 @@ constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1
 #define HILC_RES_SHARE3_0 0.44
 #define HILC_RES_SHARE3_1 0.31
 #endif
-template <int C>
-constexpr bool wide_shape() {
-  return (C == 64 && (HILC_RES_WIDE_MASK & 1)) || (C == 96 && (HILC_RES_WIDE_MASK & 2)) || (C == 128 && (HILC_RES_WIDE_MASK & 4));
-}
-
 // NB_ > 1: a CHAIN — the NB_ consecutive residual blocks of one stage (seanet.py:316-330 / streaming.py: `blocks[s]`) in ONE
 // launch: per tile the blocks run back to back, the output of block j stays in the x REGISTERS as the input (and shortcut) of
 // block j + 1, only the last block stores; every block has its own carry slots, tap table, weights and (STREAM) caches.  Needs
@@ -90,8 +78,15 @@ constexpr bool wide_shape() {
 // last phase of the launch ("D"): the stage's output never reaches HBM — it goes from the last block's registers through ELU into
 // the LDS tile, two GEMMs (the two halves of the 2C output rows) and the strided depthwise conv, which reads the tile like P3 does
 // (previous 4 columns + own 4 columns per lane) with its own two carry slots.  DR_ = r in {2, 4}: the encoder's first two stages.
-template <int C, bool STREAM, bool X3_ = false, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0>
+// POST_: the decoder's LAST layer (seanet.py:453-476: [Scale, ELU, conv k = 5 C -> 1 with bias] and the final out_scale / tanh, = hilc_conv_post)
+// as the closing phase of the launch ("Q"): the last block leaves ELU(in_scale * y) in the LDS tile instead of storing y, every lane
+// accumulates its rows' taps over its 4 columns (previous columns: left neighbour or a third carry slot), the row classes' partial sums
+// meet in LDS in a fixed order — the order hilc_conv_post uses, so the two forms agree bit for bit — and 128 threads store the waveform:
+// the stage's [B][C][T] output (2.36 GB at 256 clips) is neither written nor read.  Offline carry form, C = 96.
+template <int C, bool STREAM, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0, bool POST_ = false>
 struct Cfg {
+  static constexpr bool POST = POST_;
+  static_assert(!POST_ || (!STREAM && DR_ <= 0 && C <= 192 && !W8_), "closing conv: the offline carry form of a narrow stage");
   static constexpr int NB = NB_;
   static constexpr int DR = DR_ > 0 ? DR_ : 0;
   // DR_ < 0: the stage's UP-SAMPLING layer (seanet.py:431-436: [Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C
@@ -100,32 +95,23 @@ struct Cfg {
   // element, like the loader of hilc_up_conv), two GEMMs accumulate over the 2C rows in k order, + bias -> the x registers.  The
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
-  static_assert(DR_ <= 0 || (!X3_ && (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || (!STREAM && ((DR_ == 5 && C == 256) || (DR_ == 8 && C == 512))))),
+  static_assert(DR_ <= 0 || (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || (!STREAM && ((DR_ == 5 && C == 256) || (DR_ == 8 && C == 512)))),
                 "down-sampling phase: carry form, r = 2 / 4 (C <= 192) or the wide encoder stages of the offline model (C = 256: r = 5, C = 512: r = 8)");
   // carry columns of the down-sampling phase per half of its 2C rows: the strided conv reads k - r = r columns in front of its first
   // output's window; r = 2 / 4: the 4 in front of a lane's group; r = 8: 8; r = 5: up to 9 (a tile does not start on a multiple of 5) -> 12
   static constexpr int DCAR = DR_ <= 0 ? 0 : (DR_ == 5 ? 12 : (DR_ == 8 ? 8 : 4));
-  static_assert(DR_ >= 0 || (!X3_ && ((DR_ == -8 && C >= 512) || (DR_ == -5 && C == 384) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_)))),
+  static_assert(DR_ >= 0 || ((DR_ == -8 && C >= 512) || (DR_ == -5 && C == 384) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_))),
                 "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form), the C = 384 stage (r = 5) or the carry form (r = 4 / 2)");
-  static constexpr bool X3 = X3_;                   // EXPERIMENTAL: GEMM phases on the bf16 pipe with split operands (below)
   static constexpr int CH = C;
   static constexpr int CB = C / 32;
-  static constexpr bool WIDE = !STREAM && wide_shape<C>();
   // NARROW (C >= 256: the wide blocks — of a streaming hop, 8 or 40 frames per stream, and since round 4 of the offline model): the
   // whole channel range of a 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).
   // STREAM: at 32 columns a tile is whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the
   // previous samples, so there is no halo to recompute; 64-column tiles walk the flat column space with an 8-column halo.
   // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
   static constexpr bool NARROW = C >= 256;
-  // STREAM + SCARRY at C = 256 (the chain of a hop, round 4): 32-column tiles and FOUR waves, one per row class, two workgroups per CU.  A
-  // stream of 40 samples does not tile 64 columns, but 4 streams are exactly 5 tiles of 32: 1 024 streams = 256 runs of whole streams, no
-  // halo (12.5 % of a 64-column flat tile), no partly filled tile, and carries — hence a chain — inside a run.  OPT-IN
-  // (`ExecOptions.stream_wide_chains`, off): the launch alone 0.278 -> 0.249 ms, the hop it sits in 4.861 -> 4.905 ms (graph, same box).
-  // (C = 384 the same way: bit-identical, but its 141 KB of LDS allow one four-wave workgroup per CU — the stage 1.07 -> 1.32 ms; it
-  // keeps the halo form on 64-column tiles with eight waves.)
-  static constexpr bool NARROW4 = NARROW && STREAM && SCARRY_ && C < 512;
-  static constexpr int NCOL = WIDE ? 256 : (NARROW ? ((C >= 512 || NARROW4) ? 32 : 64) : 128);      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
+  static constexpr int NCOL = NARROW ? (C >= 512 ? 32 : 64) : 128;      // tile width = LDS row stride (floats)
+  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR + (POST_ ? 4 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
   // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
@@ -136,7 +122,7 @@ struct Cfg {
   static constexpr bool CARRYMODE = !STREAM || SCARRY_;
   static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = NARROW4 ? 4 : ((WIDE || C >= 192 || W8_) ? 8 : 4);           // waves per workgroup
+  static constexpr int NW = (C >= 192 || W8_) ? 8 : 4;           // waves per workgroup
   static constexpr int NT = 64 * NW;
   static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
   static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
@@ -203,6 +189,16 @@ struct ResDown {      // the stage's down-sampling layer (DR > 0)
   float in_scale;
 };
 
+struct ResPost {      // the decoder's last layer as the closing phase (POST)
+  const float* w;     // [C][5]
+  const float* bias;  // [1] or NULL
+  float* wav;         // [B][1][T]
+  float in_scale, out_scale;
+  int do_tanh;
+};
+
+constexpr int POST_CLASSES = 8;   // row classes of the closing conv's reduction (= hilc_conv_post's: c mod 8), summed in ascending order
+
 constexpr int MAXBLK = 3;
 constexpr int DDS = 12;   // per-row table of the down-sampling taps in LDS: [w_0..3 | w_4..7 | b, -, -, -]
 
@@ -212,6 +208,7 @@ struct ResArgs {
   int nblk;
   ResDown dn;
   ResUp up;
+  ResPost post;
   long run_tiles;     // chain launches on the streaming column space: tiles per run (whole streams), 0 = equal split of the grid
   float* y;
   int T, tiles;
@@ -307,22 +304,11 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
       for (int i = 0; i < CBW; ++i) {
         const int n = j * CBW + i;                   // MFMA index inside the set
         if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        // The pure MFMA intrinsic is free to move at IR level and hipcc sinks a whole GEMM phase's MFMAs below all of
-        // its operand loads (every operand then spills).  Default: builtins pinned per register set (end of this loop);
-        // -DHILC_RES_ASM_MFMA: the former form, a volatile asm per MFMA (keeps its place among the loads, but hides the
-        // instruction's hazards from the compiler).
-#ifndef HILC_RES_ASM_MFMA        // builtin MFMAs, pinned per register set (below); HILC_RES_ASM_MFMA = the former asm form, for A/B
         if (ZERO && s == 0 && j == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-#else
-        if (s == 0 && j == 0)      // first k-pair: C = 0 as an inline constant instead of 16 zeroed registers per block
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
-        else
-          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(wp.a[cur][j][i]), "v"(b[cur][j]));
-#endif
       }
     }
     if (more) {
@@ -330,22 +316,14 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const f
       wn += WPS * 256;
       asm volatile("" : "+v"(xn), "+s"(wn));
     }
-#ifndef HILC_RES_ASM_MFMA
     // pin the set: an empty asm that "updates" the accumulators and clobbers memory keeps this set's MFMAs above it and
     // the later sets' loads below it.  The builtins are pure, and left alone hipcc sinks a whole phase's MFMAs under all of
     // its operand loads (~300 spilled registers); pinned, they schedule as written, need fewer registers than the asm form
-    // (C = 192: 202 instead of 219) and — unlike asm — carry their hazard information: the bf16x3 phases, first written
-    // with asm MFMAs fed by VALU conversions, produced rare garbage tiles that no manual wait state fixed.
+    // (C = 192: 202 instead of 219) and — unlike an asm MFMA (rounds 1-2) — carry their hazard information: split-bf16 phases
+    // written with asm MFMAs fed by VALU conversions produced rare garbage tiles that no manual wait state fixed.
 #pragma unroll
     for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
-#endif
   }
-#ifndef HILC_RES_ASM_MFMA
-  return;
-#endif
-  // the accumulators are read next by non-MFMA instructions (ds_write after a barrier): the compiler cannot see
-  // into the asm, so the 16-pass MFMA -> VALU/DS read hazard (18 wait states) is covered by hand
-  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 }
 
 // The same phase ROLLED, for the wide channel counts of the NARROW stream shapes (C = 768: 96 register sets of 12 MFMAs —
@@ -410,109 +388,6 @@ __device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, 
   group(true);
 }
 
-// ---- EXPERIMENTAL bf16x3 GEMM phases (hilc_resblock_x3; opt-in, offline decoder only; see gemm_x3.h for the arithmetic) ----
-// Only the two GEMM phases change: the tile in LDS stays fp32 (the depthwise / ELU phases are untouched).  A wave reads
-// the 8 consecutive k of its column for a 16-deep step with eight ds_read_b32, splits them in registers (2.5 VALU per
-// value) and feeds three v_mfma_f32_32x32x16_bf16 per row block; the weights arrive pre-split and packed in lane order
-//   packed16[((((h * C/16 + ks) * CBW + i) * 2 + part) * 64 + lane) * 8 + e] = part(W[ks*16 + 8*(lane >> 5) + e][32*(h*CBW + i) + (lane & 31)])
-// (one 16-B word per lane, row block and part: hilc_resblock_pack_weights_x3; same byte size as the fp32 packing).
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-
-template <class K>
-struct X3Pipe {
-  static constexpr int CBW = K::CBW;
-  static constexpr int DEPTH = 3;                 // 16-deep steps between a weight load and its use
-  static constexpr int WPS = 2 * CBW;             // 16-B words per lane and step
-  f32x4 a[DEPTH][CBW][2];
-  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
-    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
-    a[slot][q >> 1][q & 1] = *(gvec_t)(wset + q * 256 + lane * 4);
-  }
-  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
-  }
-};
-
-// 8 fp32 -> bf16 heads and bf16 heads of the remainders, as two 4-register MFMA operands
-__device__ __forceinline__ void split8(const float (&v)[8], f32x4& hi, f32x4& lo) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const f32x2 x = {v[2 * p], v[2 * p + 1]};
-    const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
-    const f32x2 r = x - __builtin_convertvector(h, f32x2);
-    const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
-    hi[p] = __builtin_bit_cast(float, h);
-    lo[p] = __builtin_bit_cast(float, l);
-  }
-}
-
-template <class K>
-__device__ __forceinline__ void gemm_phase_x3(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                              X3Pipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS, CBW = K::CBW;
-  constexpr int DEPTH = X3Pipe<K>::DEPTH, WPS = X3Pipe<K>::WPS;
-  constexpr int KS = C / 16;
-  const int kh = lane >> 5, l31 = lane & 31;
-  lptr_t xn = (lptr_t)(X + 8 * kh * XS + colblk * 32 + l31);   // this lane's column, rows 8 kh .. 8 kh + 7 of step 0
-  float br[2][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) br[0][j] = xn[j * XS];
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;
-#pragma unroll
-  for (int i = 0; i < CBW; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
-    const bool more = s + DEPTH - 1 < KS;
-    if (s + 1 < KS) {
-      xn += 16 * XS;
-      asm volatile("" : "+v"(xn));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) br[(s + 1) & 1][j] = xn[j * XS];
-    }
-    f32x4 b1, b2;
-    split8(br[s & 1], b1, b2);
-    // Three passes over the row blocks (small terms first).  Builtins, not asm (unlike gemm_phase): with asm MFMAs fed by
-    // VALU conversions this phase produced rare garbage tiles (more often with two workgroups per CU) that neither
-    // early-clobber outputs nor spacing the dependent MFMAs removed — the compiler cannot place hazard wait states or
-    // protect operand registers around an instruction it cannot see into.  A 16-deep step is only 9 MFMAs, and the
-    // scheduling barrier per step keeps the builtin MFMAs from being sunk below the next steps' loads.
-    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-    const bf16x8_t vb1 = __builtin_bit_cast(bf16x8_t, b1), vb2 = __builtin_bit_cast(bf16x8_t, b2);
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) {
-      if (more) {
-        wp.load_word((gptr_t)wn, nxt, 2 * i, lane);
-        wp.load_word((gptr_t)wn, nxt, 2 * i + 1, lane);
-      }
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][1]), vb1, acc[i], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < CBW; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb2, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < CBW; ++i)
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wp.a[cur][i][0]), vb1, acc[i], 0, 0, 0);
-    if (more) {
-      wn += WPS * 256;
-      asm volatile("" : "+s"(wn));
-    }
-    // pin the step: an empty asm that "updates" the accumulators and clobbers memory keeps this step's MFMAs above it and
-    // the next steps' loads below it (the builtins are pure: without it hipcc sinks them under every later load and
-    // spills ~120 registers at C = 192)
-    if constexpr (CBW == 3) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) :: "memory");
-    else {
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
-    }
-  }
-}
-
 template <class K>
 __device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[K::CBW], float* X, int rowblk0, int colblk, int lane) {
   constexpr int XS = K::XS;
@@ -543,11 +418,11 @@ struct Cols {          // (no padding bytes: the struct is copied, and hipcc kee
 };
 static_assert(sizeof(Cols) == 32, "no padding");
 
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false, int NB = 1, bool W8 = false, int DRU = 0>
-__global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>;
+template <int C, bool STREAM, bool SCARRY = false, int NB = 1, bool W8 = false, int DRU = 0, bool POST = false>
+__global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>;
   constexpr int DR = K::DR, UR = K::UR;
-  using Pipe = typename std::conditional<X3, X3Pipe<K>, WeightPipe<K>>::type;
+  using Pipe = WeightPipe<K>;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
   // 4 floats in front of the tile: the "previous 4 columns" read of column group 0 (discarded halo outputs) stays a
   // plain base + constant address instead of a select
@@ -561,6 +436,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
   // STREAM, T >= 128 (at most one clip start per tile): that clip's two caches, staged before P0 so that P3 / P6
   // do not pay one exposed global-load latency per row for the single lane that needs them
   __shared__ __attribute__((aligned(16))) float HS[(STREAM && !K::NARROW) ? 2 * C * 4 : 4];
+  // POST: the row classes' partial sums of the closing conv, [class][column]
+  __shared__ __attribute__((aligned(16))) float PR[POST ? POST_CLASSES * K::NCOL : 4];
+  static_assert(!POST || (K::RPI * K::NW == POST_CLASSES), "a row class of the closing conv = the rows one half-wave walks");
   float* const X = Xbuf + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
@@ -778,7 +656,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
       // a clip's first tile: the zero padding in front of t = 0 is a zero carry (the end-of-tile barrier is behind us, P3 reads
       // it two barriers from here).  (STREAM: column group 0 of a stream's first tile is a head and takes the cache.)
       if (tile % a.tiles == 0) {
-        constexpr int NSLOT = 2 * NB + K::DCAR / 2;      // 4-float slots behind a row: H1 / H2 per block + the down-sampling phase's two halves
+        constexpr int NSLOT = 2 * NB + K::DCAR / 2 + (POST ? 1 : 0);      // 4-float slots behind a row: H1 / H2 per block + the down-sampling phase's two halves (+ the closing conv's)
         for (int e = tid; e < NSLOT * C; e += NT)
           *reinterpret_cast<f32x4*>(X + (e / NSLOT) * XS + K::NCOL + (e % NSLOT) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -909,7 +787,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
     for (int blk = 0; blk < nblk; ++blk) {
     const ResBlk& bp = a.blk[NB == 1 ? 0 : blk];
     const bool final_blk = NB == 1 || blk == nblk - 1;      // uniform
-    const bool last_blk = DR == 0 && final_blk;             // the block whose output leaves the kernel (DR > 0: none, the D phase follows)
+    const bool last_blk = DR == 0 && !POST && final_blk;    // the block whose output leaves the kernel (DR > 0 / POST: none, the D / Q phase follows)
+    [[maybe_unused]] const bool post_blk = POST && final_blk;   // ... whose ACTIVATED output goes to the tile for the closing conv
     Cols cn = cs;                                           // the next tile's columns: needed by the chain's last block only
     bool have_next = false;
     if constexpr (NB > 1) blk_off = 8 * blk;
@@ -983,8 +862,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
 
     f32x16 acc[CBW];
     // ---- P1, P2
-    if constexpr (X3) gemm_phase_x3<K>(w1t, X, acc, wp, colblk, lane);
-    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
+    if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
     lds_barrier();
     STAMP(2);
@@ -1042,8 +920,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
     STAMP(4);
 
     // ---- P4
-    if constexpr (X3) gemm_phase_x3<K>(w2t, X, acc, wp, colblk, lane);
-    else if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
+    if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
@@ -1121,11 +998,14 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
           s = __fmul_rn(__fadd_rn(s, wc[i].w), bp.out_scale);
           o[e] = __fadd_rn(s, xr[i0 + i][e]);
         }
-        if constexpr (NB == 1 && DR == 0) {
+        if constexpr (NB == 1 && DR == 0 && !POST) {
           if (out_ok) *yrow(cs, m) = o;
         } else {
           if (last_blk) {
             if (out_ok) *yrow(cs, m) = o;
+          } else if (post_blk) {
+            // the closing conv's operand, in place (this batch's rows were read above; a row is one wave instruction: read before write)
+            *(lvec_t)(xp6 + i * RSTEP * XS) = prologue4v(o, a.post.in_scale, 1);
           } else {
             xr[i0 + i] = o;                // the next block of the chain: its input and its shortcut (P0 zeroes what lies outside [0, T))
           }
@@ -1144,6 +1024,61 @@ __global__ __launch_bounds__((Cfg<C, STREAM, X3, SCARRY, NB, W8, DRU>::NT), (Cfg
     lds_barrier();   // the next block's / tile's P0 overwrites X
     if (last_blk) cs = cn;
     }                // blocks of the chain
+    if constexpr (POST) {
+      // ---- Q: wav = post(sum_c sum_j w[c][j] * a[c][t - 4 + j] + bias), a = ELU(in_scale * y) left in the tile by the last block's P6
+      //      (its closing barrier is behind us).  Row class q = the rows q, q + 8, ... one half-wave walks: an fmaf chain over (row, tap)
+      //      ascending per class and column, then the classes in ascending order — hilc_conv_post's order.
+      const bool have_next = next_tile < run1;
+      const Cols cn = columns_of(have_next ? next_tile : tile);
+      constexpr int PSLOT = K::NCOL + 8 * NB;                // the conv's carry slot behind a row: a's last 4 columns of the previous tile
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      lptr_t xq = (lptr_t)(X + rsub * XS + c4);
+      lptr_t pq = lane0 ? (lptr_t)(X + rsub * XS + PSLOT) : (lptr_t)(X + rsub * XS + c4 - 4);
+      const float* wq = a.post.w + rsub * 5;
+      // (rolled: unrolled, hipcc hoists every batch's tap loads to the top of the phase — 60 registers, spills)
+#pragma nounroll
+      for (int i0 = 0; i0 < RW; i0 += RB) {
+        f32x4 cur[RB], prev[RB];
+        float w[RB][5];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          cur[i] = *(lvec_t)(xq + i * RSTEP * XS);
+          prev[i] = *(lvec_t)(pq + i * RSTEP * XS);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) w[i][j] = wq[i * RSTEP * 5 + j];
+        }
+        wq += RB * RSTEP * 5;
+        if (lane_last) {
+#pragma unroll
+          for (int i = 0; i < RB; ++i) *(lvec_t)(xq + i * RSTEP * XS + 4 + 8 * NB) = cur[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const float v[8] = {prev[i].x, prev[i].y, prev[i].z, prev[i].w, cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) part[e] = fmaf(w[i][j], v[e + j], part[e]);
+        }
+        xq += RB * RSTEP * XS;
+        pq += RB * RSTEP * XS;
+        asm volatile("" : "+v"(xq), "+v"(pq));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      *reinterpret_cast<f32x4*>(&PR[rsub * K::NCOL + c4]) = f32x4{part[0], part[1], part[2], part[3]};
+      lds_barrier();       // partial sums visible; every wave is done reading the tile (the next tile's first phase writes it)
+      if (tid < K::NCOL) {
+        float sacc = PR[tid];
+#pragma unroll
+        for (int q = 1; q < POST_CLASSES; ++q) sacc = __fadd_rn(sacc, PR[q * K::NCOL + tid]);
+        if (a.post.bias != nullptr) sacc = __fadd_rn(sacc, a.post.bias[0]);
+        sacc = __fmul_rn(sacc, a.post.out_scale);
+        if (a.post.do_tanh) sacc = tanhf(sacc);
+        const int t = cs.t - c4 + tid;                         // offline: cs.t = the tile's first column + c4
+        if (!warm && t < T) a.post.wav[cs.b * (long)T + t] = sacc;
+      }
+      cs = cn;             // (PR is next written seven barriers from here)
+    }
     if constexpr (DR > 0) {
       // ---- D: the stage's down-sampling layer on the tile the last block left in the x registers
       const ResDown& dn = a.dn;
@@ -1443,10 +1378,10 @@ inline void set_div_magic(ResArgs& a) {
 // fill whole tiles; runs are made of as many units as it takes for all runs to be resident at once (1024 streams x 320 samples,
 // 256 workgroups: 4 streams = 10 tiles each), the last run may be short.  STREAM NARROW (C >= 512): whole-stream tiles, static
 // stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
-template <int C, bool STREAM, int NB, bool W8, int DR = 0>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR)
+template <int C, bool STREAM, int NB, bool W8, int DR = 0, bool POST = false>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR); POST: + closing conv
 int launch_chain(ResArgs a, int B, hipStream_t s) {
-  constexpr bool SC = STREAM && C <= 256;         // runs of whole streams with carries (C = 384: flat tiles with a halo; C >= 512: whole-stream tiles, static stride)
-  using K = Cfg<C, STREAM, false, SC, NB, W8, DR>;
+  constexpr bool SC = STREAM && C <= 192;         // runs of whole streams with carries (C = 384: flat tiles with a halo; C >= 512: whole-stream tiles, static stride)
+  using K = Cfg<C, STREAM, SC, NB, W8, DR, POST>;
   a.B = B;
   set_div_magic(a);
   constexpr int TO = K::TO;
@@ -1456,7 +1391,7 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
   a.run_tiles = 0;
   static std::atomic<int> resident_cache[64];
   int n_cu = 0;
-  const long resident = resident_workgroups(resblock_kernel<C, STREAM, false, SC, NB, W8, DR>, K::NT, resident_cache, n_cu);
+  const long resident = resident_workgroups(resblock_kernel<C, STREAM, SC, NB, W8, DR, POST>, K::NT, resident_cache, n_cu);
   if (resident < 1) return HILC_ERR_LAUNCH;
   long blocks;
   if constexpr (SC) {
@@ -1472,12 +1407,12 @@ int launch_chain(ResArgs a, int B, hipStream_t s) {
     if constexpr (!STREAM) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, false, SC, NB, W8, DR>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, SC, NB, W8, DR, POST>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }
 
-template <int C, bool STREAM, bool X3 = false, bool SCARRY = false>
+template <int C, bool STREAM, bool SCARRY = false>
 int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
   a.nblk = 1;
   a.run_tiles = 0;
@@ -1490,7 +1425,7 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
     a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
     a.div_shift = (unsigned)(l - 1);
   }
-  using K = Cfg<C, STREAM, X3, SCARRY>;
+  using K = Cfg<C, STREAM, SCARRY>;
   constexpr int TO = K::TO;
   a.tiles = (a.T + TO - 1) / TO;
   a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
@@ -1505,13 +1440,13 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
     int n_cu = 0, occ = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
       return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, X3, SCARRY>, K::NT, 0) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, SCARRY>, K::NT, 0) != hipSuccess || occ < 1)
       return HILC_ERR_LAUNCH;
     cached = n_cu * occ;
     if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
   }
   const long resident = cached;
-  if constexpr (STREAM && !SCARRY && !X3 && (C == 96 || C == 192)) {
+  if constexpr (STREAM && !SCARRY && (C == 96 || C == 192)) {
     // The carry form for this hop?  Only where every run is the same whole number of streams (so that no run starts inside a
     // stream and pays a warm-up tile) and the runs are fewer tile-times than the rounds of the halo form.
     constexpr int NC = K::NCOL;
@@ -1523,7 +1458,7 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
       const long units = cols / (unit * NC);
       const long k = (units + resident - 1) / resident;                          // aligned runs per workgroup (same residency: 8 KB of LDS more)
       const long halo_rounds = (a.total_tiles + resident - 1) / resident;
-      if (units % k == 0 && k * unit < halo_rounds) return launch_res<C, STREAM, X3, true>(a, B, s, units / k);
+      if (units % k == 0 && k * unit < halo_rounds) return launch_res<C, STREAM, true>(a, B, s, units / k);
     }
   }
   long blocks = a.total_tiles < resident ? a.total_tiles : resident;
@@ -1534,7 +1469,7 @@ int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) set_class_shares(a, blocks, resident, n_cu);
   }
   HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, X3, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
+  hipLaunchKernelGGL((resblock_kernel<C, STREAM, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
 }

@@ -511,11 +511,11 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   // SIMD to hide the L2 round trips of the code words (256 x 4: 143 us, 512 x 2: 96 us, 1024 x 1: 107 us; 8 / 16 frames per
   // workgroup: 240 / 369 us — profiles/r04_experiments.md)
   // large batches: the score GEMM on the matrix pipe, 32 frames per workgroup (two workgroups per CU)
-#ifdef HILC_RVQ_ENV       // tuning builds only (tools/rvq_ab.sh): HILC_RVQ_VALU=1 in the environment keeps the VALU form
+  // HILC_RVQ_VALU in the environment (read once) keeps large batches on the VALU form (16 frames per workgroup): the switch an operator has
+  // if a future part's fp32 MFMA should ever stop accumulating as a sequential fmaf chain over ascending k — which is what makes
+  // the two forms, hence offline and streaming indices, identical; tests/test_gpu_rvq.py pins that on every box it runs on, and
+  // runs this branch too.
   static const bool valu_only = getenv("HILC_RVQ_VALU") != nullptr;
-#else
-  constexpr bool valu_only = false;
-#endif
   if (nframes >= 32 * 256 && !valu_only)
     hipLaunchKernelGGL((rvq_encode_mfma_kernel<128>), dim3((unsigned)((nframes + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
   else if (nframes <= 16 * 512)

@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import contextlib
 import contextvars
-import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -34,30 +33,27 @@ FUSE_RESBLOCK_MAX_C = 192
 
 @dataclass
 class ExecOptions:
-    """Execution options of ONE model's encoder or decoder (held by the module, passed to run_encoder / run_decoder):
-    two models in one process may run different arithmetic and schedules side by side — nothing here is process-global.
+    """Launch structure of ONE model's encoder or decoder (held by the module, passed to run_encoder / run_decoder): two models
+    in one process may run different schedules side by side — nothing here is process-global.  Every setting computes the SAME
+    bits (tests pin each against the others); the defaults are the fastest measured.  The arithmetic is the reference's fp32
+    throughout: the split-bf16 decoder mode of rounds 2-4 and the launch variants that were measured slower (batched cache
+    updates, four-wave C = 256 chains, the 256-column lockstep shape) are gone from the library (round 5; `profiles/r05_experiments.md`).
 
-    decoder_gemm: "fp32" = the reference's arithmetic (default).  "bf16x3" is EXPERIMENTAL and opt-in: the GEMMs of the
-    DECODER (offline and streaming: up-sampling, wide depthwise-separable layers, the GEMM phases of the fused residual
-    blocks) run on the bf16 matrix pipe with split operands (csrc/gemm_x3.h: 16 significant bits per operand, fp32
-    accumulation).  The encoder and the RVQ — hence every index — are never touched by it.
-    stream_wide_blocks: same arithmetic either way (tests pin one launch against two, bit for bit)."""
-    decoder_gemm: str = "fp32"
-    x3_fused_block_min_c: int = 10 ** 9   # residual blocks of at least this width leave the fused kernel for two bf16x3 launches
-    x3_fused_blocks: bool = True           # in bf16x3 mode the decoder's fused blocks (C = 192 / 96) run their GEMM phases in bf16x3 too
-    stream_wide_blocks: bool = True        # streaming hop: the wide residual blocks (C = 256 ... 768) as ONE launch (False: two, as in round 2)
-    fuse_decoder_stage_narrow: bool = True  # ... the carry-form stages (C = 192 / 96) too.  PipelinedHop captures with False: next to a second chain the long
-                                            # one-workgroup-per-CU launches leave it nothing to co-reside with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90)
-    fuse_decoder_stage: bool = True        # decoder stages with C = 192 / 96 (a streaming hop: also C = 768) as one launch — up-sampling layer + residual blocks (hilc_decoder_stage)
-    fuse_decoder_stage_partial: bool = True  # ... and where LDS holds one block only behind the up-sampling phase (offline C = 768, streaming C = 384): up-sampling layer + FIRST block
-    fuse_encoder_stage_wide: bool = True   # ... and, offline, the wide stages C = 256 (r = 5) / C = 512 (r = 8)
-    fuse_encoder_stage: bool = True        # encoder stages with C = 64 / 128: residual blocks AND down-sampling layer in one launch (hilc_encoder_stage); False: chain + separate layer
-    offline_wide_blocks: bool = True       # offline: the wide residual blocks (C = 256 ... 768) as ONE carry-form launch each / per stage (False: two hilc_dws_conv launches per block, as until round 4)
-    offline_chain_blocks: bool = True      # offline: the residual blocks of a stage (C <= 192) as ONE launch (False: one launch per block, as in round 3; same-box A/B: 82.5 -> 81.3 ms)
-    stream_batch_tails: bool = False       # streaming hop: cache updates that are launches of their own (up-sampling caches, conv_post's, the waveform tail) as ONE launch per half (hilc_tail_multi) — built, bit-identical, measured +-0 / -1.4 % (pipelined): off (profiles/r04_experiments.md)
-    stream_defer_spec: bool = True         # streaming hop: SpecBlock branches of stages >= 1 computed alone and added by the down-sampling epilogue in front (False: in-line, as in round 3)
-    stream_wide_chains: bool = False       # streaming hop: the two C = 256 blocks as a chain on 32-column tiles with four waves and carries (runs of whole streams).  Built, bit-identical, faster alone (0.278 -> 0.249 ms) and SLOWER inside the hop (graph 4.861 -> 4.905 ms, pipelined 4.710 -> 4.721, same box): off (profiles/r04_experiments.md)
-    stream_chain_blocks: bool = True       # streaming hop: the residual blocks of a STAGE as one launch where the kernel exists (False: one launch per block, as in round 3)
+    stage_launches: a whole stage per launch — its residual blocks back to back per tile and its down-sampling (encoder) /
+      up-sampling (decoder) layer as the last / first phase (`hilc_encoder_stage`, `hilc_decoder_stage`, `hilc_resblock_chain`).
+      False: one launch per residual block and per layer (round 3's structure).
+    wide_blocks: the residual blocks with C >= 256 in the fused kernel (one launch per block or stage); False: two
+      depthwise-separable GEMM launches per block with the mid tensor in HBM (round 3's structure).
+    decoder_stage_narrow: (with stage_launches) the decoder stages that run ONE long workgroup per CU — C = 192 / 96, and the
+      forms that hold one block behind the up-sampling phase (offline C = 768, a hop's C = 384) — take their up-sampling layer
+      into the launch.  `PipelinedHop` captures with False: beside a second chain those launches leave it nothing to co-reside
+      with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90).
+    stream_defer_spec: streaming hop: the SpecBlock branches of stages >= 1 computed alone and added by the down-sampling
+      epilogue in front (False: in-line, as in round 3)."""
+    stage_launches: bool = True
+    wide_blocks: bool = True
+    decoder_stage_narrow: bool = True
+    stream_defer_spec: bool = True
 
 
 _DEFAULT_OPTIONS = ExecOptions()
@@ -97,18 +93,6 @@ def spectra_side_stream(stream):
         yield
     finally:
         _SIDE_STREAM.reset(token)
-_X3_SPLIT = {}            # id(weight tensor) -> (weak reference, version, split form); built on first use, dies with the weight
-
-
-def _x3(wt: Tensor, pack=None) -> Tensor:
-    """split form of a k-major weight matrix (`pack` = ops.resblock_x3_pack for the fused block's lane-ordered layout)"""
-    pack = pack or ops.x3_split
-    key = (id(wt), pack.__name__)
-    hit = _X3_SPLIT.get(key)
-    if hit is None or hit[0]() is not wt or hit[1] != wt._version:      # new tensor at a recycled id, or weights updated in place
-        hit = (weakref.ref(wt, lambda _, k=key: _X3_SPLIT.pop(k, None)), wt._version, pack(wt))
-        _X3_SPLIT[key] = hit
-    return hit[2]
 
 
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
@@ -282,46 +266,20 @@ def _fusable(rb: ResBlockSpec, x: Tensor, streaming: bool = False, wide: Optiona
 
 
 def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], new_caches: Optional[list],
-              outs: Optional[Sequence[Tensor]] = None, x3: bool = False, opts: ExecOptions = _DEFAULT_OPTIONS) -> Tensor:
+              outs: Optional[Sequence[Tensor]] = None, opts: ExecOptions = _DEFAULT_OPTIONS) -> Tensor:
     """One residual block; streaming: `caches` = its two depthwise caches, `outs` = where the next hop's caches go
-    (persistent state block) or None (fresh tensors, the reference's protocol).  `x3`: offline decoder block in the
-    experimental bf16x3 mode."""
+    (persistent state block) or None (fresh tensors, the reference's protocol)."""
     o0, o1 = (outs[0], outs[1]) if outs is not None else (None, None)
-    if (x3 and caches is None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5
-            and ops.x3_supported(x.shape[1], x.shape[1], x.shape[2], x.shape[0])
-            and (not _fusable(rb, x) or x.shape[1] >= opts.x3_fused_block_min_c)):
-        g = ops.dws_conv_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, in_scale=rb.pre_scale, in_elu=True, out_elu=True)
-        return ops.dws_conv_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, res=x, out_scale=rb.out_scale)
-    if (x3 and opts.x3_fused_blocks and caches is None and _fusable(rb, x) and ops.resblock_x3_supported(x.shape[1], x.shape[2], x.shape[0])):
-        return ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
-                               _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale)
-    if caches is None and _fusable(rb, x, False, opts.offline_wide_blocks and not x3):
+    if caches is None and _fusable(rb, x, False, opts.wide_blocks):
         # one launch per block: x is read once, y written once, everything else stays in LDS
         return ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                             rb.pre_scale, rb.out_scale)
-    if (x3 and opts.x3_fused_blocks and caches is not None and x.shape[2] >= 4 and _fusable(rb, x, True)
-            and ops.resblock_x3_supported(x.shape[1], x.shape[2], x.shape[0])):
-        y, cs = ops.resblock_x3(x, _x3(rb.pw1_wt, ops.resblock_x3_pack), rb.dw1_w, rb.dw1_b,
-                                _x3(rb.pw2_wt, ops.resblock_x3_pack), rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale,
-                                hist=(caches[0], caches[1]), hist_out=outs)
-        new_caches.extend(cs)
-        return y
-    if (caches is not None and x.shape[2] >= 4 and not (x3 and x.shape[1] > FUSE_RESBLOCK_MAX_C)
-            and _fusable(rb, x, True, opts.stream_wide_blocks)):
+    if caches is not None and x.shape[2] >= 4 and _fusable(rb, x, True, opts.wide_blocks):
         # streaming hop: same kernel, the two depthwise caches patch the first tile's halo columns; the wide blocks of a hop
-        # (C = 256 ... 768) take its narrow-tile shapes (in bf16x3 mode they stay two bf16x3 launches, below)
+        # (C = 256 ... 768) take its narrow-tile shapes
         y, cs = ops.resblock(x, rb.pw1_packed, rb.dw1_w, rb.dw1_b, rb.pw2_packed, rb.dw2_w, rb.dw2_b,
                              rb.pre_scale, rb.out_scale, hist=(caches[0], caches[1]), hist_out=outs)
         new_caches.extend(cs)
-        return y
-    if (x3 and caches is not None and FUSE_STREAM
-            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw1_w.shape[1], 1, x.shape[0])
-            and ops.dws_conv_stream_x3_supported(x.shape[1], x.shape[1], x.shape[2], rb.dw2_w.shape[1], 1, x.shape[0])):
-        g, c0 = ops.dws_conv_stream_x3(x, _x3(rb.pw1_wt), rb.dw1_w, rb.dw1_b, caches[0], in_scale=rb.pre_scale, in_elu=True,
-                                       out_elu=True, hist_out=o0)
-        y, c1 = ops.dws_conv_stream_x3(g, _x3(rb.pw2_wt), rb.dw2_w, rb.dw2_b, caches[1], res=x, out_scale=rb.out_scale,
-                                       hist_out=o1)
-        new_caches.extend([c0, c1])
         return y
     if (caches is not None and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], rb.dw1_w.shape[1], 1)
             and ops.dws_conv_stream_profitable(x.shape[2], rb.dw2_w.shape[1], 1)):
@@ -351,16 +309,15 @@ def _resblock(rb: ResBlockSpec, x: Tensor, caches: Optional[Sequence[Tensor]], n
 
 
 def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Sequence[Tensor]], ci: int, new_caches: Optional[list],
-                  caches_out: Optional[Sequence[Tensor]], x3: bool, opts: ExecOptions) -> Tensor:
-    """The residual blocks of one stage.  Streaming hop, fp32: ONE chain launch where the kernel exists (the blocks run back to
-    back per tile, the activations between them stay in registers: `ops.resblock_chain`); otherwise block by block."""
+                  caches_out: Optional[Sequence[Tensor]], opts: ExecOptions) -> Tensor:
+    """The residual blocks of one stage: ONE chain launch where the kernel exists (the blocks run back to back per tile, the
+    activations between them stay in registers: `ops.resblock_chain`); otherwise block by block."""
     n = len(blocks)
     streaming = caches is not None
-    if (streaming and not x3 and FUSE_RESBLOCK and FUSE_STREAM and opts.stream_chain_blocks and n >= 2 and x.shape[2] >= 4
+    if (streaming and FUSE_RESBLOCK and FUSE_STREAM and opts.stage_launches and n >= 2 and x.shape[2] >= 4
             and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                     and rb.dw2_b is not None for rb in blocks)
-            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.stream_wide_blocks)
-            and (x.shape[1] != 256 or opts.stream_wide_chains)
+            and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.wide_blocks)
             and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0])):
         y, cs = ops.resblock_chain(
             x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks],
@@ -368,14 +325,14 @@ def _stage_blocks(blocks: Sequence[ResBlockSpec], x: Tensor, caches: Optional[Se
             [caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(n)] if caches_out is not None else None)
         new_caches.extend(cs)
         return y
-    if (not streaming and not x3 and FUSE_RESBLOCK and opts.offline_chain_blocks and n >= 2
-            and all(rb.pw1_chain is not None and _fusable(rb, x, False, opts.offline_wide_blocks) for rb in blocks)
+    if (not streaming and FUSE_RESBLOCK and opts.stage_launches and n >= 2
+            and all(rb.pw1_chain is not None and _fusable(rb, x, False, opts.wide_blocks) for rb in blocks)
             and ops.resblock_chain_supported(x.shape[1], x.shape[2], n, x.shape[0], streaming=False)):
         return ops.resblock_chain(
             x, [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in blocks])
     for i, rb in enumerate(blocks):
         x = _resblock(rb, x, caches[ci + 2 * i: ci + 2 * i + 2] if streaming else None, new_caches,
-                      caches_out[ci + 2 * i: ci + 2 * i + 2] if caches_out is not None else None, x3=x3, opts=opts)
+                      caches_out[ci + 2 * i: ci + 2 * i + 2] if caches_out is not None else None, opts=opts)
     return x
 
 
@@ -502,14 +459,9 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
 
     wav_hist = None
     ci = 0
-    # the cache updates that are a launch of their own (waveform tail, conv_post's depthwise cache) go out as ONE launch at the end
-    tails = ops.DeferredTails() if streaming and opts.stream_batch_tails and not torch.compiler.is_compiling() else None
     if streaming:
         wav_hist = caches[0]
-        if tails is not None:
-            new_caches.append(tails.add(wav, wav_hist, es.wav_cache_len, 1.0, False, out=out(0)))
-        else:
-            new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
+        new_caches.append(ops.tail(wav, wav_hist, es.wav_cache_len, out=out(0)))
         ci = 1
     sb0 = es.stages[0].spec
     fuse_pre = (FUSE_SPECBLOCK and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
@@ -543,12 +495,11 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
             x = _spec_block(st.spec, x, wav, wav_hist)
         nxt = later[si] if defer else None
         nb = len(st.blocks)
-        if (FUSE_RESBLOCK and opts.fuse_encoder_stage and st.down_lo is not None and st.down_dw_b is not None
+        if (FUSE_RESBLOCK and opts.stage_launches and st.down_lo is not None and st.down_dw_b is not None
                 and st.down_dw_w.shape[1] == 2 * st.ratio and x.shape[2] % st.ratio == 0 and (not streaming or FUSE_STREAM)
-                and (opts.stream_chain_blocks if streaming else opts.offline_chain_blocks)
                 and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                         and rb.dw2_b is not None for rb in st.blocks)
-                and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or (opts.offline_wide_blocks and opts.fuse_encoder_stage_wide))
+                and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.wide_blocks)
                 and ops.encoder_stage_supported(x.shape[1], x.shape[2], nb, st.ratio, x.shape[0], streaming)):
             # the whole stage — its residual blocks and its down-sampling layer — is one launch; the stage's output never reaches HBM
             blocks = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks]
@@ -564,9 +515,11 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                 x = ops.encoder_stage(x, blocks, down)
             ci += 2 * nb + 1
             continue
-        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, False, opts)
+        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, opts)
         ci += 2 * len(st.blocks)
-        if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio):
+        # (a shortcut the fused layer cannot take — a long hop at a stride above 8 — falls through to pointwise GEMM + depthwise conv, which can)
+        if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio, defer, x.shape[0],
+                                                                         st.down_dw_w.shape[0]):
             x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci], res=branch_of(nxt) if defer else None,
                                        stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
@@ -584,10 +537,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         ci += 1
     if not defer:
         x = _spec_block(es.spec_post, x, wav, wav_hist)
-    if streaming and tails is not None:
-        h = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci])
-        new_caches.append(tails.add(x, caches[ci], es.post_dw_w.shape[1] - 1, 1.0, True, out=out(ci)))
-    elif streaming:
+    if streaming:
         h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)
     else:
@@ -597,8 +547,6 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         z = ops.l2norm(h, eps=1e-12, scale=float(es.dim) ** 0.5, channel_last_out=channel_last_out)
     else:
         z = h.transpose(1, 2).contiguous() if channel_last_out else h
-    if tails is not None:
-        tails.flush()
     return (z, new_caches) if streaming else z
 
 
@@ -619,12 +567,6 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
         chunks = _clip_chunks(q.shape[0], _decoder_clip_elems(ds, q.shape[2]))
         if len(chunks) > 1:
             return torch.cat([run_decoder(ds, q[lo:hi], None, None, opts) for lo, hi in chunks], dim=0)
-    if opts.decoder_gemm not in ("fp32", "bf16x3"):
-        raise RuntimeError(f"ExecOptions.decoder_gemm must be 'fp32' or 'bf16x3', got {opts.decoder_gemm!r}")
-    if opts.decoder_gemm != "fp32" and torch.compiler.is_compiling():
-        raise RuntimeError("decoder_gemm = 'bf16x3' is an eager-mode experiment: compile the default fp32 path")
-    x3 = opts.decoder_gemm == "bf16x3"
-    tails = ops.DeferredTails() if streaming and opts.stream_batch_tails and not x3 and not torch.compiler.is_compiling() else None
     ci = 0
     if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(q.shape[2], ds.pre_dw_w.shape[1], 1):
         x, c = ops.dws_conv_stream(q, ds.pre_pw_wt, ds.pre_dw_w, ds.pre_dw_b, caches[0], hist_out=out(0))
@@ -641,17 +583,12 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
     ci = 1
     for st in ds.stages:
         fused_up = FUSE_UPSAMPLE and (x.shape[2] * st.ratio) % 4 == 0
-        if (streaming and FUSE_STREAM and x3 and (x.shape[2] * st.ratio) % 4 == 0
-                and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0])):
-            x, c = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps,
-                                  hist=caches[ci], want_hist=True, hist_out=out(ci))
-            new_caches.append(c)
-        elif (streaming and not x3 and FUSE_STREAM and FUSE_RESBLOCK and opts.fuse_decoder_stage and opts.stream_chain_blocks
-              and (opts.fuse_decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.stream_wide_blocks)
-              and _stage_fusable_blocks(st, x, True, opts.fuse_decoder_stage_partial) > 0):
+        if (streaming and FUSE_STREAM and FUSE_RESBLOCK and opts.stage_launches
+                and (opts.decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.wide_blocks)
+                and _stage_fusable_blocks(st, x, True, opts.decoder_stage_narrow) > 0):
             # the whole stage — up-sampling layer and residual blocks — is one launch; the tensor between them never exists
             # (C = 384: the up-sampling layer and the FIRST block; the other two follow as launches of their own)
-            nb = _stage_fusable_blocks(st, x, True, opts.fuse_decoder_stage_partial)
+            nb = _stage_fusable_blocks(st, x, True, opts.decoder_stage_narrow)
             up_w = st.tr_w if st.taps is None else st.taps
             x, cs_, c = ops.decoder_stage(
                 x, (up_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
@@ -662,13 +599,9 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             new_caches.extend(cs_)
             ci += 1 + 2 * nb
             if nb < len(st.blocks):
-                x = _stage_blocks(st.blocks[nb:], x, caches, ci, new_caches, caches_out, x3, opts)
+                x = _stage_blocks(st.blocks[nb:], x, caches, ci, new_caches, caches_out, opts)
                 ci += 2 * (len(st.blocks) - nb)
             continue
-        elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0 and tails is not None:
-            # (the transposed conv's new cache = its last ACTIVATED input frame: with the other stages' and conv_post's in one launch)
-            new_caches.append(tails.add(x, None, 1, st.in_scale, True, out=out(ci)))
-            x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True, hist=caches[ci], taps=st.taps)
         elif streaming and FUSE_STREAM and (x.shape[2] * st.ratio) % 4 == 0:
             x, c = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True,
                                hist=caches[ci], want_hist=True, taps=st.taps, hist_out=out(ci))
@@ -678,19 +611,26 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
                                  in_scale=st.in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
-        elif (not streaming and not x3 and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.fuse_decoder_stage and opts.offline_chain_blocks
-              and (st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.offline_wide_blocks) and _stage_fusable_blocks(st, x, False, opts.fuse_decoder_stage_partial) > 0):
+        elif (not streaming and FUSE_RESBLOCK and FUSE_UPSAMPLE and opts.stage_launches
+              and (opts.decoder_stage_narrow if st.pw_wt.shape[1] <= FUSE_RESBLOCK_MAX_C else opts.wide_blocks)
+              and _stage_fusable_blocks(st, x, False, opts.decoder_stage_narrow) > 0):
             # (the widest stage, C = 768: its carry slots leave LDS room for ONE block behind the up-sampling phase; the other blocks follow)
-            nb = _stage_fusable_blocks(st, x, False, opts.fuse_decoder_stage_partial)
+            nb = _stage_fusable_blocks(st, x, False, opts.decoder_stage_narrow)
+            blocks_ = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks[:nb]]
+            if (st is ds.stages[-1] and nb == len(st.blocks) and ds.post_w.dim() == 2 and ds.post_w.shape[0] == st.pw_wt.shape[1]
+                    and ops.decoder_stage_post_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, nb, st.ratio, ds.post_w.shape[1])):
+                # the LAST stage and the closing conv (seanet.py:453-476) in one launch: the stage's [B, C, T] output — the step's largest
+                # tensor — is neither written nor read
+                return ops.decoder_stage_post(
+                    x, (st.tr_w if st.taps is None else st.taps, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio), blocks_,
+                    (ds.post_w, ds.post_b, ds.post_in_scale, ds.post_out_scale, ds.tanh))
             x = ops.decoder_stage(
                 x, (st.tr_w if st.taps is None else st.taps, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
                 [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks[:nb]])
             if nb < len(st.blocks):
-                x = _stage_blocks(st.blocks[nb:], x, None, 0, None, None, x3, opts)
+                x = _stage_blocks(st.blocks[nb:], x, None, 0, None, None, opts)
             ci += 1 + 2 * len(st.blocks)
             continue
-        elif fused_up and x3 and ops.x3_supported(x.shape[1], st.pw_wt.shape[1], x.shape[2] * st.ratio, x.shape[0]):
-            x = ops.up_conv_x3(x, st.tr_w, _x3(st.pw_wt), st.pw_b, st.ratio, in_scale=st.in_scale, taps=st.taps)
         elif fused_up:
             # the up-sampled tensor only exists inside the GEMM's loader
             x = ops.up_conv(x, st.tr_w, st.pw_wt, st.pw_b, st.ratio, in_scale=st.in_scale, in_elu=True, taps=st.taps)
@@ -698,14 +638,8 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             u = ops.dw_convtr(x, st.tr_w, st.ratio, in_scale=st.in_scale, in_elu=True)
             x = ops.pw_conv(u, st.pw_wt, st.pw_b)
         ci += 1
-        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, x3, opts)
+        x = _stage_blocks(st.blocks, x, caches, ci, new_caches, caches_out, opts)
         ci += 2 * len(st.blocks)
-    if streaming and tails is not None:
-        wav = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True, out_scale=ds.post_out_scale,
-                            do_tanh=ds.tanh, hist=caches[ci])
-        new_caches.append(tails.add(x, caches[ci], ds.post_w.shape[1] - 1, ds.post_in_scale, True, out=out(ci)))
-        tails.flush()
-        return wav, new_caches
     if streaming:
         wav, c = ops.conv_post(x, ds.post_w, ds.post_b, in_scale=ds.post_in_scale, in_elu=True,
                                out_scale=ds.post_out_scale, do_tanh=ds.tanh, hist=caches[ci], want_hist=True,

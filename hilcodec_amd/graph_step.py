@@ -187,7 +187,9 @@ class PipelinedHop:
     the benchmark): a two-stage software pipeline over hops.  One graph replay runs, side by side on two HIP streams,
     the encoder + RVQ of hop i and the dequantiser + decoder of hop i-1 — two independent chains (the only edge between
     them, the indices of hop i-1, was produced by the previous replay), so the tails of one chain's small launches are
-    filled with workgroups of the other instead of idle CUs.  The arithmetic is the GraphedHop's, launch for launch:
+    filled with workgroups of the other instead of idle CUs.  The arithmetic is the GraphedHop's — same kernels' products in the
+    same order; the decoder is captured with `ExecOptions.decoder_stage_narrow = False` (its narrow stages as up-sampling launch +
+    chain instead of one launch: another launch structure, the same bits) —
     outputs are bit-identical, the decoded audio just arrives one replay later (`step` returns the indices of the hop it
     was given and the wav of the previous one; `flush` decodes the last hop).  Cost: one hop (320 samples, 13.3 ms) of
     extra latency on the decoded output — a schedule for aggregate throughput, not for the lowest-latency single call,
@@ -262,7 +264,7 @@ class PipelinedHop:
         # one-launch form holds every CU with one long workgroup and leaves the other chain nothing to co-reside with (measured:
         # pipelined 4.72 ms without, 4.82 with; the plain graph gains 0.15 ms from it).  Context-local override, nothing is written
         # into the model's options.  The same holds for the C = 384 stage's up-sampling layer + first block (4.716 vs 4.73 - 4.76 ms).
-        with ops.sched_workspace(self.sched_dec[g]), engine.exec_overrides(fuse_decoder_stage_narrow=False, fuse_decoder_stage_partial=False):
+        with ops.sched_workspace(self.sched_dec[g]), engine.exec_overrides(decoder_stage_narrow=False):
             wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1][:, lo:hi].contiguous(), self.n), *st[p ^ 1].dec,
                                cache_out=st[p].dec)
         return wav
@@ -289,20 +291,27 @@ class PipelinedHop:
 
     @property
     def cache_enc(self) -> List[Tensor]:
-        """CURRENT encoder caches of all streams (after the hop last given to `step`), concatenated over the groups"""
+        """CURRENT encoder caches of all streams, concatenated over the groups.  Only after `flush()`: while a hop is pending the
+        decoder is one hop behind the encoder, and a (cache_enc, cache_dec) pair taken then would resume with the decoder out of
+        step — refused instead of silently wrong."""
+        self._no_pending("cache_enc")
         per_group = [blocks[self.parity].enc for blocks in self.gstate]
         return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
 
     @property
     def cache_dec(self) -> List[Tensor]:
-        """CURRENT decoder caches: the decoder is one hop behind while a hop is pending (they then describe the streams
-        after the hop BEFORE the last `step`); after `flush()` both cache lists describe the same instant"""
-        p = self.parity ^ 1 if self.pending else self.parity
-        per_group = [blocks[p].dec for blocks in self.gstate]
+        """CURRENT decoder caches (only after `flush()`, see `cache_enc`: then both cache lists describe the same instant)"""
+        self._no_pending("cache_dec")
+        per_group = [blocks[self.parity].dec for blocks in self.gstate]
         return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
 
+    def _no_pending(self, what: str) -> None:
+        if self.pending:
+            raise RuntimeError(f"PipelinedHop.{what}: a hop is encoded but not decoded yet — call flush() first (the decoder's caches "
+                               "are one hop behind the encoder's until then)")
+
     def reset(self, cache_enc: Optional[Sequence[Tensor]] = None, cache_dec: Optional[Sequence[Tensor]] = None) -> None:
-        """zero history, or resume from caches exported earlier (`cache_enc` / `cache_dec` after a `flush()`)"""
+        """zero history, or resume from caches exported earlier (`cache_enc` / `cache_dec`, which can only be read after a `flush()`)"""
         with torch.no_grad():
             self.parity, self.pending = 0, False
             for (lo, hi), (a, _b) in zip(self.bounds, self.gstate):

@@ -531,6 +531,15 @@ class HILCodec(nn.Module):
         ws = norm == "weight_standardization"
         if ws:
             kw = dict(norm_kwargs or {})
+            # the reference passes **norm_kwargs to `weight_standardization` (`modules/weight_standardization.py:44-53`: name, dim, eps, scale,
+            # learnable_gain, zero_init).  The fold standardises over every axis but 0, which is `dim = 0`; `learnable_gain` / `zero_init` only
+            # decide how weight_g was created (it is in the checkpoint or it is not).  Anything else would be folded over the wrong axes:
+            unknown = set(kw) - {"eps", "scale", "dim", "learnable_gain", "zero_init", "name"}
+            if unknown:
+                raise ValueError(f"load_offline_state_dict: unsupported weight-standardisation arguments {sorted(unknown)}")
+            if kw.get("dim", 0) not in (0, (0,), [0]) or kw.get("name", "weight") != "weight":
+                raise ValueError("load_offline_state_dict: only weight standardisation of `weight` over dim = 0 (the reference's default and "
+                                 f"its configs') can be folded, got dim = {kw.get('dim')!r}, name = {kw.get('name')!r}")
             ws_eps = float(kw.get("eps", 1e-7))
             ws_scale = None if kw.get("scale") is None else torch.ones(1) * float(kw["scale"])
             for module in self.modules():

@@ -201,172 +201,6 @@ _register("up_conv", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor tr_w
           x.new_empty(x.shape[0], wt.shape[1], x.shape[2] * stride))
 
 
-# ---- EXPERIMENTAL bf16x3 numerics mode (csrc/gemm_x3.h): opt-in, decoder side only -------------------------------------
-def _x3_split(wt):
-    K, M = wt.shape
-    out = torch.empty(2, K, M, device=wt.device, dtype=torch.int16)
-    check(lib.hilc_x3_split_weights(_ptr(wt), _ptr(out, torch.int16), K, M, _stream()), "hilc_x3_split_weights")
-    return out
-
-
-_register("x3_split", "(Tensor wt) -> Tensor", _x3_split,
-          lambda wt: torch.empty(2, wt.shape[0], wt.shape[1], device=wt.device, dtype=torch.int16))
-
-
-def _dws_conv_x3(x, wsplit, dw_w, dw_b, res, in_scale, in_elu, out_scale, out_elu):
-    B, K, T = x.shape
-    M = wsplit.shape[2]
-    y = _new(x, B, M, T)
-    with _timed("dws_conv_x3", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k5 s1 bf16x3"):
-        check(lib.hilc_dws_conv_x3(_ptr(x), _ptr(wsplit, torch.int16), _ptr(dw_w), _ptr(dw_b), _ptr(res), _ptr(y), B, K, M,
-                                   T, in_scale, int(in_elu), out_scale, int(out_elu), _stream()), "hilc_dws_conv_x3")
-    return y
-
-
-_register("dws_conv_x3", "(Tensor x, Tensor wsplit, Tensor dw_w, Tensor? dw_b, Tensor? res, float in_scale, bool in_elu, "
-          "float out_scale, bool out_elu) -> Tensor", _dws_conv_x3,
-          lambda x, wsplit, dw_w, dw_b, res, in_scale, in_elu, out_scale, out_elu:
-          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2]))
-
-
-def _up_conv_x3(x, hist, hist_out, tr_w, taps, wsplit, bias, stride, in_scale):
-    B, K, Tin = x.shape
-    M = wsplit.shape[2]
-    for h in (hist, hist_out):
-        if h is not None and h.numel() != B * K:
-            raise RuntimeError(f"cache must be [{B},{K},1], got {tuple(h.shape)}")
-    y = _new(x, B, M, Tin * stride)
-    with _timed("up_conv_x3", 2.0 * B * Tin * stride * K * M,
-                f"K{K} M{M} Tin{Tin} r{stride} bf16x3" + (" stream" if hist is not None or hist_out is not None else "")):
-        check(lib.hilc_up_conv_x3(_ptr(x), _ptr(hist), _ptr(hist_out), _ptr(tr_w), _ptr(taps), _ptr(wsplit, torch.int16),
-                                  _ptr(bias), _ptr(y), B, K, M, Tin, stride, in_scale, _stream()), "hilc_up_conv_x3")
-    return y
-
-
-_register("up_conv_x3", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor tr_w, Tensor? taps, Tensor wsplit, Tensor? bias, "
-          "int stride, float in_scale) -> Tensor", _up_conv_x3,
-          lambda x, hist, hist_out, tr_w, taps, wsplit, bias, stride, in_scale:
-          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2] * stride))
-
-
-def _dws_conv_stream_x3(x, wsplit, dw_w, dw_b, hist, hist_out, res, in_scale, in_elu, out_scale, out_elu):
-    B, K, T = x.shape
-    M = wsplit.shape[2]
-    for h in (hist, hist_out):
-        if h is not None and tuple(h.shape) != (B, M, 4):
-            raise RuntimeError(f"cache must be [{B},{M},4], got {tuple(h.shape)}")
-    y = _new(x, B, M, T)
-    with _timed("dws_conv_x3", 2.0 * B * T * K * M, f"K{K} M{M} T{T} k5 s1 bf16x3 stream"):
-        check(lib.hilc_dws_conv_stream_x3(_ptr(x), _ptr(wsplit, torch.int16), _ptr(dw_w), _ptr(dw_b), _ptr(hist),
-                                          _ptr(hist_out), _ptr(res), _ptr(y), B, K, M, T, in_scale, int(in_elu), out_scale,
-                                          int(out_elu), _stream()), "hilc_dws_conv_stream_x3")
-    return y
-
-
-_register("dws_conv_stream_x3", "(Tensor x, Tensor wsplit, Tensor dw_w, Tensor? dw_b, Tensor? hist, Tensor(a!) hist_out, "
-          "Tensor? res, float in_scale, bool in_elu, float out_scale, bool out_elu) -> Tensor", _dws_conv_stream_x3,
-          lambda x, wsplit, dw_w, dw_b, hist, hist_out, res, in_scale, in_elu, out_scale, out_elu:
-          x.new_empty(x.shape[0], wsplit.shape[2], x.shape[2]))
-
-
-def _resblock_x3_pack(wt):
-    Cc = wt.shape[0]
-    out = _new(wt, Cc * Cc)                       # C*C*4 bytes: bf16 heads and remainders in MFMA lane order
-    check(lib.hilc_resblock_pack_weights_x3(_ptr(wt), _ptr(out), Cc, _stream()), "hilc_resblock_pack_weights_x3")
-    return out
-
-
-_register("resblock_x3_pack", "(Tensor wt) -> Tensor", _resblock_x3_pack, lambda wt: wt.new_empty(wt.shape[0] * wt.shape[0]))
-
-
-def _resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale):
-    B, Cc, T = x.shape
-    streaming = hist1_out is not None or hist1 is not None
-    for h in (hist1, hist2, hist1_out, hist2_out):
-        if h is not None and tuple(h.shape) != (B, Cc, 4):
-            raise RuntimeError(f"resblock caches must be [{B},{Cc},4], got {tuple(h.shape)}")
-    y = torch.empty_like(x)
-    with _timed("resblock_x3", 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} bf16x3" + (" stream" if streaming else "")):
-        check(lib.hilc_resblock_x3(_ptr(x), _ptr(w1s), _ptr(dw1_w), _ptr(dw1_b), _ptr(w2s), _ptr(dw2_w), _ptr(dw2_b),
-                                   _ptr(hist1), _ptr(hist2), _ptr(hist1_out), _ptr(hist2_out), _ptr(y),
-                                   _ptr(_sched_buffer(x.device), torch.int32), int(streaming), B, Cc, T, pre_scale, out_scale,
-                                   _stream()), "hilc_resblock_x3")
-    return y
-
-
-_register("resblock_x3", "(Tensor x, Tensor w1s, Tensor dw1_w, Tensor dw1_b, Tensor w2s, Tensor dw2_w, Tensor dw2_b, "
-          "Tensor? hist1, Tensor? hist2, Tensor(a!)? hist1_out, Tensor(b!)? hist2_out, float pre_scale, float out_scale) -> Tensor",
-          _resblock_x3,
-          lambda x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist1, hist2, hist1_out, hist2_out, pre_scale, out_scale:
-          torch.empty_like(x))
-
-
-def resblock_x3_supported(C: int, T: int, B: int = 1) -> bool:
-    """mirror of hilc_resblock_x3's limits (32-bit byte offsets: the tensor must stay below 4 GiB)"""
-    return C in (96, 192) and T % 4 == 0 and B * C * T * 4 < (1 << 32)
-
-
-def resblock_x3_pack(wt: Tensor) -> Tensor:
-    """k-major `[C,C]` pointwise weights -> the split, lane-ordered form of hilc_resblock_x3"""
-    return _OPS.resblock_x3_pack(wt)
-
-
-def resblock_x3(x: Tensor, w1s: Tensor, dw1_w: Tensor, dw1_b: Tensor, w2s: Tensor, dw2_w: Tensor, dw2_b: Tensor,
-                pre_scale: float, out_scale: float, hist: Optional[Sequence[Tensor]] = None,
-                hist_out: Optional[Sequence[Tensor]] = None):
-    """`resblock` (offline, or a streaming hop with its two caches) with its two GEMM phases in the EXPERIMENTAL bf16x3 mode"""
-    if hist is None:
-        return _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, None, None, None, None, float(pre_scale),
-                                float(out_scale))
-    B, Cc, _ = x.shape
-    o1 = _state_out(hist_out[0] if hist_out is not None else None, x, B, Cc, 4)
-    o2 = _state_out(hist_out[1] if hist_out is not None else None, x, B, Cc, 4)
-    y = _OPS.resblock_x3(x, w1s, dw1_w, dw1_b, w2s, dw2_w, dw2_b, hist[0], hist[1], o1, o2, float(pre_scale), float(out_scale))
-    return y, [o1, o2]
-
-
-def x3_supported(K: int, M: int, T: int, B: int = 1) -> bool:
-    """mirror of hilc_x3_supported, plus the entry points' 4 GiB limit on the input tensor (32-bit byte offsets)"""
-    return K % 32 == 0 and M % 8 == 0 and T % 4 == 0 and B * K * T * 4 < (1 << 32)
-
-
-def x3_split(wt: Tensor) -> Tensor:
-    """k-major fp32 `[K,M]` -> `[2,K,M]` bf16 bit patterns (int16): head and head of the remainder (hilc_x3_split_weights)"""
-    return _OPS.x3_split(wt)
-
-
-def dws_conv_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], res: Optional[Tensor] = None,
-                in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0, out_elu: bool = False) -> Tensor:
-    """`dws_conv` (k5, stride 1) with the pointwise GEMM in the EXPERIMENTAL bf16x3 mode (hilc_dws_conv_x3)"""
-    return _OPS.dws_conv_x3(x, wsplit, dw_w, dw_b, res, float(in_scale), bool(in_elu), float(out_scale), bool(out_elu))
-
-
-def up_conv_x3(x: Tensor, tr_w: Tensor, wsplit: Tensor, bias: Optional[Tensor], stride: int, in_scale: float = 1.0,
-               taps: Optional[Tensor] = None, hist: Optional[Tensor] = None, want_hist: bool = False,
-               hist_out: Optional[Tensor] = None):
-    """`up_conv` (ELU prologue; streaming: the transposed conv's one-frame cache -> (y, new cache)) with the pointwise GEMM
-    in the EXPERIMENTAL bf16x3 mode (hilc_up_conv_x3)"""
-    if taps is None and stride not in (2, 4, 8):
-        taps = up_conv_taps(tr_w, stride)
-    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], 1) if want_hist else None
-    y = _OPS.up_conv_x3(x, hist, hout, tr_w, taps, wsplit, bias, int(stride), float(in_scale))
-    return (y, hout) if want_hist else y
-
-
-def dws_conv_stream_x3_supported(K: int, M: int, T: int, k: int, stride: int, B: int = 1) -> bool:
-    return k == 5 and stride == 1 and T <= 128 and T % 4 == 0 and x3_supported(K, M, T, B)
-
-
-def dws_conv_stream_x3(x: Tensor, wsplit: Tensor, dw_w: Tensor, dw_b: Optional[Tensor], hist: Optional[Tensor],
-                       res: Optional[Tensor] = None, in_scale: float = 1.0, in_elu: bool = False, out_scale: float = 1.0,
-                       out_elu: bool = False, hist_out: Optional[Tensor] = None):
-    """streaming hop of a wide k5 / stride-1 depthwise-separable layer in the EXPERIMENTAL bf16x3 mode -> (y, new cache)"""
-    hout = _state_out(hist_out, x, x.shape[0], wsplit.shape[2], 4)
-    y = _OPS.dws_conv_stream_x3(x, wsplit, dw_w, dw_b, hist, hout, res, float(in_scale), bool(in_elu), float(out_scale),
-                                bool(out_elu))
-    return y, hout
-
-
 def _resblock_pack(wt):
     Cc = wt.shape[0]
     out = _new(wt, Cc * Cc)
@@ -555,6 +389,38 @@ _register("decoder_stage", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, 
           xin.new_empty(xin.shape[0], xin.shape[1] // 2, xin.shape[2] * stride))
 
 
+def _decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, in_scale, stride, params, pre_scales, out_scales, post_w, post_b, post_in_scale,
+                        post_out_scale, do_tanh):
+    import ctypes
+    from ._lib import PostParams, ResblockParams, UpParams
+    B, K2, Tin = xin.shape
+    Cc, T = K2 // 2, Tin * stride
+    n = len(pre_scales)
+    if len(params) != 6 * n or len(out_scales) != n:
+        raise RuntimeError("decoder_stage_post: 6 parameter tensors per block")
+    if post_w.dim() != 2 or post_w.shape[0] != Cc:
+        raise RuntimeError(f"decoder_stage_post: the closing conv's taps must be [{Cc}, k], got {tuple(post_w.shape)}")
+    blocks = (ResblockParams * n)()
+    for i in range(n):
+        w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), None, None, None, None,
+                                   float(pre_scales[i]), float(out_scales[i]))
+    up = UpParams(_ptr(xin), _ptr(tr_w), _ptr(w_lo), _ptr(w_hi), _ptr(bias), None, None, float(in_scale), int(stride))
+    wav = torch.empty(B, 1, T, device=xin.device, dtype=torch.float32)
+    post = PostParams(_ptr(post_w), _ptr(post_b), _ptr(wav), float(post_in_scale), float(post_out_scale), int(do_tanh), int(post_w.shape[1]))
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} up r{stride} + stage x{n} + conv_post"):
+        check(lib.hilc_decoder_stage_post(ctypes.cast(ctypes.pointer(up), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n,
+                                          ctypes.cast(ctypes.pointer(post), ctypes.c_void_p), B, Cc, T, _stream()), "hilc_decoder_stage_post")
+    return wav
+
+
+_register("decoder_stage_post", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, Tensor? bias, float in_scale, int stride, Tensor[] params, "
+          "float[] pre_scales, float[] out_scales, Tensor post_w, Tensor? post_b, float post_in_scale, float post_out_scale, bool do_tanh) -> Tensor",
+          _decoder_stage_post,
+          lambda xin, tr_w, w_lo, w_hi, bias, in_scale, stride, params, pre_scales, out_scales, post_w, post_b, post_in_scale, post_out_scale, do_tanh:
+          xin.new_empty(xin.shape[0], 1, xin.shape[2] * stride))
+
+
 def _resblock_pack_rc(wt, row_classes):
     Cc = wt.shape[0]
     out = torch.empty(Cc * Cc, device=wt.device, dtype=torch.float32)
@@ -712,28 +578,6 @@ def _tail(x, hist, out):
 _register("tail", "(Tensor x, Tensor? hist, Tensor(a!) out) -> ()", _tail, lambda x, hist, out: None)
 
 
-def _tail_multi(xs, hists, outs, in_scales, in_elus):
-    import ctypes
-    from ._lib import TailDesc
-    n = len(xs)
-    if not (len(hists) == len(outs) == len(in_scales) == len(in_elus) == n) or n < 1:
-        raise RuntimeError("tail_multi: one (x, hist, out, in_scale, in_elu) per cache")
-    descs = (TailDesc * n)()
-    for i in range(n):
-        x, out = xs[i], outs[i]
-        hist = hists[i] if hists[i].numel() > 0 else None           # (an empty tensor stands for "no history": Tensor?[] is not a schema type)
-        B, Cc, T = x.shape
-        if tuple(out.shape[:2]) != (B, Cc) or (hist is not None and tuple(hist.shape[:2]) != (B, Cc)):
-            raise RuntimeError("tail_multi: x, hist and out must agree in [B, C]")
-        descs[i] = TailDesc(_ptr(x), _ptr(hist), _ptr(out), B * Cc, T, out.shape[-1], hist.shape[-1] if hist is not None else 0,
-                            float(in_scales[i]), int(in_elus[i]))
-    check(lib.hilc_tail_multi(ctypes.cast(descs, ctypes.c_void_p), n, _stream()), "hilc_tail_multi")
-
-
-_register("tail_multi", "(Tensor[] xs, Tensor[] hists, Tensor(a!)[] outs, float[] in_scales, bool[] in_elus) -> ()", _tail_multi,
-          lambda xs, hists, outs, in_scales, in_elus: None)
-
-
 def _l2norm(x, eps, scale, channel_last_out):
     B, Cc, T = x.shape
     y = _new(x, *((B, T, Cc) if channel_last_out else (B, Cc, T)))
@@ -861,20 +705,30 @@ def dws_conv(x: Tensor, wt: Tensor, dw_w: Tensor, dw_b: Optional[Tensor] = None,
                          bool(out_elu))
 
 
-def dws_conv_stream_supported(T: int, k: int, stride: int) -> bool:
+def dws_conv_stream_supported(T: int, k: int, stride: int, has_res: bool = False, B: int = 1, M: int = 1) -> bool:
     """whole-clip tiles: a hop of at most 128 samples per stream, a multiple of the stride; longer hops for the
-    down-sampling form (k = 2 * stride): per-clip tiles with a recomputed halo"""
+    down-sampling form (k = 2 * stride): per-clip tiles with a recomputed halo — which take a shortcut `res` only in their
+    flat-tile form (csrc/gemm.hip: stride <= 8, fewer than 2^31 outputs, a tile holds at most two stream starts)"""
     if T > 128:
-        return k == 2 * stride and stride <= 16 and T % 4 == 0 and T % stride == 0
+        if not (k == 2 * stride and stride <= 16 and T % 4 == 0 and T % stride == 0):
+            return False
+        if not has_res:
+            return True
+        h = (stride + 3) // 4 * 4
+        n_out = (128 - h - stride) // stride + 1
+        while (n_out * stride) % 4 != 0:
+            n_out -= 1
+        to = T // stride
+        return stride <= 8 and B * to + T < (1 << 31) and B * M * to < (1 << 31) and to * 2 >= n_out + 1
     return T % stride == 0 and stride <= k <= 32
 
 
-def dws_conv_stream_profitable(T: int, k: int, stride: int) -> bool:
+def dws_conv_stream_profitable(T: int, k: int, stride: int, has_res: bool = False, B: int = 1, M: int = 1) -> bool:
     """where the fused hop beats pointwise GEMM + cached depthwise conv (measured, tools/layer_profile.py
     --mode streaming): not for 2- or 3-sample hops of the tiled core, whose depthwise taps are nearly all cache reads."""
     if T == 1 and stride == 1:
         return k <= 32  # single-frame layers: the latency-bound 32 x 32-tile kernel (csrc/frame1.hip), taps in its epilogue
-    return dws_conv_stream_supported(T, k, stride) and T // stride >= 1 and T >= 4
+    return dws_conv_stream_supported(T, k, stride, has_res, B, M) and T // stride >= 1 and T >= 4
 
 
 def _state_out(given: Optional[Tensor], like: Tensor, *shape) -> Tensor:
@@ -935,7 +789,7 @@ def resblock_chain_supported(C: int, T: int, nblk: int, B: int = 1, streaming: b
         return C in (64, 96, 128, 192, 256, 384, 512)
     if B * C * T * 4 >= (1 << 32):
         return False
-    return C in (64, 96, 128, 192, 256) or (C in (512, 768) and 32 % T == 0)
+    return C in (64, 96, 128, 192) or (C in (512, 768) and 32 % T == 0)
 
 
 def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
@@ -1014,6 +868,26 @@ def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: O
     uout = _state_out(up_hist_out, xin, B, K2, 1)
     y = _OPS.decoder_stage(xin, tr_w, w_lo, w_hi, bias, up_hist, uout, float(in_scale), int(stride), params, hin, hout, pre, post)
     return y, hout, uout
+
+
+def decoder_stage_post_supported(C: int, T: int, nblk: int, stride: int, ksize: int) -> bool:
+    """mirror of hilc_decoder_stage_post_supported: the offline decoder's LAST stage with the closing conv in the same launch"""
+    return C == 96 and stride == 2 and nblk == 3 and ksize == 5 and T > 0 and T % 4 == 0
+
+
+def decoder_stage_post(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], post: Sequence) -> Tensor:
+    """The offline decoder's last stage AND its closing layer in ONE launch (hilc_decoder_stage_post): `up`, `blocks` as in
+    `decoder_stage` (offline), `post` = (w `[C,5]`, bias `[1]` or None, in_scale, out_scale, do_tanh) as given to `conv_post`.
+    xin `[B,2C,T/r]` -> wav `[B,1,T]`, equal bit for bit to `conv_post(decoder_stage(...))`."""
+    tr_w, w_lo, w_hi, bias, in_scale, stride = up
+    params, pre, post_s = [], [], []
+    for blk in blocks:
+        params.extend(blk[:6])
+        pre.append(float(blk[6]))
+        post_s.append(float(blk[7]))
+    pw, pb, p_in, p_out, p_tanh = post
+    return _OPS.decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, float(in_scale), int(stride), params, pre, post_s, pw, pb, float(p_in),
+                                   float(p_out), bool(p_tanh))
 
 
 def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:
@@ -1165,25 +1039,6 @@ def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = No
     out = _state_out(out, x, x.shape[0], x.shape[1], pad)
     _OPS.tail(x, hist, out)
     return out
-
-
-class DeferredTails:
-    """Cache updates of a streaming hop collected and issued as ONE launch (hilc_tail_multi): `add` = what the op's own
-    `hist_out` would have written — the last `pad` samples of [hist | pro(x)] — `flush` launches them (at most 8 per launch)."""
-
-    def __init__(self):
-        self.items = []
-
-    def add(self, x: Tensor, hist: Optional[Tensor], pad: int, in_scale: float, in_elu: bool, out: Optional[Tensor] = None) -> Tensor:
-        out = _state_out(out, x, x.shape[0], x.shape[1], pad)
-        self.items.append((x, hist if hist is not None else x.new_empty(0), out, float(in_scale), bool(in_elu)))
-        return out
-
-    def flush(self) -> None:
-        for i in range(0, len(self.items), 8):
-            part = self.items[i:i + 8]
-            _OPS.tail_multi([p[0] for p in part], [p[1] for p in part], [p[2] for p in part], [p[3] for p in part], [p[4] for p in part])
-        self.items = []
 
 
 def l2norm(x: Tensor, eps: float = 1e-12, scale: float = 1.0, channel_last_out: bool = False) -> Tensor:

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 13   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6: *_x3 (experimental); 7: their streaming forms; 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: hilc_tail_multi; 13: hilc_decoder_stage */
+#define HILC_ABI_VERSION 14   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -114,36 +114,6 @@ int hilc_resblock(const float* x, const float* w1t, const float* dw1_w, const fl
                   const float* dw2_w, const float* dw2_b, float* y, int B, int C, int T, float pre_scale,
                   float out_scale, void* stream);
 int hilc_resblock_supported(int C, int T);
-
-/* ---- EXPERIMENTAL numerics mode "bf16x3" (csrc/gemm_x3.h) — opt-in, decoder side only, never the default --------
- * The layer's GEMM runs on the bf16 matrix pipe with both operands split into two bf16 parts (three products, fp32
- * accumulation): operands carry 16 significant bits instead of 24.  Nothing in the reference corresponds to it; the
- * product calls these entry points only when the caller asks for it (the decoder module's `exec_options.decoder_gemm = "bf16x3"`),
- * and only for decoder layers, so the encoder, the RVQ and therefore every index stay exact fp32.
- * hilc_x3_split_weights: k-major fp32 `[K][M]` -> `wsplit` = `[2][K][M]` bf16 (head, head of the remainder).
- * hilc_dws_conv_x3 / hilc_up_conv_x3: as hilc_dws_conv (ksize 5, stride 1) / hilc_up_conv_expanded (in_elu = 1)
- * with `wsplit` in place of `wt`; K % 32 == 0, M % 8 == 0, T % 4 == 0 (hilc_x3_supported), else HILC_ERR_UNSUPPORTED. */
-int hilc_x3_supported(int K, int M, int T);
-int hilc_x3_split_weights(const float* wt, void* wsplit, int K, int M, void* stream);
-int hilc_dws_conv_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* res, float* y,
-                     int B, int K, int M, int T, float in_scale, int in_elu, float out_scale, int out_elu, void* stream);
-int hilc_up_conv_x3(const float* x, const float* hist, float* hist_out, const float* tr_w, const float* tr_w_expanded,
-                    const void* wsplit, const float* bias, float* y, int B, int K, int M, int Tin, int stride, float in_scale,
-                    void* stream);
-/* streaming hop (hist / hist_out as in hilc_dws_conv_stream, T <= 128, ksize 5, stride 1; hilc_up_conv_x3 takes the
- * transposed conv's one-frame cache like hilc_up_conv_stream) */
-int hilc_dws_conv_stream_x3(const float* x, const void* wsplit, const float* dw_w, const float* dw_b, const float* hist,
-                            float* hist_out, const float* res, float* y, int B, int K, int M, int T, float in_scale,
-                            int in_elu, float out_scale, int out_elu, void* stream);
-/* hilc_resblock_x3: hilc_resblock_balanced (offline or streaming, same argument meaning) with the two GEMM phases in the same split-operand arithmetic; the
- * tile in LDS and the depthwise / ELU phases stay fp32.  C = 96 or 192 (the decoder's narrow widths).  w1s / w2s = the
- * k-major `[C][C]` matrices packed by hilc_resblock_pack_weights_x3 (C*C*4 bytes: bf16 head and remainder in MFMA lane
- * order). */
-int hilc_resblock_pack_weights_x3(const float* wt, void* packed, int C, void* stream);
-int hilc_resblock_x3(const float* x, const void* w1s, const float* dw1_w, const float* dw1_b, const void* w2s,
-                     const float* dw2_w, const float* dw2_b, const float* hist1, const float* hist2, float* hist1_out,
-                     float* hist2_out, float* y, int* sched, int streaming, int B, int C, int T, float pre_scale,
-                     float out_scale, void* stream);
 
 /* One-off (per checkpoint) re-layout of a k-major `[C][C]` pointwise matrix (wt[k][m], the layout hilc_pw_conv
  * takes) into "MFMA lane order": the operands one lane feeds to the matrix pipe for a 16-deep K slice become
@@ -224,21 +194,22 @@ int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streami
 int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, float* y, int streaming,
                        int B, int C, int T, void* stream);
 
-/* ---- several cache updates in one launch (ABI 12) ----------------------------------------------------------------------
- * out[row][i] = last `pad` samples of [hist | pro(x)] per row (pro = in_scale, then ELU if in_elu) — what hilc_tail,
- * hilc_up_conv_stream (its `hist_out`: the transposed conv's cache = the last ACTIVATED input frame, `causal_layers.py:168-188`)
- * and hilc_conv_post (`hist_out`) each do in a launch of their own; a streaming decoder hop has five of them.  Same values. */
-#define HILC_TAIL_MAX 8
-typedef struct hilc_tail_desc {
-  const float* x;      /* [rows][T] */
-  const float* hist;   /* [rows][hist_len] or NULL (zeros) */
-  float* out;          /* [rows][pad] */
-  long rows;
-  int T, pad, hist_len;
-  float in_scale;
-  int in_elu;
-} hilc_tail_desc;
-int hilc_tail_multi(const hilc_tail_desc* descs, int n, void* stream);
+/* ---- the decoder's LAST stage AND its closing layer in one launch (ABI 14) --------------------------------------------------
+ * `seanet.py:453-476`: `[Scale, ELU, SConv1d(C, 1, k = 5, bias)]`, then the model's final scale / tanh — hilc_conv_post — as the closing
+ * phase of the hilc_decoder_stage launch of the offline model's last stage (C = 96, r = 2, three blocks): the last block leaves
+ * ELU(in_scale * y) in the LDS tile, the launch stores `wav` `[B][1][T]`; the stage's `[B][C][T]` output never reaches HBM.  Equals
+ * hilc_decoder_stage followed by hilc_conv_post bit for bit (same row classes c mod 8, same order of the partial sums).  `up->hist`
+ * is ignored (offline).  hilc_decoder_stage_post_supported names the shapes; everything else: HILC_ERR_UNSUPPORTED. */
+typedef struct hilc_post_params {
+  const float* w;      /* [C][ksize] */
+  const float* bias;   /* [1] or NULL */
+  float* wav;          /* [B][1][T] */
+  float in_scale, out_scale;
+  int do_tanh, ksize;
+} hilc_post_params;
+int hilc_decoder_stage_post_supported(int C, int T, int nblk, int stride, int ksize);
+int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, const hilc_post_params* post,
+                            int B, int C, int T, void* stream);
 
 /* ---- an ENCODER STAGE in one launch (ABI 11): its residual blocks and its down-sampling layer ------------------------------
  * `seanet.py:316-339` (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C without bias, depthwise conv
@@ -285,7 +256,9 @@ int hilc_conv_pre(const float* wav, const float* hist, int hist_len, const float
 
 /* ---- last decoder conv: [Scale, ELU,] Conv1d(C -> 1, ksize, causal, bias), * out_scale, tanh -----
  * y[b,0,t] = act((sum_c sum_j w[c][j] * xe[b,c,t-(ksize-1)+j] + bias[0]) * out_scale), act = tanh if do_tanh.
- * Replaces: `seanet.py:457-473` / `streaming.py:643-647`. hist/hist_out as in hilc_dw_conv. */
+ * Replaces: `seanet.py:457-473` / `streaming.py:643-647`. hist/hist_out as in hilc_dw_conv.
+ * Order of the channel sum (ksize 5, T % 4 == 0, 16-B aligned x): eight classes c mod 8, each an fmaf chain over (c, tap) ascending, the
+ * classes added in ascending order — the order of hilc_decoder_stage_post's closing phase. */
 int hilc_conv_post(const float* x, const float* hist, const float* w, const float* bias, float* y,
                    float* hist_out, int B, int C, int T, int ksize, float in_scale, int in_elu,
                    float out_scale, int do_tanh, void* stream);

@@ -356,7 +356,7 @@ def shard_golden(ref):
     print("shard rank 7: idx", idx.shape, "checksum of the 8 clips", int(idx.sum()))
 
 
-WS_KWARGS = {"eps": 1e-7, "scale": 1.25}
+WS_KWARGS = {"eps": 1e-7, "scale": 0.8}      # (1.25 until round 4: the decoder caches reached |x| = 30 and the cache test needed a relative bar; at 0.8 they are O(1) and every bar is absolute)
 
 
 def ws_golden(ref):

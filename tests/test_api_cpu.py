@@ -220,35 +220,32 @@ def test_scalar_n_accepts_any_integer_like():
         ops.per_clip_n([1, 2], 3, 8, torch.device("cpu"))
 
 
-def test_x3_weight_cache_follows_the_weight(monkeypatch):
-    """engine._x3 (EXPERIMENTAL bf16x3 mode): the split form of a weight matrix is built once per tensor and version, is
-    rebuilt after an in-place update, is keyed by the layout that was asked for, and dies with the weight (no leak when
-    models are re-created)."""
-    import gc
+def test_dws_conv_stream_mirror_knows_which_long_hops_take_a_shortcut():
+    """ops.dws_conv_stream_supported(..., has_res): hilc_dws_conv_stream adds `res` on long hops (T > 128) only in its flat-tile form —
+    stride <= 8, fewer than 2^31 outputs; the engine asks the mirror before it hands the SpecBlock branch to the layer."""
+    from hilcodec_amd import ops
+    assert ops.dws_conv_stream_supported(320, 4, 2, True, 1024, 128) and ops.dws_conv_stream_supported(160, 8, 4, True, 1024, 256)
+    assert ops.dws_conv_stream_supported(320, 32, 16) and not ops.dws_conv_stream_supported(320, 32, 16, True)       # stride 16: no shortcut
+    assert ops.dws_conv_stream_supported(360, 18, 9) and not ops.dws_conv_stream_profitable(360, 18, 9, True, 4, 64)
+    assert not ops.dws_conv_stream_supported(320, 4, 2, True, 1 << 24, 128)                                           # 2^31 outputs
+    assert ops.dws_conv_stream_supported(40, 10, 5, True) and ops.dws_conv_stream_supported(8, 16, 8, True)         # short hops: whole-clip tiles
+
+
+def test_exec_options_are_launch_structure_only():
+    """engine.ExecOptions: four booleans that select launches, never arithmetic (the split-bf16 decoder mode and the rejected launch
+    variants left the library in round 5); nothing process-global."""
+    import dataclasses
     from hilcodec_amd import engine
-    calls = []
-
-    def split(w):
-        calls.append(("split", w._version))
-        return w.clone()
-
-    def pack(w):
-        calls.append(("pack", w._version))
-        return w.clone()
-
-    engine._X3_SPLIT.clear()
-    w = torch.zeros(4, 4)
-    a = engine._x3(w, split)
-    assert engine._x3(w, split) is a and len(calls) == 1
-    b = engine._x3(w, pack)
-    assert b is not a and len(calls) == 2 and len(engine._X3_SPLIT) == 2
-    w.add_(1.0)
-    assert engine._x3(w, split) is not a and len(calls) == 3
-    del w
-    gc.collect()
-    assert len(engine._X3_SPLIT) == 0
-    assert engine.ExecOptions().decoder_gemm == "fp32"            # the default arithmetic is the reference's
+    fields = dataclasses.fields(engine.ExecOptions)
+    assert [f.name for f in fields] == ["stage_launches", "wide_blocks", "decoder_stage_narrow", "stream_defer_spec"]
+    assert all(f.type in (bool, "bool") and f.default is True for f in fields)
     assert not hasattr(engine, "DECODER_GEMM") and not hasattr(engine, "SIDE_STREAM")     # no process-global switches
+    with engine.exec_overrides(decoder_stage_narrow=False):
+        assert engine._effective(engine.ExecOptions()).decoder_stage_narrow is False
+    assert engine._effective(engine.ExecOptions()).decoder_stage_narrow is True
+    with pytest.raises(TypeError):
+        with engine.exec_overrides(decoder_gemm="bf16x3"):
+            engine._effective(engine.ExecOptions())
 
 
 def test_clip_chunks_keep_activations_below_32bit_offsets():

@@ -70,13 +70,13 @@ def test_streaming_lines_small(extra):
         assert "pipelined" in d["config"]["workload"]
 
 
-def test_experimental_line_is_labelled():
+def test_exec_opt_switch_changes_no_index():
+    """`--exec-opt` (A/B of a launch-structure flag) prints the same index checksum as the default structure"""
+    base = run_bench("--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-clock-probe")
     d = run_bench("--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-clock-probe",
-                  "--decoder-gemm", "bf16x3")
+                  "--exec-opt", "stage_launches=0", "--exec-opt", "wide_blocks=0")
     check_common(d, 2, 1)
-    assert "EXPERIMENTAL" in d["metric"] and "bf16x3" in d["dtype"] and "note" in d["roofline"]
-    n = d["numerics"]
-    assert n["indices_equal_to_fp32_path"] is True and 0 < n["dwav_max_vs_fp32_path"] < 5e-5
+    assert d["index_checksum"] == base["index_checksum"] and d["dtype"] == "f32"
 
 
 def test_rccl_path_executes_at_world_size_one():

@@ -144,19 +144,22 @@ def test_whole_model_weight_standardization(golden):
 
 
 def test_offline_launch_structure_options_change_no_bit():
-    """`exec_options.offline_chain_blocks` / `fuse_encoder_stage` / `fuse_decoder_stage` (whole stages per launch, round 4) against one
-    launch per residual block and per down- / up-sampling layer (round 3): z, indices and wav bit for bit, on clips long enough for
-    several tiles per run and ragged against the tile width."""
-    from hilcodec_amd import ops
+    """`exec_options.stage_launches` (whole stages per launch, round 4) against one launch per residual block and per down- /
+    up-sampling layer (round 3), `wide_blocks` (the C >= 256 blocks in the fused kernel) against two depthwise-separable launches per
+    block, and `decoder_stage_narrow`: z, indices and wav bit for bit, on clips long enough for several tiles per run and ragged
+    against the tile width."""
+    import dataclasses
+    from hilcodec_amd import engine, ops
     model, mk, sd = build("hil_speech")
     dev = torch.device("cuda:0")
     x = synth.synth_clips(5, 9280, seed=31).to(dev)
+    assert [f.name for f in dataclasses.fields(engine.ExecOptions)] == ["stage_launches", "wide_blocks", "decoder_stage_narrow", "stream_defer_spec"]
 
-    def run(chain, stages, wide=True):
+    def run(stages, wide=True, narrow=True):
         for half in (model.encoder, model.decoder):
-            half.exec_options.offline_chain_blocks = chain
-            half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = stages
-            half.exec_options.offline_wide_blocks = wide
+            half.exec_options.stage_launches = stages
+            half.exec_options.wide_blocks = wide
+            half.exec_options.decoder_stage_narrow = narrow
         with torch.no_grad(), ops.timed_launches() as t:
             z = model.encoder(x)
             q, _, _, idx = model.quantizer(z, None, return_indices=True)
@@ -164,21 +167,20 @@ def test_offline_launch_structure_options_change_no_bit():
         return z, idx, wav, sum(r[0] == "resblock" for r in t.records), len(t.records)
 
     try:
-        a = run(True, True)
-        b = run(True, False)
-        c = run(False, False)
-        d = run(True, True, False)
-        e = run(True, False, False)
-        f = run(False, False, False)
+        a = run(True)
+        c = run(False)
+        d = run(True, False)
+        f = run(False, False)
+        g = run(True, True, False)
     finally:
         for half in (model.encoder, model.decoder):
-            half.exec_options.offline_chain_blocks = half.exec_options.fuse_encoder_stage = half.exec_options.fuse_decoder_stage = True
-            half.exec_options.offline_wide_blocks = True
-    # without the wide blocks' fused form (round 3 + the narrow stages of round 4) — fused-kernel launches: 4 stages / 4 chains / 2 * 2 +
-    # 2 * 3 blocks; and the stage form saves the four down- / up-sampling launches
-    assert (d[3], e[3], f[3]) == (4, 4, 10) and e[4] - d[4] == 4, (d[3:], e[3:], f[3:])
-    # with them: encoder 4 stages / chains, decoder C = 768: (up-sampling layer +) first block, two blocks; C = 384 / 192 / 96: one launch each;
-    # block by block: 4 * 2 + 4 * 3; the stage form saves all eight down- / up-sampling launches; every wide block is one launch less than two
-    assert (a[3], b[3], c[3]) == (10, 10, 20) and b[4] - a[4] == 8 and f[4] - c[4] == 10, (a[3:], b[3:], c[3:], f[3:])
-    for other in (b, c, d, e, f):
+            half.exec_options.stage_launches = half.exec_options.wide_blocks = half.exec_options.decoder_stage_narrow = True
+    # without the wide blocks' fused form (round 3 + the narrow stages of round 4) — fused-kernel launches: 4 stages / 2 * 2 + 2 * 3 blocks
+    assert (d[3], f[3]) == (4, 10), (d[3:], f[3:])
+    # with them: encoder 4 stages, decoder C = 768: (up-sampling layer +) first block, two blocks; C = 384 / 192 / 96: one launch each;
+    # block by block: 4 * 2 + 4 * 3, eight down- / up-sampling launches and the closing conv (a phase of the last stage by default) more; every wide block is one launch less than two
+    assert (a[3], c[3]) == (10, 20) and c[4] - a[4] == 19 and f[4] - c[4] == 10, (a[3:], c[3:], f[3:])
+    # the decoder's narrow / partial stage forms off: C = 768, 192 and 96 get their up-sampling launch back and the closing conv its own (C = 384 keeps its whole-stage launch)
+    assert g[3] == 10 and g[4] - a[4] == 4, (a[3:], g[3:])
+    for other in (c, d, f, g):
         assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])

@@ -228,38 +228,6 @@ def test_tail(env):
     assert torch.equal(ops.tail(x.to(dev), None, 9).cpu(), torch.cat([torch.zeros(2, 3, 2), x], 2))
 
 
-def test_tail_multi_equals_the_ops_own_cache_updates(env):
-    """hilc_tail_multi: the cache updates of a decoder hop (four up-sampling layers: last ACTIVATED input frame; conv_post: last 4
-    activated samples) and of the encoder (waveform tail, no activation) in one launch == each op's own `hist_out`."""
-    ops, fold, O, dev = env
-    B = 37
-    t = ops.DeferredTails()
-    want = []
-    for i, (K, Tin, r) in enumerate(((1536, 1, 8), (768, 8, 5), (384, 40, 4), (192, 160, 2))):
-        x = rnd(10 + i, B, K, Tin).to(dev)
-        tw, wt, b = (rnd(20 + i, K, 2 * r) * 0.3).to(dev), (rnd(30 + i, K, K // 2) / K ** 0.5).to(dev), (rnd(40 + i, K // 2) * 0.1).to(dev)
-        cache = (rnd(50 + i, B, K, 1) * 0.5).to(dev)
-        y, c = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=cache, want_hist=True)
-        y2 = ops.up_conv(x, tw, wt, b, r, in_scale=0.7071, in_elu=True, hist=cache)
-        assert torch.equal(y, y2)
-        want.append((c, t.add(x, None, 1, 0.7071, True)))
-    x = rnd(60, B, 96, 320).to(dev)
-    w, b = (rnd(61, 96, 5) * 0.2).to(dev), (rnd(62, 1) * 0.1).to(dev)
-    cache = (rnd(63, B, 96, 4) * 0.5).to(dev)
-    y, c = ops.conv_post(x, w, b, in_scale=0.7071, in_elu=True, out_scale=0.1122, do_tanh=True, hist=cache, want_hist=True)
-    want.append((c, t.add(x, cache, 4, 0.7071, True)))
-    wav, wh = rnd(70, B, 1, 320).to(dev), rnd(71, B, 1, 1023).to(dev)
-    want.append((ops.tail(wav, wh, 1023), t.add(wav, wh, 1023, 1.0, False)))
-    short = rnd(72, B, 8, 2).to(dev)                        # fewer samples than the cache is long: the rest comes from the old cache
-    sh = rnd(73, B, 8, 4).to(dev)
-    h, c = ops.dw_conv(short, (rnd(74, 8, 5) * 0.3).to(dev), None, in_elu=True, hist=sh, want_hist=True)
-    want.append((c, t.add(short, sh, 4, 1.0, True)))
-    assert len(t.items) == 7
-    t.flush()
-    for a, b_ in want:
-        assert a.shape == b_.shape and torch.equal(a, b_)
-
-
 def test_errors(env):
     ops, fold, O, dev = env
     x = torch.zeros(1, 8, 16, device=dev)
@@ -402,8 +370,7 @@ def test_wide_stream_block_equals_two_launches(env, C, T, B):
 @pytest.mark.parametrize("C,T,B,n", [(64, 320, 5, 2), (64, 320, 1024, 2), (96, 320, 3, 3), (96, 320, 1024, 3), (128, 160, 7, 2), (128, 160, 1024, 2),
                                       (192, 160, 6, 3), (192, 160, 1024, 3), (512, 8, 21, 2), (512, 8, 1024, 2), (768, 8, 37, 3),
                                       (768, 8, 1024, 3), (96, 640, 2, 3), (64, 960, 3, 2), (192, 480, 2, 3), (128, 4, 9, 2), (96, 12, 70, 2),
-                                      (768, 8, 5, 2), (192, 160, 9, 2), (256, 40, 1024, 2), (256, 40, 3, 2), (256, 120, 5, 2), (256, 8, 33, 2), (256, 4, 1, 2),
-                                      (256, 44, 1023, 2)])
+                                      (768, 8, 5, 2), (192, 160, 9, 2)])
 def test_resblock_chain_equals_block_by_block(env, C, T, B, n):
     """The residual blocks of one stage of a streaming hop in ONE launch (hilc_resblock_chain: `streaming.py:497-503,633-639`
     runs them one after the other) against the same blocks launched one by one (hilc_resblock_stream): output and all 2n new
@@ -667,16 +634,135 @@ def test_decoder_stage_offline_equals_up_conv_then_blocks(env, C, r, Tin, B):
     assert torch.equal(y, y2), float((y - y2).abs().max())
 
 
+def _oracle_blocks(O, C, n, seed0=0):
+    """n residual blocks as reference state dicts (for O.resblock) and as the op's parameter tuples (k-major weights, not packed)"""
+    sds, raw = [], []
+    for j in range(n):
+        sd = {
+            "p.block.1.conv.conv.weight": rnd(seed0 + 10 * j + 1, C, C, 1) / C ** 0.5,
+            "p.block.2.conv.conv.weight": rnd(seed0 + 10 * j + 2, C, 1, 5) * 0.5, "p.block.2.conv.conv.bias": rnd(seed0 + 10 * j + 3, C) * 0.2,
+            "p.block.4.conv.conv.weight": rnd(seed0 + 10 * j + 4, C, C, 1) / C ** 0.5,
+            "p.block.5.conv.conv.weight": rnd(seed0 + 10 * j + 5, C, 1, 5) * 0.5, "p.block.5.conv.conv.bias": rnd(seed0 + 10 * j + 6, C) * 0.2,
+            "p.res_scale_param": torch.tensor([0.7 + 0.1 * j]),
+        }
+        sds.append(sd)
+        raw.append((sd["p.block.1.conv.conv.weight"][:, :, 0].t().contiguous(), sd["p.block.2.conv.conv.weight"][:, 0].contiguous(),
+                    sd["p.block.2.conv.conv.bias"], sd["p.block.4.conv.conv.weight"][:, :, 0].t().contiguous(),
+                    sd["p.block.5.conv.conv.weight"][:, 0].contiguous(), sd["p.block.5.conv.conv.bias"],
+                    (1 + j * RS ** 2) ** -0.5, float(RS * sd["p.res_scale_param"][0])))
+    return sds, raw
+
+
+def _chain_params(ops, raw, dev, streaming=False):
+    return [(ops.resblock_chain_pack(w1.to(dev), streaming), d1.to(dev), b1.to(dev), ops.resblock_chain_pack(w2.to(dev), streaming), d2.to(dev),
+             b2.to(dev), pre, post) for (w1, d1, b1, w2, d2, b2, pre, post) in raw]
+
+
+@pytest.mark.parametrize("C,T,B,n", [(96, 120, 7, 3), (64, 1000, 3, 2), (384, 300, 2, 3), (512, 28, 5, 2), (192, 132, 300, 3)])
+def test_resblock_chain_offline_vs_oracle_composition(env, C, T, B, n):
+    """hilc_resblock_chain (offline) against the ORACLE's composition of the stage's blocks (`seanet.py:316-330`: O.resblock n times) — an
+    op-level oracle leg for the stage launches, at shapes no model-level golden reaches (ragged batches, T below one tile)."""
+    ops, fold, O, dev = env
+    assert ops.resblock_chain_supported(C, T, n, B, streaming=False)
+    sds, raw = _oracle_blocks(O, C, n)
+    x = rnd(C + T, B, C, T)
+    ref = x
+    for j, sd in enumerate(sds):
+        ref = O.resblock(sd, "p", ref, RS, j)
+    y = ops.resblock_chain(x.to(dev), _chain_params(ops, raw, dev))
+    close(y, ref, 5e-5, f"chain C{C} T{T} B{B}")
+
+
+@pytest.mark.parametrize("C,r,T,B,n", [(64, 2, 124, 5, 2), (128, 4, 1000, 3, 2), (256, 5, 300, 2, 2), (512, 8, 72, 3, 2), (64, 2, 24, 300, 1)])
+def test_encoder_stage_offline_vs_oracle_composition(env, C, r, T, B, n):
+    """hilc_encoder_stage (offline) against the oracle: the stage's blocks, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C,
+    depthwise conv k = 2r stride r] (`seanet.py:330-339`) and the next stage's SpecBlock branch added (`res`)."""
+    ops, fold, O, dev = env
+    assert ops.encoder_stage_supported(C, T, n, r, B, streaming=False)
+    sds, raw = _oracle_blocks(O, C, n)
+    x = rnd(C + T + r, B, C, T)
+    ref = x
+    for j, sd in enumerate(sds):
+        ref = O.resblock(sd, "p", ref, RS, j)
+    wd = rnd(70, 2 * C, C, 1) / C ** 0.5
+    dw, db = rnd(71, 2 * C, 1, 2 * r) * 0.3, rnd(72, 2 * C) * 0.1
+    res = rnd(73, B, 2 * C, T // r) * 0.5
+    in_scale = (1 + n * RS ** 2) ** -0.5
+    ref = O.sconv1d(F.conv1d(F.elu(ref * in_scale), wd), dw, db, stride=r, groups=2 * C) + res
+    wt = wd[:, :, 0].t().contiguous().to(dev)                  # k-major [C, 2C]
+    down = (ops.resblock_chain_pack(wt[:, :C].contiguous(), False), ops.resblock_chain_pack(wt[:, C:].contiguous(), False),
+            dw[:, 0].contiguous().to(dev), db.to(dev), in_scale, r)
+    y = ops.encoder_stage(x.to(dev), _chain_params(ops, raw, dev), down, res=res.to(dev))
+    close(y, ref, 5e-5, f"encoder stage C{C} r{r} T{T} B{B}")
+
+
+@pytest.mark.parametrize("C,r,Tin,B", [(192, 4, 31, 5), (96, 2, 300, 3), (768, 8, 9, 2), (384, 5, 24, 3), (96, 2, 14, 300)])
+def test_decoder_stage_offline_vs_oracle_composition(env, C, r, Tin, B):
+    """hilc_decoder_stage (offline) against the oracle: `[Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C + bias]`
+    (`seanet.py:431-436`) followed by the stage's residual blocks (`:437-452`)."""
+    ops, fold, O, dev = env
+    n = 1 if C == 768 else 3
+    assert ops.decoder_stage_supported(C, Tin * r, n, r, B, streaming=False)
+    sds, raw = _oracle_blocks(O, C, n)
+    tw = rnd(80, 2 * C, 1, 2 * r) * 0.3
+    wu = rnd(81, C, 2 * C, 1) / (2 * C) ** 0.5
+    bu = rnd(82, C) * 0.1
+    xin = rnd(100 + C, B, 2 * C, Tin)
+    ref = F.conv1d(O.sconvtr1d(F.elu(xin * 0.7071), tw, None, r, 2 * C), wu, bu)
+    for j, sd in enumerate(sds):
+        ref = O.resblock(sd, "p", ref, RS, j)
+    twd = tw[:, 0].contiguous().to(dev)
+    wt = wu[:, :, 0].t().contiguous().to(dev)                  # k-major [2C, C]
+    taps = ops.up_conv_taps(twd, r)
+    up = (twd if taps is None else taps, ops.resblock_chain_pack(wt[:C].contiguous(), False), ops.resblock_chain_pack(wt[C:].contiguous(), False),
+          bu.to(dev), 0.7071, r)
+    y = ops.decoder_stage(xin.to(dev), up, _chain_params(ops, raw, dev))
+    close(y, ref, 5e-5, f"decoder stage C{C} r{r} Tin{Tin} B{B}")
+
+
+@pytest.mark.parametrize("Tin,B", [(12000, 2), (300, 7), (14, 300), (62, 5), (6000, 24)])
+def test_decoder_stage_post_equals_stage_then_conv_post_and_oracle(env, Tin, B):
+    """hilc_decoder_stage_post: the offline decoder's LAST stage (C = 96, r = 2, three blocks) with the closing conv k = 5 C -> 1, the
+    final scale and tanh (`seanet.py:453-476`) as the launch's closing phase == hilc_decoder_stage followed by hilc_conv_post, bit
+    for bit (same row classes, same order of the partial sums) — ragged batches, T below a tile, runs that start inside a clip
+    (warm-up tiles) — and, on the small shapes, the oracle's composition."""
+    ops, fold, O, dev = env
+    C, r, n = 96, 2, 3
+    T = Tin * r
+    assert ops.decoder_stage_post_supported(C, T, n, r, 5) and not ops.decoder_stage_post_supported(192, T, n, 4, 5)
+    sds, raw = _oracle_blocks(O, C, n)
+    blocks = _chain_params(ops, raw, dev)
+    tw = rnd(80, 2 * C, 1, 2 * r) * 0.3
+    wu = rnd(81, C, 2 * C, 1) / (2 * C) ** 0.5
+    bu = rnd(82, C) * 0.1
+    pw, pb = rnd(83, 1, C, 5) * 0.2, rnd(84, 1) * 0.1
+    xin = rnd(100 + Tin, B, 2 * C, Tin)
+    twd = tw[:, 0].contiguous().to(dev)
+    wt = wu[:, :, 0].t().contiguous().to(dev)
+    up = (twd, ops.resblock_chain_pack(wt[:C].contiguous(), False), ops.resblock_chain_pack(wt[C:].contiguous(), False), bu.to(dev), 0.7071, r)
+    post = (pw[0].contiguous().to(dev), pb.to(dev), 0.5, 0.1122, True)
+    wav = ops.decoder_stage_post(xin.to(dev), up, blocks, post)
+    y = ops.decoder_stage(xin.to(dev), up, blocks)
+    wav2 = ops.conv_post(y, post[0], post[1], in_scale=0.5, in_elu=True, out_scale=0.1122, do_tanh=True)
+    assert wav.shape == (B, 1, T) and torch.equal(wav, wav2), float((wav - wav2).abs().max())
+    if B * T <= 50000:
+        ref = F.conv1d(O.sconvtr1d(F.elu(xin * 0.7071), tw, None, r, 2 * C), wu, bu)
+        for j, sd in enumerate(sds):
+            ref = O.resblock(sd, "p", ref, RS, j)
+        ref = torch.tanh(O.sconv1d(F.elu(ref * 0.5), pw, pb) * 0.1122)
+        close(wav, ref, 2e-5, f"decoder stage + conv_post Tin{Tin} B{B}")
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
-    assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(256, 40, 2, 1) == 1
+    assert lib.hilc_resblock_chain_supported(768, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(384, 40, 3, 1) == 0 and lib.hilc_resblock_chain_supported(256, 40, 2, 1) == 0
     assert lib.hilc_resblock_chain_supported(96, 320, 1, 1) == 0 and lib.hilc_resblock_chain_supported(96, 320, 4, 1) == 0
     assert lib.hilc_resblock_chain_supported(96, 320, 3, 0) == 1 and lib.hilc_resblock_chain_supported(96, 322, 3, 1) == 0
     assert lib.hilc_resblock_chain_supported(768, 8, 3, 0) == 0 and lib.hilc_resblock_chain_supported(64, 320, 3, 0) == 0
     assert lib.hilc_resblock_chain_supported(64, 320, 3, 1) == 0 and lib.hilc_resblock_chain_supported(512, 8, 3, 1) == 0      # 2-block instantiations
     assert not ops.resblock_chain_supported(64, 320, 3, 2) and ops.resblock_chain_supported(64, 320, 2, 2)
-    assert not ops.resblock_chain_supported(384, 40, 3, 8) and ops.resblock_chain_supported(256, 40, 2, 8) and not ops.resblock_chain_supported(256, 40, 3, 8) and not ops.resblock_chain_supported(96, 320, 3, 40000)
+    assert not ops.resblock_chain_supported(384, 40, 3, 8) and not ops.resblock_chain_supported(256, 40, 2, 8) and ops.resblock_chain_supported(256, 3000, 2, 8, streaming=False) and not ops.resblock_chain_supported(96, 320, 3, 40000)
 
 
 def test_wide_stream_block_shapes_it_does_not_take(env):

@@ -16,8 +16,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--model", default="hil_speech")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--mode", default="offline", choices=["offline", "streaming"])
-ap.add_argument("--no-stage", action="store_true", help="encoder stages as chain + separate down-sampling layer")
-ap.add_argument("--no-chain", action="store_true", help="one launch per residual block (round 3) instead of one per stage")
+ap.add_argument("--no-stage", action="store_true", help="one launch per residual block and per down- / up-sampling layer (round 3) instead of one per stage")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 mk = synth.model_kwargs(args.model)
@@ -25,8 +24,7 @@ model = hilcodec_amd.HILCodec(24000, 1, **mk).eval()
 model.load_state_dict(synth.synth_state_dict(args.model, 7), strict=False)
 for l in model.quantizer.layers:
     l.initted = True
-model.encoder.exec_options.offline_chain_blocks = model.decoder.exec_options.offline_chain_blocks = not args.no_chain
-model.encoder.exec_options.fuse_encoder_stage = not args.no_stage
+model.encoder.exec_options.stage_launches = model.decoder.exec_options.stage_launches = not args.no_stage
 x = synth.synth_clips(args.batch, 24000).to(dev)
 
 
@@ -42,8 +40,7 @@ if args.mode == "streaming":
     smodel = StreamingHILCodec(24000, **smk).eval()
     smodel.load_offline_state_dict(synth.synth_state_dict(args.model, 7))
     smodel.remove_weight_reparameterizations()
-    smodel.encoder.exec_options.stream_chain_blocks = smodel.decoder.exec_options.stream_chain_blocks = not args.no_chain
-    smodel.encoder.exec_options.fuse_encoder_stage = not args.no_stage
+    smodel.encoder.exec_options.stage_launches = smodel.decoder.exec_options.stage_launches = not args.no_stage
     nq = mk["vq_kwargs"]["num_quantizers"]
     xs = synth.synth_clips(args.batch, 320, seed=4321).to(dev)
     state = list(smodel.initialize_cache(xs))
