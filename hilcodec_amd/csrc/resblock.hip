@@ -1,5 +1,5 @@
 // Entry points of the fused residual block, one block per launch (kernel: resblock_kernel.h).
-#include "resblock_kernel.h"
+#include "resblock_launch.h"
 
 namespace {
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* wt, float* packed, int C, int RH) {

@@ -6,7 +6,7 @@
 // the next block's input and shortcut — the activations between the blocks of a stage never reach HBM, and a streaming hop
 // loses 2 of 3 launch boundaries per stage (at 1024 streams a launch is 5-10 tiles per workgroup: its ends are 10-20 % of it).
 // Same products in the same order as hilc_resblock / hilc_resblock_stream: bit-identical (tests/test_gpu_ops.py).
-#include "resblock_kernel.h"
+#include "resblock_launch.h"
 
 namespace {
 constexpr bool chain_width(int C) { return C == 64 || C == 96 || C == 128 || C == 192; }
@@ -144,6 +144,36 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
     case 256: return launch_chain<256, false, 2, false, 5>(a, B, s);
     default: return launch_chain<512, false, 2, false, 8>(a, B, s);
   }
+}
+
+// ---- the encoder's FIRST stage with its input computed in the launch (offline) ------------------------------------------------------------
+// seanet.py:280-286 (first conv), 220-246 (SpecBlock of stage 0), 316-339 (blocks, down-sampling layer): == hilc_spec_block_conv_pre followed by
+// hilc_encoder_stage (C = 64, r = 2), bit for bit; the [B][64][T] tensor between the two never exists (1.57 GB written and read at 256 clips).
+extern "C" int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize) {
+  return nblk >= 1 && nblk <= 2 && stride == 2 && n_fft == 64 && hop == 1 && pre_ksize == 5 && T > 0 && T % 4 == 0;
+}
+
+extern "C" int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
+                                   int B, int T, void* stream) {
+  if (!spec || !blocks || !down) return HILC_ERR_NULL;
+  if (!spec->wav || !spec->dft_packed || !spec->nyq_sin || !spec->pw_packed || !spec->pre_w) return HILC_ERR_NULL;
+  if (!down->w_lo || !down->w_hi || !down->dw_w || !down->dw_b || !down->y) return HILC_ERR_NULL;
+  if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
+  if (!hilc_encoder_stage0_supported(T, nblk, down->stride, spec->n_fft, spec->hop, spec->pre_ksize)) return HILC_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(down->y) & 15) || (reinterpret_cast<uintptr_t>(down->res) & 15) || down->res == down->y) return HILC_ERR_UNSUPPORTED;
+  ResArgs a;
+  a.x = spec->wav; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
+  if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
+  a.up = ResUp{};
+  a.post = ResPost{};
+  ResDown& d = a.dn;
+  d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = nullptr; d.hist_out = nullptr;
+  d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
+  ResSpec0& sp = a.spec;
+  sp.wav = spec->wav; sp.dft = spec->dft_packed; sp.nyq = spec->nyq_sin; sp.pw = spec->pw_packed; sp.bias = spec->bias;
+  sp.pre_w = spec->pre_w; sp.pre_b = spec->pre_b; sp.pre_in_scale = spec->pre_in_scale; sp.mean = spec->mean; sp.stdv = spec->std;
+  sp.out_scale = spec->out_scale; sp.normalize = spec->normalize;
+  return launch_chain<64, false, 2, false, 2, false, true>(a, B, (hipStream_t)stream);
 }
 
 // ---- a DECODER STAGE of a streaming hop in one launch: its up-sampling layer and its residual blocks -----------------------------

@@ -1,411 +1,23 @@
 #pragma once
-// resblock_kernel.h — shared by resblock.hip (one block per launch) and resblock_chain.hip (a stage's blocks in one launch).
-//
-// Fully fused SEANet residual block for the narrow, long layers (C <= 192), gfx950.
-//
-//   y = x + out_scale * dw2( pw2( ELU( dw1( pw1( ELU(pre_scale * x) ) ) + b1 ) ) ) + b2 )      (seanet.py:129-148)
-//
-// For C in {64, 96} the un-fused block is HBM-bound (1x1 conv intensity = C/4 flop/B): this kernel reads x ONCE and
-// writes y once; everything between lives in registers and one LDS tile.
-//
-// Workgroup = NW waves walking a CONTIGUOUS run of tiles; a tile = NCOL columns of one clip (see Cfg), column c <-> time
-// t0 + c with t0 = NCOL * (tile within the clip).  The two causal k = 5 convs need the 4 columns in front of a tile of H1 and
-// of H2: the previous tile of the run leaves them in LDS (CARRY), a clip's first tile takes zeros (streaming: the caches).  A run
-// that starts inside a clip walks the tile in front of it once without storing anything (warm-up).  No column is computed twice
-// (rounds 1-3 recomputed an 8-column halo per tile: 6.25 % of the GEMM work).
-//   P0  a1 = ELU(pre*x) from the x REGISTERS (loaded during the previous tile's P6)  -> LDS  X[k][c]
-//   P1  GEMM1  H1 = W1 * a1   (fp32 MFMA 32x32x2; a wave owns one 32-column block and CBW row blocks)
-//   P2  accumulators -> LDS  X[m][c]
-//   P3  a2 = ELU(dw1(H1)+b1) in place (a row is handled by one wave instruction, so read-before-write holds
-//       without a barrier, for the tile and for the carry)
-//   P4  GEMM2  H2 = W2 * a2
-//   P5  accumulators -> LDS
-//   P6  y = (dw2(H2)+b2)*out_scale + x (the shortcut comes from the x registers: no re-read) -> HBM; as soon as a
-//       row batch is stored its x registers are re-loaded with the NEXT tile's rows, so the loads travel under the
-//       rest of P6 / the barrier and P0 never waits for HBM (the next tile's lines were touched into this XCD's L2
-//       during GEMM2).
-// Cost model behind this shape (profiles/r02_mfma_shadow_microbench.txt): next to fp32 MFMAs (64 cycles each) LDS
-// traffic and sparse global loads are free, a VALU instruction costs ~2.8 cycles of the same pipe (4.9 when a SIMD
-// hosts a single wave: one wave cannot issue VALU back to back), v_exp_f32 8.4.  Hence: (i) the element-wise phases
-// process rows in BATCHES — all LDS reads of a batch, then the arithmetic, then the writes; the in-place row
-// update used to serialise on one exposed LDS round trip per row (P3 / P6 ran at a third of their VALU rate);
-// (ii) every LDS address is base + compile-time constant (a select in an address hides the no-alias fact from the
-// scheduler); (iii) C = 192, whose 96 KB tile allows one workgroup per CU, runs 8 waves (two per SIMD, each owning
-// half of the row blocks) so that the VALU phases issue at full rate.
-// A operands (weights) are read straight from global memory (L1/L2 resident, a few tens of KB) into VGPRs one
-// 16-deep K slice ahead — no LDS staging, no barrier in the K loop.
-// Summation order: k ascending (an fmaf chain), taps j = 0..4 — the same as the un-fused kernels.
-//
-// STREAM instantiation (hilc_resblock_stream; streaming.py:195-276 with causal_layers.py:147-167 caches): the
-// tile walks the FLAT column space (clip-major, b*T + t) so short hops (T = 160 / 320 per stream) still fill
-// 120 of 128 columns; the 4 samples before a clip's t = 0 come from the caches hist1 / hist2 (= last 4
-// pointwise outputs of the previous hop) instead of the LDS neighbours, and the lanes holding t = T-4..T-1
-// store the new caches.  Per-column arithmetic is identical, so hop-by-hop output == offline output bit for bit.
-#include <stdlib.h>
-
-#include <atomic>
-#include <type_traits>
-
-#include "gemm_core.h"
-
-using namespace hilc;
+// resblock_kernel.h — part 3 of 4: the kernel.  Phase map of one tile (details: resblock_cfg.h):
+//   [U]   up-sampling layer (decoder stages, Cfg::UR > 0): operand built in the tile, two GEMMs, + bias -> x registers
+//   per block of the chain:  P0 prologue -> tile | P1 GEMM1 | P2 acc -> tile | P3 dw1 + ELU in place | P4 GEMM2 | P5 acc -> tile |
+//                            P6 dw2, scale, shortcut -> HBM / x registers (next block) / activated tile (Q follows)
+//   [D]   down-sampling layer (encoder stages, Cfg::DR > 0): ELU -> tile, two GEMMs, strided depthwise conv (+ res) -> HBM
+//   [Q]   closing conv of the decoder (Cfg::POST): taps over the activated tile, class sums through PR, tanh -> waveform
+// Register / LDS contract between the phases:
+//   * xr[RW] (f32x4 per row of the lane) is the ONLY tile-sized state in registers: the block's input and shortcut; P6 of a chain's
+//     inner block overwrites it with the block's output; it is dead after the last block's P6 when D / Q follows (D re-uses it for the
+//     next tile's rows).
+//   * the LDS tile X[C][XS] has ONE owner at a time: P0/P3/U/D0/P6(Q) write operands, GEMM phases read them, acc_to_x overwrites them
+//     with results; every hand-over is one lds_barrier().  Columns NCOL.. of a row are the carry slots (4 floats each): H1 / H2 of
+//     every block, then the D phase's two halves or the Q phase's one — written by the lane of the tile's last column group, read by
+//     the lane of column group 0 of the NEXT tile of the run, zeroed at a clip's first tile.
+//   * DW / DWD (tap tables) are written once per workgroup (or per block: DW_RELOAD) and read-only inside a phase; PR belongs to Q.
+#include "resblock_gemm.h"
+#include "stream_gemm.h"
 
 namespace {
-
-constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1, w2_0, w2_1 | w2_2..4, b2]
-
-// Shape of a workgroup: 128-column tiles for C <= 192 (8 waves at C = 192 and where W8_ says so, else 4: two or three workgroups per
-// CU), the NARROW shapes for C >= 256.  (A 256-column lockstep shape with one 8-wave workgroup per CU was measured three times,
-// rounds 2-4: 3-6 % slower at every width; tools/ history.)
-// run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
-// (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
-// 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
-// (round 4, stage launches on the no-longer-power-limited chip, tools/share_sweep_chain.sh: C = 96 stage 0.50 -> 9.16 ms, 0.56 -> 8.89, 0.60 - 0.62 -> 8.70,
-// 0.64 -> 8.84, 0.68 -> 9.10, 0.72 -> 9.43; C = 64 stage 3.44 / 3.39 / 3.30 / 3.38 / 3.42 / 3.54)
-#ifndef HILC_RES_SHARE2_0
-#define HILC_RES_SHARE2_0 0.61
-#endif
-#ifndef HILC_RES_SHARE3_0
-#define HILC_RES_SHARE3_0 0.44
-#define HILC_RES_SHARE3_1 0.31
-#endif
-// NB_ > 1: a CHAIN — the NB_ consecutive residual blocks of one stage (seanet.py:316-330 / streaming.py: `blocks[s]`) in ONE
-// launch: per tile the blocks run back to back, the output of block j stays in the x REGISTERS as the input (and shortcut) of
-// block j + 1, only the last block stores; every block has its own carry slots, tap table, weights and (STREAM) caches.  Needs
-// the carry form (contiguous runs) or whole-stream tiles (NARROW, C >= 512).  W8_: 8 waves also below C = 192 (one workgroup
-// per CU: a streaming hop of 1024 streams is then 256 equal runs of 4 whole streams — no partly filled round).
-// DR_ > 0: the stage's DOWN-SAMPLING layer (seanet.py:330-339: [Scale, ELU, 1x1 conv C -> 2C, depthwise k = 2r stride r]) as the
-// last phase of the launch ("D"): the stage's output never reaches HBM — it goes from the last block's registers through ELU into
-// the LDS tile, two GEMMs (the two halves of the 2C output rows) and the strided depthwise conv, which reads the tile like P3 does
-// (previous 4 columns + own 4 columns per lane) with its own two carry slots.  DR_ = r in {2, 4}: the encoder's first two stages.
-// POST_: the decoder's LAST layer (seanet.py:453-476: [Scale, ELU, conv k = 5 C -> 1 with bias] and the final out_scale / tanh, = hilc_conv_post)
-// as the closing phase of the launch ("Q"): the last block leaves ELU(in_scale * y) in the LDS tile instead of storing y, every lane
-// accumulates its rows' taps over its 4 columns (previous columns: left neighbour or a third carry slot), the row classes' partial sums
-// meet in LDS in a fixed order — the order hilc_conv_post uses, so the two forms agree bit for bit — and 128 threads store the waveform:
-// the stage's [B][C][T] output (2.36 GB at 256 clips) is neither written nor read.  Offline carry form, C = 96.
-template <int C, bool STREAM, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0, bool POST_ = false>
-struct Cfg {
-  static constexpr bool POST = POST_;
-  static_assert(!POST_ || (!STREAM && DR_ <= 0 && C <= 192 && !W8_), "closing conv: the offline carry form of a narrow stage");
-  static constexpr int NB = NB_;
-  static constexpr int DR = DR_ > 0 ? DR_ : 0;
-  // DR_ < 0: the stage's UP-SAMPLING layer (seanet.py:431-436: [Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C
-  // with bias]) as the FIRST phase of the launch ("U", r = -DR_): the tile's x is not read but computed — the up-sampled operand of
-  // the 2C rows is built in the LDS tile one half (C rows) at a time from the input frames, their cache and the 2r taps (two FMAs per
-  // element, like the loader of hilc_up_conv), two GEMMs accumulate over the 2C rows in k order, + bias -> the x registers.  The
-  // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
-  static constexpr int UR = DR_ < 0 ? -DR_ : 0;
-  static_assert(DR_ <= 0 || (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || (!STREAM && ((DR_ == 5 && C == 256) || (DR_ == 8 && C == 512)))),
-                "down-sampling phase: carry form, r = 2 / 4 (C <= 192) or the wide encoder stages of the offline model (C = 256: r = 5, C = 512: r = 8)");
-  // carry columns of the down-sampling phase per half of its 2C rows: the strided conv reads k - r = r columns in front of its first
-  // output's window; r = 2 / 4: the 4 in front of a lane's group; r = 8: 8; r = 5: up to 9 (a tile does not start on a multiple of 5) -> 12
-  static constexpr int DCAR = DR_ <= 0 ? 0 : (DR_ == 5 ? 12 : (DR_ == 8 ? 8 : 4));
-  static_assert(DR_ >= 0 || ((DR_ == -8 && C >= 512) || (DR_ == -5 && C == 384) || ((DR_ == -4 || DR_ == -2) && C <= 192 && (!STREAM || SCARRY_))),
-                "up-sampling phase: 32-column tiles (r = 8: whole streams, or the offline carry form), the C = 384 stage (r = 5) or the carry form (r = 4 / 2)");
-  static constexpr int CH = C;
-  static constexpr int CB = C / 32;
-  // NARROW (C >= 256: the wide blocks — of a streaming hop, 8 or 40 frames per stream, and since round 4 of the offline model): the
-  // whole channel range of a 32- or 64-column tile in LDS, the eight waves split the ROW blocks (RH = 8 or 4 row classes).
-  // STREAM: at 32 columns a tile is whole streams (T divides 32): every tile starts at a stream's t = 0, where the caches supply the
-  // previous samples, so there is no halo to recompute; 64-column tiles walk the flat column space with an 8-column halo.
-  // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
-  static constexpr bool NARROW = C >= 256;
-  static constexpr int NCOL = NARROW ? (C >= 512 ? 32 : 64) : 128;      // tile width = LDS row stride (floats)
-  static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR + (POST_ ? 4 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
-  // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
-  // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
-  // recomputed an 8-column left halo of the two causal k = 5 convs: 6.25 % of a 128-column tile.)  STREAM keeps the halo and the
-  // strided / ticketed tile order: a hop is 2.5-5 tiles per workgroup, runs would rarely start on a stream's t = 0 and each start
-  // inside a stream costs a warm-up tile (measured: 5.34 -> 6.26 ms per hop with two stream groups).
-  // SCARRY: the carry form for a STREAMING launch whose geometry lets every run start on a stream's t = 0 (launch_res decides:
-  // 1024 streams x 160 samples = 256 runs of exactly 5 tiles = 4 whole streams each, five rounds of tiles instead of six).
-  static constexpr bool CARRYMODE = !STREAM || SCARRY_;
-  static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
-  static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = (C >= 192 || W8_) ? 8 : 4;           // waves per workgroup
-  static constexpr int NT = 64 * NW;
-  static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
-  static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
-  static constexpr int RPI = 256 / NCOL;             // rows covered by one wave instruction of the element-wise phases
-  static constexpr int RSTEP = RPI * NW;
-  static constexpr int RW = C / RSTEP;               // rows per lane there
-#ifndef HILC_RES_RB
-#define HILC_RES_RB 4
-#endif
-  static constexpr int RB = HILC_RES_RB;             // rows per batch there
-  // weight stream: DEPTH register sets of KP k-pairs each; the loads run DEPTH-1 sets (= (DEPTH-1)*KP*CBW MFMAs per
-  // wave, twice that in wall time with two waves per SIMD) ahead of their use
-#ifdef HILC_RES_KP
-  static constexpr int KP = HILC_RES_KP;
-  static constexpr int DEPTH = HILC_RES_DEPTH;
-#else
-  // (round 4, on a chip that is no longer power-limited — tools/build_variants.py + variant_table.sh, one box: KP = 4 / DEPTH = 2 instead of 4 / 4
-  //  at C = 192: 14.84 -> 14.64 ms per offline stage, instead of 8 / 2 at C = 96: 9.00 -> 8.89; the wide shapes lose with it: C = 768 5.30 -> 5.39)
-  static constexpr int KP = C >= 96 ? 4 : 8;
-  static constexpr int DEPTH = C >= 256 ? 4 : (C == 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
-#endif
-#ifndef HILC_RES_MINW
-#define HILC_RES_MINW 2
-#endif
-  static constexpr int MINW = NW == 8 ? 2 : HILC_RES_MINW;   // waves per SIMD the register budget must allow
-  static_assert(NW % (NCOL / 32) == 0 && CB % RH == 0 && RW % RB == 0 && C % RSTEP == 0, "tile split");
-  static_assert(NB_ >= 1 && NB_ <= 3 && (NB_ == 1 || CARRYMODE || (NARROW && C >= 512)), "a chain needs carries or whole-stream tiles");
-};
-
-struct ResBlk {       // one residual block's parameters
-  const float* w1t;   // packed, see WeightPipe
-  const float* dw1_w; // [C][5]
-  const float* dw1_b; // [C]
-  const float* w2t;
-  const float* dw2_w;
-  const float* dw2_b;
-  const float* hist1;   // STREAM: [B][C][4] caches of the two depthwise convs (NULL = zeros), and their successors
-  const float* hist2;
-  float* hist1_out;
-  float* hist2_out;
-  float pre_scale, out_scale;
-};
-
-struct ResUp {        // the stage's up-sampling layer (UR > 0)
-  const float* xin;   // [B][2C][T/r]
-  const float* tr_w;  // [2C][2r] taps of the depthwise transposed conv
-  const float* w_lo;  // rows [0, C) of the k-major [2C][C] pointwise weight, packed like a block's matrix
-  const float* w_hi;  // rows [C, 2C)
-  const float* bias;  // [C]
-  const float* hist;  // [B][2C] the ACTIVATED last input frame of the previous hop (NULL = zeros)
-  float* hist_out;
-  float in_scale;
-};
-
-struct ResDown {      // the stage's down-sampling layer (DR > 0)
-  const float* w_lo;  // packed like a block's matrix: columns [0, C) of the k-major [C][2C] pointwise weight
-  const float* w_hi;  // columns [C, 2C)
-  const float* dw_w;  // [2C][2r]
-  const float* dw_b;  // [2C]
-  const float* hist;  // STREAM: [B][2C][r] last r pointwise outputs of the previous hop (NULL = zeros)
-  float* hist_out;
-  const float* res;   // optional [B][2C][T/r]: added to the output (the next stage's SpecBlock branch)
-  float* y;           // [B][2C][T/r]
-  float in_scale;
-};
-
-struct ResPost {      // the decoder's last layer as the closing phase (POST)
-  const float* w;     // [C][5]
-  const float* bias;  // [1] or NULL
-  float* wav;         // [B][1][T]
-  float in_scale, out_scale;
-  int do_tanh;
-};
-
-constexpr int POST_CLASSES = 8;   // row classes of the closing conv's reduction (= hilc_conv_post's: c mod 8), summed in ascending order
-
-constexpr int MAXBLK = 3;
-constexpr int DDS = 12;   // per-row table of the down-sampling taps in LDS: [w_0..3 | w_4..7 | b, -, -, -]
-
-struct ResArgs {
-  const float* x;
-  ResBlk blk[MAXBLK];
-  int nblk;
-  ResDown dn;
-  ResUp up;
-  ResPost post;
-  long run_tiles;     // chain launches on the streaming column space: tiles per run (whole streams), 0 = equal split of the grid
-  float* y;
-  int T, tiles;
-  int classes;        // carry form: workgroups per CU (0 = equal runs) and the cumulative run shares of the dispatch classes, 16-bit fractions
-  unsigned cum[5];
-  long total_tiles;
-  int B;
-  unsigned div_magic, div_shift;   // STREAM: n / T == __umulhi(n, div_magic) >> div_shift for n < 2^31
-  // optional dynamic tile scheduler: two ints, zero at launch and zero again at exit.  Co-resident workgroups do
-  // not share a CU fairly (the older one wins issue arbitration), so with static tile lists part of the kernel runs
-  // at reduced occupancy; with tickets the faster workgroup simply takes more tiles.
-  int* sched;
-  unsigned long long* dbg;   // optional [tiles][8] s_memtime stamps (HILC_DEBUG_STAMPS builds, tools/res_phase_times.py)
-};
-
-#ifdef HILC_DEBUG_STAMPS
-unsigned long long* g_dbg = nullptr;   // tools/res_phase_times.py builds its own copy of the library with this
-#endif
-
-// The weight pointers go through an empty asm (LICM fence, see resblock_kernel) and come back without their
-// address space: loads through them would be FLAT instructions (LDS-or-global check, both wait counters).  This
-// type puts them back into the global address space -> global_load.
-typedef const __attribute__((address_space(1))) float* gptr_t;
-// the same for the laundered LDS row pointers: keep them 32-bit LDS pointers (ds_read / ds_write, not flat_load)
-typedef __attribute__((address_space(3))) float* lptr_t;
-typedef __attribute__((address_space(3))) f32x4* lvec_t;
-typedef __attribute__((address_space(3))) f32x2* lvec2_t;
-
-// Packed ("MFMA lane order") weights, produced by hilc_resblock_pack_weights from the k-major [K][C] matrix.  For
-// the wave class h (row half, RH of them) and K slice kt the 8*CBW operands a lane feeds to the MFMAs sit in
-// NQ = 2*CBW consecutive 16-B words per lane and a wave's 64 lanes read 1 KiB contiguous per load:
-//   packed[(((h * C/16 + kt) * NQ + q) * 64 + lane) * 4 + e] = W[kt*16 + 2j + (lane >> 5)][32*(h*CBW + i) + (lane & 31)]
-//   with q*4 + e = j*CBW + i   (j = k-pair of the slice, i = row block of the wave).
-// DEPTH register sets: the weights of slice kt+DEPTH-1 are requested in the shadow of the MFMAs of slice kt; the
-// first DEPTH-1 slices are requested by prefetch() BEFORE the element-wise phase that precedes the GEMM.
-template <class K>
-struct WeightPipe {
-  static constexpr int CBW = K::CBW;
-  static constexpr int DEPTH = K::DEPTH;
-  static constexpr int KP = K::KP;              // k-pairs per register set (8 = one 16-deep slice, 4 = half of one)
-  static constexpr int WPS = KP * CBW / 4;      // 16-B words per lane and set (consecutive in the packed array)
-  static_assert(KP * CBW % 4 == 0 && 8 % KP == 0, "register set = whole 16-B words");
-  float a[DEPTH][KP][CBW];
-  // wset: UNIFORM pointer to the set's first word (scalar base + lane offset + immediate: no per-lane 64-bit adds)
-  __device__ __forceinline__ void load_word(gptr_t wset, int slot, int q, int lane) {
-    typedef const __attribute__((address_space(1))) f32x4* gvec_t;
-    const f32x4 v = *(gvec_t)(wset + q * 256 + lane * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) a[slot][(q * 4 + e) / CBW][(q * 4 + e) % CBW] = v[e];
-  }
-  __device__ __forceinline__ void prefetch(const float* __restrict__ wt, int lane) {
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < WPS; ++q) load_word((gptr_t)(wt + d * WPS * 256), d, q, lane);
-  }
-};
-
-// wt: this wave class's part of the packed matrix;  X: LDS tile;  colblk: the wave's 32-column block
-template <class K, bool ZERO = true>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                           WeightPipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS;
-  constexpr int CBW = K::CBW;
-  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
-  constexpr int NSETS = C / 2 / KP;
-  const int kh = lane >> 5, l31 = lane & 31;
-  // this lane's B column: X[(2p+kh)][32*colblk + l31], p = k-pair.  `xn` walks ahead of the MFMAs one register set at a
-  // time and is laundered after every step: a DS instruction reaches 64 KB past its base register, the tile is up to
-  // 136 KB, and left alone hipcc materialises one base register per far row and keeps them all alive (spilling them).
-  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
-  float b[DEPTH][KP];
-#pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d) {
-#pragma unroll
-    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
-    xn += KP * 2 * XS;
-    asm volatile("" : "+v"(xn));
-  }
-  // Issue order, pinned: the weight words of set s+DEPTH-1 are spread over the MFMAs of set s (one every fourth),
-  // its LDS operand reads one per k-pair.
-  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
-#pragma unroll
-  for (int s = 0; s < NSETS; ++s) {
-    const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
-    const int sn = s + DEPTH - 1;
-    const bool more = sn < NSETS;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      if (more) b[nxt][j] = xn[j * 2 * XS];
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int n = j * CBW + i;                   // MFMA index inside the set
-        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        if (ZERO && s == 0 && j == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        }
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-      }
-    }
-    if (more) {
-      xn += KP * 2 * XS;
-      wn += WPS * 256;
-      asm volatile("" : "+v"(xn), "+s"(wn));
-    }
-    // pin the set: an empty asm that "updates" the accumulators and clobbers memory keeps this set's MFMAs above it and
-    // the later sets' loads below it.  The builtins are pure, and left alone hipcc sinks a whole phase's MFMAs under all of
-    // its operand loads (~300 spilled registers); pinned, they schedule as written, need fewer registers than the asm form
-    // (C = 192: 202 instead of 219) and — unlike an asm MFMA (rounds 1-2) — carry their hazard information: split-bf16 phases
-    // written with asm MFMAs fed by VALU conversions produced rare garbage tiles that no manual wait state fixed.
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");
-  }
-}
-
-// The same phase ROLLED, for the wide channel counts of the NARROW stream shapes (C = 768: 96 register sets of 12 MFMAs —
-// fully unrolled that is 25 KB of code per phase): a loop over groups of DEPTH sets, so that the register-set indices stay
-// compile-time; issue order, products and k order are those of gemm_phase.
-template <class K, bool ZERO = true>
-__device__ __forceinline__ void gemm_phase_rolled(const float* __restrict__ wt, const float* X, f32x16 (&acc)[K::CBW],
-                                                  WeightPipe<K>& wp, int colblk, int lane) {
-  constexpr int C = K::CH, XS = K::XS;
-  constexpr int CBW = K::CBW;
-  constexpr int DEPTH = WeightPipe<K>::DEPTH, KP = WeightPipe<K>::KP, WPS = WeightPipe<K>::WPS;
-  constexpr int NSETS = C / 2 / KP;
-  static_assert(NSETS % DEPTH == 0 && NSETS >= 2 * DEPTH, "whole groups of register sets");
-  constexpr int NG = NSETS / DEPTH;
-  const int kh = lane >> 5, l31 = lane & 31;
-  lptr_t xn = (lptr_t)(X + kh * XS + colblk * 32 + l31);
-  float b[DEPTH][KP];
-#pragma unroll
-  for (int d = 0; d < DEPTH - 1; ++d) {
-#pragma unroll
-    for (int j = 0; j < KP; ++j) b[d][j] = xn[j * 2 * XS];
-    xn += KP * 2 * XS;
-    asm volatile("" : "+v"(xn));
-  }
-  constexpr int LD_EVERY = KP * CBW / WPS;           // = 4
-  const float* wn = wt + (DEPTH - 1) * WPS * 256;    // uniform: first word of the set being fetched
-  if constexpr (ZERO) {
-#pragma unroll
-    for (int i = 0; i < CBW; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  }
-  auto one_set = [&](auto dc, bool more) {
-    constexpr int cur = decltype(dc)::value, nxt = (cur + DEPTH - 1) % DEPTH;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      if (more) b[nxt][j] = xn[j * 2 * XS];
-#pragma unroll
-      for (int i = 0; i < CBW; ++i) {
-        const int n = j * CBW + i;
-        if (more && n % LD_EVERY == 0) wp.load_word((gptr_t)wn, nxt, n / LD_EVERY, lane);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.a[cur][j][i], b[cur][j], acc[i], 0, 0, 0);
-      }
-    }
-    if (more) {
-      xn += KP * 2 * XS;
-      wn += WPS * 256;
-      asm volatile("" : "+v"(xn), "+s"(wn));
-    }
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) asm volatile("" : "+v"(acc[i]) :: "memory");      // pin the set (see gemm_phase)
-  };
-  auto group = [&](bool last) {
-    one_set(std::integral_constant<int, 0>{}, true);       // set s = g*DEPTH fetches set s + DEPTH - 1: inside this group
-    if constexpr (DEPTH > 1) one_set(std::integral_constant<int, 1>{}, !last);
-    if constexpr (DEPTH > 2) one_set(std::integral_constant<int, 2>{}, !last);
-    if constexpr (DEPTH > 3) one_set(std::integral_constant<int, 3>{}, !last);
-    static_assert(DEPTH <= 4, "group body");
-  };
-#pragma nounroll
-  for (int g = 0; g < NG - 1; ++g) group(false);
-  group(true);
-}
-
-template <class K>
-__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[K::CBW], float* X, int rowblk0, int colblk, int lane) {
-  constexpr int XS = K::XS;
-  lptr_t xb = (lptr_t)(X + (rowblk0 * 32 + 4 * (lane >> 5)) * XS + colblk * 32 + (lane & 31));
-#pragma unroll
-  for (int i = 0; i < K::CBW; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xb[((r & 3) + 8 * (r >> 2)) * XS] = acc[i][r];     // acc_row(r, lane) without its lane term
-    xb += 32 * XS;
-    asm volatile("" : "+v"(xb));      // one base register per row block (see gemm_phase)
-  }
-}
-
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() drains vmcnt as well (it is a memory fence for global
-// memory too), i.e. every barrier would wait for the weight words and the next tile's x rows that are deliberately
-// kept in flight across it — measured as a 3-7 k cycle hole at the end of every tile.  All data exchanged between
-// the waves here lives in LDS, and a wave's LDS operations complete in order: lgkmcnt(0) + s_barrier is sufficient.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // this lane's 4 columns of a tile: clip, time (a multiple of 4; T % 4 == 0: the group is entirely inside or outside)
 struct Cols {          // (no padding bytes: the struct is copied, and hipcc keeps a copied struct's padding alive as private arrays
@@ -418,9 +30,9 @@ struct Cols {          // (no padding bytes: the struct is copied, and hipcc kee
 };
 static_assert(sizeof(Cols) == 32, "no padding");
 
-template <int C, bool STREAM, bool SCARRY = false, int NB = 1, bool W8 = false, int DRU = 0, bool POST = false>
-__global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::MINW)) void resblock_kernel(ResArgs a) {
-  using K = Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>;
+template <int C, bool STREAM, bool SCARRY = false, int NB = 1, bool W8 = false, int DRU = 0, bool POST = false, bool SPEC0 = false>
+__global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::NT), (Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::MINW)) void resblock_kernel(ResArgs a) {
+  using K = Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>;
   constexpr int DR = K::DR, UR = K::UR;
   using Pipe = WeightPipe<K>;
   constexpr int CBW = K::CBW, NW = K::NW, NT = K::NT, RW = K::RW, RB = K::RB, XS = K::XS, TO = K::TO, RSTEP = K::RSTEP;
@@ -439,6 +51,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
   // POST: the row classes' partial sums of the closing conv, [class][column]
   __shared__ __attribute__((aligned(16))) float PR[POST ? POST_CLASSES * K::NCOL : 4];
   static_assert(!POST || (K::RPI * K::NW == POST_CLASSES), "a row class of the closing conv = the rows one half-wave walks");
+  // SPEC0: the tile's waveform segment (127 + 64 samples) and the same scaled for the first conv
+  __shared__ __attribute__((aligned(16))) float SEG[SPEC0 ? 192 : 4];
+  __shared__ __attribute__((aligned(16))) float SEGS[SPEC0 ? 192 : 4];
   float* const X = Xbuf + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
@@ -644,7 +259,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
   }
   cs = columns_of(tile < run1 ? tile : 0);
   f32x4 xr[RW];
-  if (UR == 0 && tile < run1) {
+  if (UR == 0 && !SPEC0 && tile < run1) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) xr[i] = *xrow(cs, rsub + RSTEP * i);
   }
@@ -779,6 +394,96 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = up.bias != nullptr ? __fadd_rn(v[e], bv) : v[e];
           xr[i] = v;
+        }
+      }
+      lds_barrier();       // block 0's P0 overwrites X
+    }
+    if constexpr (SPEC0) {
+      // ---- S: x = conv_pre(wav) + out_scale * (W_pw * logspec(STFT_64(wav)) + bias) for the tile's 128 frames (hop 1: frame = sample).
+      //      hilc_spec_block_conv_pre's phases S0 / A / B / C / D on this kernel's tile (wave = 32-column block, both row blocks), same
+      //      fmaf chains and roundings: bit-identical; the result goes to the x registers instead of HBM.
+      const ResSpec0& sp = a.spec;
+      constexpr int N = 64, NBIN = 33, SROWS = 40, KP0 = 4, DEPTH0 = 2;
+      const int f0 = cs.t - c4;                              // the tile's first frame (offline: cs.t = f0 + c4 for every lane)
+      {
+        const int s0 = f0 - (N - 1);
+        const float* wb = sp.wav + cs.b * (long)T;
+        for (int i = tid; i < 127 + N; i += NT) {
+          const int t = s0 + i;
+          const float v = (t >= 0 && t < T) ? wb[t] : 0.f;
+          SEG[i] = v;
+          SEGS[i] = v * sp.pre_in_scale;                     // scaled once per sample, not once per use
+        }
+        for (int i = tid; i < (SROWS - NBIN) * 128; i += NT) X[(NBIN + (i >> 7)) * XS + (i & 127)] = 0.f;   // zero rows of the conv's padded K
+      }
+      lds_barrier();
+      const int kh = lane >> 5, col = colblk * 32 + (lane & 31);
+      f32x16 acc[CBW];
+      {
+        int off[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) off[p] = col + 2 * p + kh;
+        auto bop = [&](int P) -> float { return SEG[off[P & 7] + 16 * (P >> 3)]; };
+        stream_gemm<CBW, KP0, DEPTH0, N / 2 / KP0>(sp.dft, acc, lane, bop);
+      }
+      float nyq_im = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < N; ++k) nyq_im = fmaf(sp.nyq[k], SEG[col + k], nyq_im);
+      const SpecFinish finish = SpecFinish::make(sp.mean, sp.stdv, sp.normalize);
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int row = i * 32 + acc_row(r, lane);          // even
+          if (i == 0 && r == 0) {
+            if (kh == 0) {                                    // rows 0, 1: the two real bins
+              X[0 * XS + col] = finish(acc[0][0], 0.f);
+              X[(N / 2) * XS + col] = finish(acc[0][1], nyq_im);
+            } else {                                          // rows 4, 5: bin 2
+              X[(row >> 1) * XS + col] = finish(acc[0][0], acc[0][1]);
+            }
+          } else {
+            X[(row >> 1) * XS + col] = finish(acc[i][r], acc[i][r + 1]);
+          }
+        }
+      }
+      lds_barrier();
+      {
+        const float* sl = X + kh * XS + col;
+        auto bop = [&](int P) -> float { return sl[2 * P * XS]; };
+        stream_gemm<CBW, KP0, DEPTH0, SROWS / 2 / KP0>(sp.pw, acc, lane, bop);
+      }
+      lds_barrier();                                          // every wave is done reading the spectrogram rows
+      acc_to_x<K>(acc, X, rowblk0, colblk, lane);
+      lds_barrier();
+      {
+        lptr_t xp = (lptr_t)(X + rsub * XS + c4);
+        // column c of the tile is time f0 + c = segment sample c + N - 1: the first conv's taps read samples c + N - 5 .. c + N - 1
+        float sm[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm[j] = SEGS[c4 + j + N - 5];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const int m = rsub + RSTEP * i;
+          const float bv = sp.bias != nullptr ? sp.bias[m] : 0.f;
+          const float pb = sp.pre_b != nullptr ? sp.pre_b[m] : 0.f;
+          float w5[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) w5[j] = sp.pre_w[m * 5 + j];
+          f32x4 v = *(lvec_t)(xp + i * RSTEP * XS);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float acc5 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc5 = fmaf(w5[j], sm[e + j], acc5);
+            const float rr = sp.pre_b != nullptr ? __fadd_rn(acc5, pb) : acc5;
+            float t = v[e];
+            if (sp.bias != nullptr) t = __fadd_rn(t, bv);
+            t = __fmul_rn(t, sp.out_scale);
+            v[e] = __fadd_rn(t, rr);                          // separate roundings: y.mul_(scale); x.add_(y)
+          }
+          xr[i] = v;
+          if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // rows stay rows: hoisting every row's taps costs RW * 7 registers (spills)
         }
       }
       lds_barrier();       // block 0's P0 overwrites X
@@ -926,7 +631,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     have_next = next_tile < run1;
     if (last_blk) cn = columns_of(have_next ? next_tile : tile);
-    if constexpr (!STREAM && UR == 0) {      // (UR > 0: x is computed, not read — nothing to touch, and a.x has another shape)
+    if constexpr (!STREAM && UR == 0 && !SPEC0) {      // (UR > 0 / SPEC0: x is computed, not read — nothing to touch, and a.x has another shape)
       if (final_blk) {
       long nb;
       int nt0;
@@ -1011,7 +716,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
           }
         }
       }
-      if (UR == 0 && last_blk && have_next) {
+      if (UR == 0 && !SPEC0 && last_blk && have_next) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) xr[i0 + i] = *xrow(cn, rsub + RSTEP * (i0 + i));
       }
@@ -1101,7 +806,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
         }
       };
       d0();
-      if (!DWIDE && have_next) {                   // the x registers are free (no shortcut here): the next tile's rows travel under both GEMMs
+      if (!DWIDE && !SPEC0 && have_next) {         // the x registers are free (no shortcut here): the next tile's rows travel under both GEMMs
 #pragma unroll
         for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
       }
@@ -1315,163 +1020,6 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST>::NT), (C
   }
   if (touch == 1.2345678e-30f) a.y[0] = touch;   // keeps the touch loads alive; never true in practice
 #undef STAMP
-}
-
-// Offline carry form with several workgroups per CU: runs in proportion to the speeds of the dispatch classes (see resblock_kernel)
-inline void set_class_shares(ResArgs& a, long blocks, long resident, int n_cu) {
-  a.classes = 0;
-  if (n_cu > 0 && blocks == resident && resident % n_cu == 0 && resident / n_cu >= 2 && resident / n_cu <= 4 &&
-      a.total_tiles >= 8 * resident) {
-    const int cls = (int)(resident / n_cu);
-    // shares of the dispatch classes (first-dispatched first), measured: see tools/res_wg_times.py and profiles/r03_experiments.md
-    double share[4] = {0, 0, 0, 0};
-    if (cls == 2) { share[0] = HILC_RES_SHARE2_0; share[1] = 1.0 - share[0]; }
-    else if (cls == 3) { share[0] = HILC_RES_SHARE3_0; share[1] = HILC_RES_SHARE3_1; share[2] = 1.0 - share[0] - share[1]; }
-    else { for (int i = 0; i < cls; ++i) share[i] = 1.0 / cls; }
-#ifdef HILC_RES_SHARE_ENV      // tuning builds only
-    if (cls == 2) { if (const char* e = getenv("HILC_SHARE2_0")) { share[0] = atof(e); share[1] = 1.0 - share[0]; } }
-    if (cls == 3) {
-      if (const char* e = getenv("HILC_SHARE3_0")) share[0] = atof(e);
-      if (const char* e = getenv("HILC_SHARE3_1")) share[1] = atof(e);
-      share[2] = 1.0 - share[0] - share[1];
-    }
-#endif
-    double acc = 0;
-    a.cum[0] = 0;
-    for (int i = 0; i < cls; ++i) { acc += share[i]; a.cum[i + 1] = (unsigned)(acc * 65536.0 + 0.5); }
-    a.cum[cls] = 65536u;
-    a.classes = cls;
-  }
-}
-
-// number of workgroups of this instantiation that can be resident on the device (CUs x occupancy), cached per device
-template <class KernelT>
-int resident_workgroups(KernelT kernel, int threads, std::atomic<int>* cache, int& n_cu_out) {
-  constexpr int MAXDEV = 64;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  int n_cu = 0;
-  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) return -1;
-  n_cu_out = n_cu;
-  int cached = dev >= 0 && dev < MAXDEV ? cache[dev].load(std::memory_order_relaxed) : 0;
-  if (cached == 0) {
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0) != hipSuccess || occ < 1) return -1;
-    cached = n_cu * occ;
-    if (dev >= 0 && dev < MAXDEV) cache[dev].store(cached, std::memory_order_relaxed);
-  }
-  return cached;
-}
-
-inline void set_div_magic(ResArgs& a) {
-  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
-  int l = 0;
-  while ((1L << l) < a.T) ++l;
-  if (l < 1) l = 1;
-  const unsigned long long p = 1ULL << (31 + l);
-  a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
-  a.div_shift = (unsigned)(l - 1);
-}
-
-// A CHAIN launch: a.nblk blocks of one stage, one launch.  Offline: the carry form's contiguous runs (equal split).  STREAM,
-// C <= 192: runs of whole streams on the flat column space — the shortest run is `unit` tiles = the fewest whole streams that
-// fill whole tiles; runs are made of as many units as it takes for all runs to be resident at once (1024 streams x 320 samples,
-// 256 workgroups: 4 streams = 10 tiles each), the last run may be short.  STREAM NARROW (C >= 512): whole-stream tiles, static
-// stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
-template <int C, bool STREAM, int NB, bool W8, int DR = 0, bool POST = false>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR); POST: + closing conv
-int launch_chain(ResArgs a, int B, hipStream_t s) {
-  constexpr bool SC = STREAM && C <= 192;         // runs of whole streams with carries (C = 384: flat tiles with a halo; C >= 512: whole-stream tiles, static stride)
-  using K = Cfg<C, STREAM, SC, NB, W8, DR, POST>;
-  a.B = B;
-  set_div_magic(a);
-  constexpr int TO = K::TO;
-  a.tiles = (a.T + TO - 1) / TO;
-  a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
-  a.classes = 0;
-  a.run_tiles = 0;
-  static std::atomic<int> resident_cache[64];
-  int n_cu = 0;
-  const long resident = resident_workgroups(resblock_kernel<C, STREAM, SC, NB, W8, DR, POST>, K::NT, resident_cache, n_cu);
-  if (resident < 1) return HILC_ERR_LAUNCH;
-  long blocks;
-  if constexpr (SC) {
-    long g = a.T, h = K::NCOL;
-    while (h != 0) { const long t = g % h; g = h; h = t; }                      // gcd(T, NCOL)
-    const long unit = (long)a.T / g;                                              // tiles of the shortest run of whole streams
-    const long units = (a.total_tiles + unit - 1) / unit;
-    const long k = (units + resident - 1) / resident;                            // units per run
-    a.run_tiles = k * unit;
-    blocks = (a.total_tiles + a.run_tiles - 1) / a.run_tiles;
-  } else {
-    blocks = a.total_tiles < resident ? a.total_tiles : resident;
-    if constexpr (!STREAM) set_class_shares(a, blocks, resident, n_cu);
-  }
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, SC, NB, W8, DR, POST>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
-
-template <int C, bool STREAM, bool SCARRY = false>
-int launch_res(ResArgs a, int B, hipStream_t s, long carry_grid = 0) {
-  a.nblk = 1;
-  a.run_tiles = 0;
-  a.B = B;
-  {  // division by the invariant T (Granlund-Montgomery, 31-bit dividends): l = ceil(log2 T), m = ceil(2^(31+l) / T)
-    int l = 0;
-    while ((1L << l) < a.T) ++l;
-    if (l < 1) l = 1;
-    const unsigned long long p = 1ULL << (31 + l);
-    a.div_magic = (unsigned)((p + (unsigned long long)a.T - 1) / (unsigned long long)a.T);
-    a.div_shift = (unsigned)(l - 1);
-  }
-  using K = Cfg<C, STREAM, SCARRY>;
-  constexpr int TO = K::TO;
-  a.tiles = (a.T + TO - 1) / TO;
-  a.total_tiles = STREAM ? ((long)B * a.T + TO - 1) / TO : (long)B * a.tiles;
-  // persistent grid = exactly what can be resident (a surplus workgroup would only start after a resident one has
-  // walked its whole tile list).  Immutable per-device facts, looked up once per device (a process may drive several GPUs).
-  constexpr int MAXDEV = 64;
-  static std::atomic<int> resident_cache[MAXDEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return HILC_ERR_LAUNCH;
-  int cached = dev >= 0 && dev < MAXDEV ? resident_cache[dev].load(std::memory_order_relaxed) : 0;
-  if (cached == 0) {
-    int n_cu = 0, occ = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
-      return HILC_ERR_LAUNCH;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resblock_kernel<C, STREAM, SCARRY>, K::NT, 0) != hipSuccess || occ < 1)
-      return HILC_ERR_LAUNCH;
-    cached = n_cu * occ;
-    if (dev >= 0 && dev < MAXDEV) resident_cache[dev].store(cached, std::memory_order_relaxed);
-  }
-  const long resident = cached;
-  if constexpr (STREAM && !SCARRY && (C == 96 || C == 192)) {
-    // The carry form for this hop?  Only where every run is the same whole number of streams (so that no run starts inside a
-    // stream and pays a warm-up tile) and the runs are fewer tile-times than the rounds of the halo form.
-    constexpr int NC = K::NCOL;
-    long g = a.T, h = NC;
-    while (h != 0) { const long t = g % h; g = h; h = t; }                      // gcd(T, NCOL)
-    const long unit = (long)a.T / g;                                              // tiles of the shortest aligned run
-    const long cols = (long)B * a.T;
-    if (cols % (unit * NC) == 0) {
-      const long units = cols / (unit * NC);
-      const long k = (units + resident - 1) / resident;                          // aligned runs per workgroup (same residency: 8 KB of LDS more)
-      const long halo_rounds = (a.total_tiles + resident - 1) / resident;
-      if (units % k == 0 && k * unit < halo_rounds) return launch_res<C, STREAM, true>(a, B, s, units / k);
-    }
-  }
-  long blocks = a.total_tiles < resident ? a.total_tiles : resident;
-  if (SCARRY && carry_grid > 0 && carry_grid <= resident) blocks = carry_grid;
-  a.classes = 0;
-  if constexpr (!STREAM) {
-    int n_cu = 0;
-    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) set_class_shares(a, blocks, resident, n_cu);
-  }
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL((resblock_kernel<C, STREAM, SCARRY>), dim3((unsigned)blocks), dim3(K::NT), 0, s, a);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
 }
 
 }  // namespace

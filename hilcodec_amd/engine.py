@@ -467,7 +467,21 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
     fuse_pre = (FUSE_SPECBLOCK and sb0.fused is not None and sb0.n_fft == 64 and sb0.hop == 1
                 and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2])
                 and (wav_hist is None or wav_hist.shape[-1] >= 63))
-    if fuse_pre:
+    st0 = es.stages[0]
+    fuse_stage0 = (fuse_pre and not streaming and FUSE_RESBLOCK and opts.stage_launches and st0.down_lo is not None and st0.down_dw_b is not None
+                   and st0.down_dw_w.shape[1] == 2 * st0.ratio and wav.shape[2] % st0.ratio == 0
+                   and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+                           and rb.dw2_b is not None for rb in st0.blocks)
+                   and ops.encoder_stage0_supported(wav.shape[2], len(st0.blocks), st0.ratio, 64, 1, es.pre_w.shape[1]))
+    if fuse_stage0:
+        # first conv + first SpecBlock + the whole first stage in one launch: neither the [64 x T] tensor in front of the stage nor the one
+        # behind its blocks ever exists
+        x = ops.encoder_stage0(
+            wav, (sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b, es.pre_in_scale, sb0.mean, sb0.std, sb0.normalize,
+                  sb0.out_scale),
+            [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st0.blocks],
+            (st0.down_lo, st0.down_hi, st0.down_dw_w, st0.down_dw_b, st0.down_in_scale, st0.ratio))
+    elif fuse_pre:
         # first conv + first SpecBlock in one launch: the [64 x T] tensor between them never exists
         x = ops.spec_block_conv_pre(wav, sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b,
                                     es.pre_in_scale, 64, 1, sb0.mean, sb0.std, sb0.normalize, sb0.out_scale, hist=wav_hist)
@@ -479,6 +493,8 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
     # (`res`): one launch and one read + write of x less per stage on the critical path, the same two roundings in the same
     # order (`fadd(down, branch)`), bit-identical to the in-line form.
     later = [st.spec for st in es.stages[1:]] + [es.spec_post]
+    # (offline the same deferral was measured in round 5: 73.8 -> 75.2 ms per step, same box — the branch-only launches write what the
+    #  in-line ones read-modify-write, and the stage launches gain a `res` read: kept in-line)
     defer = streaming and FUSE_STREAM and opts.stream_defer_spec
     side = None if torch.compiler.is_compiling() else _SIDE_STREAM.get()          # (a tracing compiler cannot read a ContextVar; it never forks streams)
     early = _early_branches(later, wav, wav_hist, side) if defer else None
@@ -491,6 +507,9 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         return _spec_branch(sb, wav, wav_hist)
 
     for si, st in enumerate(es.stages):
+        if fuse_stage0 and si == 0:
+            ci += 2 * len(st.blocks) + 1
+            continue
         if not (fuse_pre and si == 0) and not (defer and si > 0):
             x = _spec_block(st.spec, x, wav, wav_hist)
         nxt = later[si] if defer else None

@@ -389,6 +389,41 @@ _register("decoder_stage", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, 
           xin.new_empty(xin.shape[0], xin.shape[1] // 2, xin.shape[2] * stride))
 
 
+def _encoder_stage0(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, pre_scales,
+                    out_scales, w_lo, w_hi, ddw_w, ddw_b, dres, in_scale, stride):
+    import ctypes
+    from ._lib import DownParams, ResblockParams, Spec0Params
+    B, one, T = wav.shape
+    Cc, k = pre_w.shape
+    n = len(pre_scales)
+    if one != 1 or Cc != 64 or len(params) != 6 * n or len(out_scales) != n or T % stride != 0:
+        raise RuntimeError("encoder_stage0: wav [B,1,T], a 64-channel first conv, 6 parameter tensors per block, T a multiple of the stride")
+    blocks = (ResblockParams * n)()
+    for i in range(n):
+        w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), None, None, None, None,
+                                   float(pre_scales[i]), float(out_scales[i]))
+    To = T // stride
+    if dres is not None and tuple(dres.shape) != (B, 2 * Cc, To):
+        raise RuntimeError(f"encoder_stage0: res must be {(B, 2 * Cc, To)}, got {tuple(dres.shape)}")
+    y = torch.empty(B, 2 * Cc, To, device=wav.device, dtype=torch.float32)
+    spec = Spec0Params(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(pre_w), _ptr(pre_b),
+                       float(pre_in_scale), float(mean), float(std), float(out_scale), int(normalize), 64, 1, int(k))
+    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), None, None, _ptr(dres), _ptr(y), float(in_scale), int(stride))
+    work = 2.0 * B * T * 64 * (64 + 1 + 32 + 1) + 2.0 * B * T * Cc * k + 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc
+    with _timed("resblock", work, f"C{Cc} T{T} conv_pre + spec N64 + stage x{n} + down s{stride}"):
+        check(lib.hilc_encoder_stage0(ctypes.cast(ctypes.pointer(spec), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n,
+                                      ctypes.cast(ctypes.pointer(down), ctypes.c_void_p), B, T, _stream()), "hilc_encoder_stage0")
+    return y
+
+
+_register("encoder_stage0", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor pre_w, Tensor? pre_b, "
+          "float pre_in_scale, float mean, float std, int normalize, float out_scale, Tensor[] params, float[] pre_scales, float[] out_scales, "
+          "Tensor w_lo, Tensor w_hi, Tensor ddw_w, Tensor ddw_b, Tensor? dres, float in_scale, int stride) -> Tensor", _encoder_stage0,
+          lambda wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, pre_scales,
+          out_scales, w_lo, w_hi, ddw_w, ddw_b, dres, in_scale, stride: wav.new_empty(wav.shape[0], 2 * pre_w.shape[0], wav.shape[2] // stride))
+
+
 def _decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, in_scale, stride, params, pre_scales, out_scales, post_w, post_b, post_in_scale,
                         post_out_scale, do_tanh):
     import ctypes
@@ -868,6 +903,27 @@ def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: O
     uout = _state_out(up_hist_out, xin, B, K2, 1)
     y = _OPS.decoder_stage(xin, tr_w, w_lo, w_hi, bias, up_hist, uout, float(in_scale), int(stride), params, hin, hout, pre, post)
     return y, hout, uout
+
+
+def encoder_stage0_supported(T: int, nblk: int, stride: int, n_fft: int, hop: int, pre_ksize: int) -> bool:
+    """mirror of hilc_encoder_stage0_supported: the offline encoder's FIRST stage with the first conv and its SpecBlock in the same launch"""
+    return 1 <= nblk <= 2 and stride == 2 and n_fft == 64 and hop == 1 and pre_ksize == 5 and T > 0 and T % 4 == 0
+
+
+def encoder_stage0(wav: Tensor, spec: Sequence, blocks: Sequence[Sequence], down: Sequence, res: Optional[Tensor] = None) -> Tensor:
+    """The offline encoder's first conv, stage-0 SpecBlock, residual blocks and down-sampling layer in ONE launch (hilc_encoder_stage0):
+    `spec` = (dft_packed, nyq_sin, pw_packed, bias, pre_w `[64,5]`, pre_b, pre_in_scale, mean, std, normalize, out_scale) as given to
+    `spec_block_conv_pre`; `blocks`, `down`, `res` as in `encoder_stage` (offline).  wav `[B,1,T]` -> `[B,128,T/2]`, equal bit for bit to
+    `encoder_stage(spec_block_conv_pre(wav, ...), blocks, down)`."""
+    dft, nyq, pw, bias, pre_w, pre_b, pre_in, mean, std, normalize, out_scale = spec
+    w_lo, w_hi, ddw_w, ddw_b, in_scale, stride = down
+    params, pre, post = [], [], []
+    for blk in blocks:
+        params.extend(blk[:6])
+        pre.append(float(blk[6]))
+        post.append(float(blk[7]))
+    return _OPS.encoder_stage0(wav, dft, nyq, pw, bias, pre_w, pre_b, float(pre_in), float(mean), float(std), int(normalize), float(out_scale),
+                               params, pre, post, w_lo, w_hi, ddw_w, ddw_b, res, float(in_scale), int(stride))
 
 
 def decoder_stage_post_supported(C: int, T: int, nblk: int, stride: int, ksize: int) -> bool:

@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 14   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post */
+#define HILC_ABI_VERSION 14   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post, hilc_encoder_stage0 */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -227,6 +227,23 @@ typedef struct hilc_down_params {
 int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming);
 int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down, int streaming,
                        int B, int C, int T, void* stream);
+
+/* ---- the encoder's FIRST stage with its input computed in the launch (ABI 14, offline) ----------------------------------------
+ * `seanet.py:280-286` (first conv k = 5, 1 -> 64), `:220-246` (stage 0's SpecBlock: STFT n_fft 64 hop 1 -> log-magnitude -> 1x1 conv),
+ * `:316-339` (the stage's residual blocks and down-sampling layer): hilc_spec_block_conv_pre's arithmetic as the opening phase of the
+ * hilc_encoder_stage launch for C = 64, r = 2 — equal to the two launches bit for bit; the `[B][64][T]` tensor between them never
+ * reaches HBM.  `spec`: the arguments of hilc_spec_block_conv_pre (packed tables from hilc_spec_block_pack); `down->hist` is ignored. */
+typedef struct hilc_spec0_params {
+  const float* wav;         /* [B][T] */
+  const float* dft_packed; const float* nyq_sin; const float* pw_packed; const float* bias;
+  const float* pre_w;       /* [64][5] */
+  const float* pre_b;       /* [64] or NULL */
+  float pre_in_scale, mean, std, out_scale;
+  int normalize, n_fft, hop, pre_ksize;
+} hilc_spec0_params;
+int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize);
+int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
+                        int B, int T, void* stream);
 
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)

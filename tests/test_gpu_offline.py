@@ -178,8 +178,8 @@ def test_offline_launch_structure_options_change_no_bit():
     # without the wide blocks' fused form (round 3 + the narrow stages of round 4) — fused-kernel launches: 4 stages / 2 * 2 + 2 * 3 blocks
     assert (d[3], f[3]) == (4, 10), (d[3:], f[3:])
     # with them: encoder 4 stages, decoder C = 768: (up-sampling layer +) first block, two blocks; C = 384 / 192 / 96: one launch each;
-    # block by block: 4 * 2 + 4 * 3, eight down- / up-sampling launches and the closing conv (a phase of the last stage by default) more; every wide block is one launch less than two
-    assert (a[3], c[3]) == (10, 20) and c[4] - a[4] == 19 and f[4] - c[4] == 10, (a[3:], c[3:], f[3:])
+    # block by block: 4 * 2 + 4 * 3, eight down- / up-sampling launches, the first conv + SpecBlock and the closing conv (phases of the first / last stage by default) more; every wide block is one launch less than two
+    assert (a[3], c[3]) == (10, 20) and c[4] - a[4] == 20 and f[4] - c[4] == 10, (a[3:], c[3:], f[3:])
     # the decoder's narrow / partial stage forms off: C = 768, 192 and 96 get their up-sampling launch back and the closing conv its own (C = 384 keeps its whole-stage launch)
     assert g[3] == 10 and g[4] - a[4] == 4, (a[3:], g[3:])
     for other in (c, d, f, g):

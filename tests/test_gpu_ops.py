@@ -753,6 +753,36 @@ def test_decoder_stage_post_equals_stage_then_conv_post_and_oracle(env, Tin, B):
         close(wav, ref, 2e-5, f"decoder stage + conv_post Tin{Tin} B{B}")
 
 
+@pytest.mark.parametrize("T,B,n", [(24000, 3, 2), (1000, 5, 2), (124, 40, 2), (8, 300, 1), (9280, 24, 2)])
+def test_encoder_stage0_equals_conv_pre_spec_then_stage(env, T, B, n):
+    """hilc_encoder_stage0: the offline encoder's first conv and stage-0 SpecBlock (`seanet.py:280-286, 220-246`) as the opening phase of the
+    C = 64 stage launch == hilc_spec_block_conv_pre followed by hilc_encoder_stage, bit for bit — clips shorter than a tile, ragged
+    batches, runs that start inside a clip (warm-up tiles), with and without the biases and a shortcut behind the down-sampling layer."""
+    ops, fold, O, dev = env
+    C, r, n_fft = 64, 2, 64
+    assert ops.encoder_stage0_supported(T, n, r, 64, 1, 5) and not ops.encoder_stage0_supported(T, n, 4, 64, 1, 5)
+    basis = synth.stft_basis(n_fft)
+    bt = fold.stft_basis_layout(basis).to(dev)
+    w = rnd(n_fft + 1, C, n_fft // 2 + 1, 1) / (n_fft // 2 + 1) ** 0.5
+    wt = fold.pointwise_layout(w).to(dev)
+    bias = (rnd(n_fft + 2, C) * 0.1).to(dev)
+    dft_p, nyq, pw_p = ops.spec_block_tables(bt, wt, n_fft)
+    pre_w, pre_b = (rnd(71, 64, 5) * 0.5).to(dev), (rnd(72, 64) * 0.1).to(dev)
+    sds, raw = _oracle_blocks(O, C, n)
+    blocks = _chain_params(ops, raw, dev)
+    wd = (rnd(70, C, 2 * C) / C ** 0.5).to(dev)                 # k-major [C, 2C]
+    down = (ops.resblock_chain_pack(wd[:, :C].contiguous(), False), ops.resblock_chain_pack(wd[:, C:].contiguous(), False),
+            (rnd(73, 2 * C, 2 * r) * 0.3).to(dev), (rnd(74, 2 * C) * 0.1).to(dev), (1 + n * RS ** 2) ** -0.5, r)
+    wav = synth.synth_clips(B, T, seed=T + B).to(dev)
+    res = (rnd(75, B, 2 * C, T // r) * 0.5).to(dev)
+    for sb, pb, rs in ((bias, pre_b, None), (None, None, res), (bias, None, res)):
+        spec = (dft_p, nyq, pw_p, sb, pre_w, pb, 1 / 0.1122080159, -4.0, 2.8, True, 0.37)
+        y = ops.encoder_stage0(wav, spec, blocks, down, res=rs)
+        x0 = ops.spec_block_conv_pre(wav, dft_p, nyq, pw_p, sb, pre_w, pb, 1 / 0.1122080159, n_fft, 1, -4.0, 2.8, True, 0.37)
+        y2 = ops.encoder_stage(x0, blocks, down, res=rs)
+        assert y.shape == (B, 2 * C, T // r) and torch.equal(y, y2), float((y - y2).abs().max())
+
+
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
