@@ -62,7 +62,7 @@ constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1
 // run shares of the dispatch classes of the offline carry form (two / three workgroups per CU)
 // (tools/share_sweep2.sh on the -DHILC_RES_SHARE_ENV build: two classes 0.50 -> 2.47 / 2.02 ms at C = 96 / 128, 0.62-0.65 -> 2.40 /
 // 1.93, 0.71 -> 2.44 / 1.99; three classes (C = 64) 1/3 each -> 1.49 ms, 0.44 / 0.31 / 0.25 -> 1.46)
-// (round 4, stage launches on the no-longer-power-limited chip, tools/share_sweep_chain.sh: C = 96 stage 0.50 -> 9.16 ms, 0.56 -> 8.89, 0.60 - 0.62 -> 8.70,
+// (round 4, stage launches, a box holding 2.39 GHz at 1.2 kW, tools/share_sweep_chain.sh: C = 96 stage 0.50 -> 9.16 ms, 0.56 -> 8.89, 0.60 - 0.62 -> 8.70,
 // 0.64 -> 8.84, 0.68 -> 9.10, 0.72 -> 9.43; C = 64 stage 3.44 / 3.39 / 3.30 / 3.38 / 3.42 / 3.54)
 #ifndef HILC_RES_SHARE2_0
 #define HILC_RES_SHARE2_0 0.61
@@ -146,7 +146,7 @@ struct Cfg {
   static constexpr int KP = HILC_RES_KP;
   static constexpr int DEPTH = HILC_RES_DEPTH;
 #else
-  // (round 4, on a chip that is no longer power-limited — tools/build_variants.py + variant_table.sh, one box: KP = 4 / DEPTH = 2 instead of 4 / 4
+  // (round 4, a box holding 2.39 GHz at 1.2 kW — tools/build_variants.py + variant_table.sh, one box: KP = 4 / DEPTH = 2 instead of 4 / 4
   //  at C = 192: 14.84 -> 14.64 ms per offline stage, instead of 8 / 2 at C = 96: 9.00 -> 8.89; the wide shapes lose with it: C = 768 5.30 -> 5.39)
   static constexpr int KP = C >= 96 ? 4 : 8;
   static constexpr int DEPTH = C >= 256 ? 4 : (C == 128 ? (STREAM ? 2 : 3) : 2);   // (STREAM, C = 128: the cache handling needs the third set's 20 registers)
