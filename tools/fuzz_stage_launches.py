@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Random-shape check of the round-4 launches of the OFFLINE model against the launches they replace (bit for bit): wide one-launch blocks vs
-two hilc_dws_conv, chains vs block by block, encoder stages vs blocks + down-sampling layer, decoder stages vs up-sampling layer + blocks.
+"""Random-shape check of the round-4 / round-5 launches of the OFFLINE model against the launches they replace (bit for bit): wide one-launch blocks vs
+two hilc_dws_conv, chains vs block by block, encoder stages vs blocks + down-sampling layer, decoder stages vs up-sampling layer + blocks, the last
+decoder stage with the closing conv vs stage + hilc_conv_post, the first encoder stage with its input phase vs hilc_spec_block_conv_pre + stage.
 Shapes: random clip counts and lengths around the tile widths (32 / 64 / 128 columns), clips shorter than a tile, single clips.
    python tools/fuzz_stage_launches.py [cases] [seed]"""
 import os, random, sys
@@ -32,7 +33,7 @@ def pick_T(mult):
 
 bad = 0
 for case in range(N):
-    kind = rng.choice(["wide", "chain", "enc", "dec"])
+    kind = rng.choice(["wide", "chain", "enc", "dec", "post", "spec0"])
     try:
         if kind == "wide":
             C = rng.choice([256, 384, 512, 768]); T = pick_T(4); B = rng.choice([1, 2, 3, 7, 40])
@@ -66,6 +67,41 @@ for case in range(N):
             ref = ops.dws_conv(ref, wd, dw, db, stride=r, in_scale=0.7746, in_elu=True)
             if res is not None:
                 ref = ref + res
+        elif kind == "post":
+            C, r, n = 96, 2, 3
+            Tin = max(2, pick_T(4) // r); B = rng.choice([1, 2, 5, 33, 300])
+            if (Tin * r) % 4:
+                Tin *= 2
+            T = Tin * r
+            bls = [block(C, j) for j in range(n)]
+            tw, wu, bu = rnd(2 * C, 2 * r) * 0.3, rnd(2 * C, C) / (2 * C) ** 0.5, rnd(C) * 0.1
+            up = (tw, ops.resblock_chain_pack(wu[:C].contiguous(), False), ops.resblock_chain_pack(wu[C:].contiguous(), False), bu, 0.7071, r)
+            pw, pb = rnd(C, 5) * 0.2, (rnd(1) * 0.1 if rng.random() < 0.7 else None)
+            tanh = rng.random() < 0.7
+            xin = rnd(B, 2 * C, Tin)
+            assert ops.decoder_stage_post_supported(C, T, n, r, 5)
+            y = ops.decoder_stage_post(xin, up, [b["chain"] for b in bls], (pw, pb, 0.5, 0.1122, tanh))
+            ref = ops.conv_post(ops.decoder_stage(xin, up, [b["chain"] for b in bls]), pw, pb, in_scale=0.5, in_elu=True, out_scale=0.1122, do_tanh=tanh)
+        elif kind == "spec0":
+            from hilcodec_amd import fold, synth
+            C, r = 64, 2; n = rng.choice([1, 2])
+            T = pick_T(4); B = rng.choice([1, 2, 5, 33, 300])
+            bls = [block(C, j) for j in range(n)]
+            bt = fold.stft_basis_layout(synth.stft_basis(64)).to(dev)
+            wt = rnd(33, 64) / 33 ** 0.5
+            dft_p, nyq, pw_p = ops.spec_block_tables(bt, wt.contiguous(), 64)
+            sb = rnd(64) * 0.1 if rng.random() < 0.7 else None
+            pre_w, pre_b = rnd(64, 5) * 0.5, (rnd(64) * 0.1 if rng.random() < 0.7 else None)
+            wd, dw, db = rnd(C, 2 * C) / C ** 0.5, rnd(2 * C, 2 * r) * 0.4, rnd(2 * C) * 0.2
+            down = (ops.resblock_chain_pack(wd[:, :C].contiguous(), False), ops.resblock_chain_pack(wd[:, C:].contiguous(), False), dw, db, 0.7746, r)
+            res = rnd(B, 2 * C, T // r) if rng.random() < 0.5 else None
+            wav = rnd(B, 1, T) * 0.1
+            norm = rng.choice([0, 1])
+            spec = (dft_p, nyq, pw_p, sb, pre_w, pre_b, 8.9, -4.0, 2.8, norm, 0.37)
+            assert ops.encoder_stage0_supported(T, n, r, 64, 1, 5)
+            y = ops.encoder_stage0(wav, spec, [b["chain"] for b in bls], down, res=res)
+            x0 = ops.spec_block_conv_pre(wav, dft_p, nyq, pw_p, sb, pre_w, pre_b, 8.9, 64, 1, -4.0, 2.8, norm, 0.37)
+            ref = ops.encoder_stage(x0, [b["chain"] for b in bls], down, res=res)
         else:
             C, r, nmax = rng.choice([(96, 2, 3), (192, 4, 3), (384, 5, 3), (768, 8, 1)]); n = rng.randint(1, nmax)
             Tin = max(1, pick_T(4) // r); B = rng.choice([1, 2, 5, 33])
