@@ -95,28 +95,88 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         const float* src = j < 5 ? bq.dw1_w + (m * 5 + j) : (j == 5 ? bq.dw1_b + m : (j < 11 ? bq.dw2_w + (m * 5 + (j - 6)) : bq.dw2_b + m));
         dst[e] = *src;
       }
-    } else {
-      // (once per workgroup, in front of the tile loop — but a hop is 5 - 10 tiles per workgroup: the branchy form's 5 - 14 serial rounds of
-      //  four exec-mask regions were a visible part of a streaming stage launch)
-      constexpr int NE = C * DWS;
-#pragma unroll 4
-      for (int i = 0; i < (NE + NT - 1) / NT; ++i) {
-        const int e = tid + i * NT;
-        const int ec = (NE % NT == 0 || e < NE) ? e : NE - 1;
-        const int m = ec / DWS, j = ec - m * DWS;
-        const float* src = j < 5 ? bq.dw1_w + (m * 5 + j) : (j == 5 ? bq.dw1_b + m : (j < 11 ? bq.dw2_w + (m * 5 + (j - 6)) : bq.dw2_b + m));
-        const float v = *src;
-        if (NE % NT == 0 || e < NE) dst[ec] = v;
-      }
     }
   };
   if constexpr (!DW_RELOAD) {
-    for (int q = 0; q < nblk; ++q) load_taps(a.blk[q], DW + q * C * DWS);
+    // All blocks' tables, ONE row per thread and round: a row's 12 words are 12 independent loads and every block's are requested before the
+    // first LDS store — one global round trip per launch (two where C > NT) instead of two per block (an element per thread and round:
+    // a hop is 5 - 10 tiles per workgroup, and the prologue's round trips were a visible part of a streaming stage launch).
+    constexpr int RND = (C + NT - 1) / NT;
+    if constexpr (NB == 1 && STREAM) {
+      // (the one-block streaming shapes sit at their register limit — C = 128: 24 bytes of scratch with twelve more words live here: a row as
+      //  three groups of four words, three round trips; these launches only run with ExecOptions.stage_launches off)
+      const ResBlk& bq = a.blk[0];
+#pragma unroll
+      for (int it = 0; it < RND; ++it) {
+        const int m = tid + it * NT;
+        const int mc = (C % NT == 0 || m < C) ? m : C - 1;
+#pragma unroll
+        for (int w4 = 0; w4 < DWS / 4; ++w4) {
+          float t4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = 4 * w4 + e;
+            t4[e] = j < 5 ? bq.dw1_w[mc * 5 + j] : (j == 5 ? bq.dw1_b[mc] : (j < 11 ? bq.dw2_w[mc * 5 + (j - 6)] : bq.dw2_b[mc]));
+          }
+          if (C % NT == 0 || m < C) *reinterpret_cast<f32x4*>(&DW[m * DWS + 4 * w4]) = f32x4{t4[0], t4[1], t4[2], t4[3]};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+    float tv[NB][RND][DWS];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      if (q < nblk) {
+        const ResBlk& bq = a.blk[q];
+#pragma unroll
+        for (int it = 0; it < RND; ++it) {
+          const int m = tid + it * NT;
+          const int mc = (C % NT == 0 || m < C) ? m : C - 1;
+#pragma unroll
+          for (int j = 0; j < 5; ++j) tv[q][it][j] = bq.dw1_w[mc * 5 + j];
+          tv[q][it][5] = bq.dw1_b[mc];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) tv[q][it][6 + j] = bq.dw2_w[mc * 5 + j];
+          tv[q][it][11] = bq.dw2_b[mc];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      if (q < nblk) {
+#pragma unroll
+        for (int it = 0; it < RND; ++it) {
+          const int m = tid + it * NT;
+          if (C % NT == 0 || m < C) {
+#pragma unroll
+            for (int w4 = 0; w4 < DWS / 4; ++w4)
+              *reinterpret_cast<f32x4*>(&DW[(q * C + m) * DWS + 4 * w4]) =
+                  f32x4{tv[q][it][4 * w4], tv[q][it][4 * w4 + 1], tv[q][it][4 * w4 + 2], tv[q][it][4 * w4 + 3]};
+          }
+        }
+      }
+    }
+    }
   }
   if constexpr (DR > 0 && !DWIDE) {
-    for (int e = tid; e < 2 * C * DDS; e += NT) {
-      const int m = e / DDS, j = e - m * DDS;
-      DWD[e] = j < 2 * DR ? a.dn.dw_w[m * 2 * DR + j] : (j == 8 ? a.dn.dw_b[m] : 0.f);
+    // the down-sampling layer's table the same way: one row (2r taps + bias) per thread, every load in flight before the first store
+    constexpr int RND = (2 * C + NT - 1) / NT;
+    float tw[RND][2 * DR + 1];
+#pragma unroll
+    for (int it = 0; it < RND; ++it) {
+      const int m = tid + it * NT;
+      const int mc = ((2 * C) % NT == 0 || m < 2 * C) ? m : 2 * C - 1;
+#pragma unroll
+      for (int j = 0; j < 2 * DR; ++j) tw[it][j] = a.dn.dw_w[mc * 2 * DR + j];
+      tw[it][2 * DR] = a.dn.dw_b[mc];
+    }
+#pragma unroll
+    for (int it = 0; it < RND; ++it) {
+      const int m = tid + it * NT;
+      if ((2 * C) % NT == 0 || m < 2 * C) {
+#pragma unroll
+        for (int j = 0; j < DDS; ++j) DWD[m * DDS + j] = j < 2 * DR ? tw[it][j] : (j == 8 ? tw[it][2 * DR] : 0.f);
+      }
     }
   }
   if (tid < 4) Xbuf[tid] = 0.f;
