@@ -461,7 +461,7 @@ def main():
             flops = sum(tot[k][1] for k in kinds)
             secs = sum(tot[k][2] for k in kinds)
             roof.update({
-                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_lin_wr_kernel<BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM,..,NB,W8,DRU> (residual blocks / whole stages: chain, + down- or up-sampling phase) + spec_block_kernel<N> ("
+                "kernel": "hilc::gemm_lin_kernel<MB,BOp,Epilogue> / gemm_lin_wr_kernel<BOp,Epilogue> / gemm_kernel<MB,Loader,Epilogue> + resblock_kernel<C,STREAM,..,NB,W8,DRU,POST,SPEC0> (residual blocks / whole stages: chain, + down- or up-sampling phase, + the closing conv behind the last decoder stage, + first conv and SpecBlock in front of the first encoder stage) + spec_block_kernel<N> ("
                           + "+".join(kinds) + "; fp32 v_mfma_f32_32x32x2_f32)",
                 "achieved": flops / secs / 1e12, "frac": flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "launches_per_step": launches // args.steps, "avg_launch_us": secs / launches * 1e6,
