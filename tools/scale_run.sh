@@ -33,7 +33,9 @@ for LEG in ${LEGS:-offline streaming}; do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["ranks"]
-print(f"N={d['n_gpus']}: {d['value']:.0f} xRT  {d['ms_per_step']:.3f} ms/step  skew {r['wall_skew_s'] * 1e3:.2f} ms  rccl_ranks {r['rccl_ranks']}  {d['config']['workload']}")
+sus = d["roofline"].get("sustained_per_rank") or ([d["roofline"]["sustained"]] if d["roofline"].get("sustained") else [])
+clk = " ".join(f"{int(x.get('sclk_mhz') or 0)}MHz/{int(x.get('power_w') or 0)}W" for x in sus)      # every rank's device while all ranks keep stepping
+print(f"N={d['n_gpus']}: {d['value']:.0f} xRT  {d['ms_per_step']:.3f} ms/step  skew {r['wall_skew_s'] * 1e3:.2f} ms  rccl_ranks {r['rccl_ranks']}  [{clk}]  {d['config']['workload']}")
 PY
   done
 done
