@@ -1,7 +1,7 @@
 """GPU: the bench.py contract on a small workload — one JSON line per invocation with the fields the driver and the judge
 read (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
-data / config.workload / roofline / cpu_baseline), for the headline mode, the streaming schedules and the separately
-labelled experimental line."""
+data / config.workload / roofline / cpu_baseline), for the headline mode, the streaming schedules, the launch-structure
+A/B switch and the multi-GPU plumbing at world size 1."""
 import json
 import os
 import subprocess
