@@ -59,7 +59,7 @@ class Stamped(ops._timed):
             qs = torch.quantile(tt[:400000], torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64, device=dev)).tolist()
             d = (b[:, 1:] - b[:, :-1]).double().median(dim=0).values.tolist()
             k = 1.0      # an s_memtime tick is a shader cycle (guide, "s_memtime tick vs SQ PMC units")
-            span = (b[:, 7].max() - b[:, 0].min()).item() * k
+            span = ms * 1e-3 * 2.39e9                      # (s_memtime bases differ between XCDs: the launch time at the sustained clock instead)
             rows.append((self.tag, ms, int(live.sum()), tt.mean().item() * k, [q * k for q in qs], tt.sum().item() * k / span / 256, [v * k for v in d], self.work / ms / 1e9))
         return False
 
