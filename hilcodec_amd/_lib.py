@@ -60,16 +60,16 @@ SIGNATURES = {
     "hilc_spec_block_conv_pre": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _f, _f, _i, _f, _p],
     "hilc_spec_block": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _f, _p],
     "hilc_l2norm": [_p, _p, _i, _i, _i, _f, _f, _i, _p],
-    "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_encode": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_mse_finalize": [_p, _p, _i, _d, _p],
     "hilc_rvq_decode": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "hilc_rvq_encode_mixed": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hilc_rvq_encode_mixed": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_rvq_ema_stats": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "hilc_rvq_ema_update": [_p, _p, _p, _p, _d, _i, _i, _i, _p],
     "hilc_rvq_decode_mixed": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def source_hash() -> str:

@@ -102,8 +102,8 @@ struct Cfg {
   // element, like the loader of hilc_up_conv), two GEMMs accumulate over the 2C rows in k order, + bias -> the x registers.  The
   // [B][C][T] tensor between the up-sampling layer and the first block never exists.  Whole-stream tiles only (NARROW, C >= 512).
   static constexpr int UR = DR_ < 0 ? -DR_ : 0;
-  static_assert(DR_ <= 0 || (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || (!STREAM && ((DR_ == 5 && C == 256) || (DR_ == 8 && C == 512)))),
-                "down-sampling phase: carry form, r = 2 / 4 (C <= 192) or the wide encoder stages of the offline model (C = 256: r = 5, C = 512: r = 8)");
+  static_assert(DR_ <= 0 || (((DR_ == 2 || DR_ == 4) && (!STREAM || SCARRY_) && C <= 192) || ((!STREAM || SCARRY_) && DR_ == 5 && C == 256) || (!SCARRY_ && DR_ == 8 && C == 512)),
+                "down-sampling phase: carry form, r = 2 / 4 (C <= 192) or the wide encoder stages (C = 256: r = 5, offline and the hop's 32-column carry form; C = 512: r = 8, offline and a hop's whole-stream tiles)");
   // carry columns of the down-sampling phase per half of its 2C rows: the strided conv reads k - r = r columns in front of its first
   // output's window; r = 2 / 4: the 4 in front of a lane's group; r = 8: 8; r = 5: up to 9 (a tile does not start on a multiple of 5) -> 12
   static constexpr int DCAR = DR_ <= 0 ? 0 : (DR_ == 5 ? 12 : (DR_ == 8 ? 8 : 4));
@@ -117,7 +117,14 @@ struct Cfg {
   // previous samples, so there is no halo to recompute; 64-column tiles walk the flat column space with an 8-column halo.
   // Offline: the carry form, like every other width — one workgroup per CU walks a contiguous run of a clip's tiles.
   static constexpr bool NARROW = C >= 256;
-  static constexpr int NCOL = NARROW ? (C >= 512 ? 32 : 64) : 128;      // tile width = LDS row stride (floats)
+  // N32 (round 6): the STREAMING carry form of the two wide stages whose streams are 40 columns per frame of a hop (C = 256 encoder, C = 384
+  // decoder).  64-column flat tiles with a halo could neither carry nor chain (a run of whole streams = 8 streams = 128 runs for 1 024
+  // streams: half the chip), so those stages were 3 + 4 launches at 67 - 100 TF.  On 32-column tiles a run of whole streams is 5 tiles =
+  // 4 streams: 1 024 streams = exactly one run per CU, no halo, no partly filled round, the whole stage — blocks and its down- / up-sampling
+  // layer — one launch.  Every wave owns ONE 32-row block (C = 256: 8 waves, C = 384: 12 waves = three per SIMD).
+  static constexpr bool N32 = STREAM && SCARRY_ && NARROW;
+  static_assert(!N32 || C == 256 || C == 384, "32-column carry form: the C = 256 / C = 384 stages of a hop");
+  static constexpr int NCOL = NARROW ? ((C >= 512 || N32) ? 32 : 64) : 128;      // tile width = LDS row stride (floats)
   static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR + (POST_ ? 4 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
@@ -129,7 +136,7 @@ struct Cfg {
   static constexpr bool CARRYMODE = !STREAM || SCARRY_;
   static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = (C >= 192 || W8_) ? 8 : 4;           // waves per workgroup
+  static constexpr int NW = (N32 && C == 384) ? 12 : ((C >= 192 || W8_) ? 8 : 4);           // waves per workgroup
   static constexpr int NT = 64 * NW;
   static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
   static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave
@@ -154,7 +161,7 @@ struct Cfg {
 #ifndef HILC_RES_MINW
 #define HILC_RES_MINW 2
 #endif
-  static constexpr int MINW = NW == 8 ? 2 : HILC_RES_MINW;   // waves per SIMD the register budget must allow
+  static constexpr int MINW = NW >= 8 ? NW / 4 : HILC_RES_MINW;   // waves per SIMD the register budget must allow
   static_assert(NW % (NCOL / 32) == 0 && CB % RH == 0 && RW % RB == 0 && C % RSTEP == 0, "tile split");
   static_assert(NB_ >= 1 && NB_ <= 3 && (NB_ == 1 || CARRYMODE || (NARROW && C >= 512)), "a chain needs carries or whole-stream tiles");
 };

@@ -47,8 +47,10 @@ extern "C" int hilc_resblock_chain_row_classes(int C) {
   static_assert(Cfg<64, true, true, 2, false>::RH == 1 && Cfg<96, true, true, 3, false>::RH == 1 &&
                 Cfg<128, true, true, 2, true>::RH == 2 && Cfg<192, true, true, 3, false>::RH == 2 &&
                 Cfg<512, true, false, 2, false>::RH == 8 && Cfg<768, true, false, 3, false>::RH == 8, "packed layout");
-  static_assert(Cfg<384, true, false, 1, false, -5>::RH == 4, "packed layout");
-  if (C == 256 || C == 384) return 4;
+  // the hop's C = 256 / C = 384 stages: 32-column carry tiles, every wave one 32-row block (8 / 12 waves)
+  static_assert(Cfg<256, true, true, 2, false, 5>::RH == 8 && Cfg<384, true, true, 3, false, -5>::RH == 12 && Cfg<512, true, false, 2, false, 8>::RH == 8, "packed layout");
+  if (C == 256) return 8;
+  if (C == 384) return 12;
   return C >= 512 ? 8 : ((C == 96 || C == 64) ? 1 : (chain_width(C) ? 2 : 0));
 }
 
@@ -111,8 +113,11 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
 extern "C" int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
   if (nblk < 1 || nblk > 2 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
   if ((C == 64 && stride == 2) || (C == 128 && stride == 4)) return 1;
-  // the wide stages of the OFFLINE model (narrow-tile carry form; the strided conv's outputs do not align with 4-column lanes there)
-  return !streaming && ((C == 256 && stride == 5) || (C == 512 && stride == 8));
+  // the wide stages (narrow-tile shapes; the strided conv's outputs do not align with 4-column lanes there).  Offline: the carry form.
+  // A hop (round 6): C = 256 on 32-column carry tiles (whole frames of 40 columns per stream: a stream's last r columns never straddle
+  // two tiles), C = 512 on whole-stream tiles (T = 8, 16, 32)
+  if (!streaming) return (C == 256 && stride == 5) || (C == 512 && stride == 8);
+  return (C == 256 && stride == 5 && T % 40 == 0) || (C == 512 && stride == 8 && T % 8 == 0 && 32 % T == 0);
 }
 
 extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
@@ -137,7 +142,14 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = streaming ? down->hist : nullptr;
   d.hist_out = streaming ? down->hist_out : nullptr; d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
   hipStream_t s = (hipStream_t)stream;
-  if (streaming) return C == 64 ? launch_chain<64, true, 2, false, 2>(a, B, s) : launch_chain<128, true, 2, true, 4>(a, B, s);
+  if (streaming) {
+    switch (C) {
+      case 64: return launch_chain<64, true, 2, false, 2>(a, B, s);
+      case 128: return launch_chain<128, true, 2, true, 4>(a, B, s);
+      case 256: return launch_chain<256, true, 2, false, 5>(a, B, s);
+      default: return launch_chain<512, true, 2, false, 8>(a, B, s);
+    }
+  }
   switch (C) {
     case 64: return launch_chain<64, false, 2, false, 2>(a, B, s);
     case 128: return launch_chain<128, false, 2, true, 4>(a, B, s);
@@ -184,9 +196,9 @@ extern "C" int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_res
 extern "C" int hilc_decoder_stage_supported(int C, int T, int nblk, int stride, int streaming) {
   if (nblk < 1 || nblk > 3 || T <= 0 || T % 4 != 0 || stride <= 0 || T % stride != 0) return 0;
   if (C == 768) return stride == 8 && (streaming ? 32 % T == 0 : nblk == 1);      // whole streams per 32-column tile; offline: carry form, up-sampling layer + FIRST block (LDS)
-  // r = 5: up->tr_w = the EXPANDED tap table of hilc_up_conv_expand_taps.  Offline: carry form, the whole stage; a streaming hop: the
-  // halo form of the wide blocks (64-column flat tiles), the up-sampling layer + the stage's FIRST block
-  if (C == 384) return stride == 5 && (!streaming || nblk == 1);
+  // r = 5: up->tr_w = the EXPANDED tap table of hilc_up_conv_expand_taps.  Offline: carry form, the whole stage; a streaming hop
+  // (round 6): 32-column carry tiles, runs of whole streams, the whole stage (rounds 4-5: 64-column halo tiles, the first block only)
+  if (C == 384) return stride == 5;
   return (C == 192 && stride == 4) || (C == 96 && stride == 2);      // the carry form: streaming hops and the offline model
 }
 
@@ -246,7 +258,7 @@ int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* bl
   if (streaming) {
     switch (C) {
       case 768: return launch_chain<768, true, 3, false, -8>(a, B, s);
-      case 384: return launch_chain<384, true, 1, false, -5>(a, B, s);
+      case 384: return launch_chain<384, true, 3, false, -5>(a, B, s);
       case 192: return launch_chain<192, true, 3, false, -4>(a, B, s);
       default: return launch_chain<96, true, 3, false, -2>(a, B, s);
     }

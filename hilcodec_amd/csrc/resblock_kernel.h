@@ -911,20 +911,42 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
           // belongs to the tile that holds its LAST column — from the tile and, left of its first column, from the half's carry
           // slot (the previous tile's last DCAR columns; zeros at a clip's start = the conv's zero padding).  Taps and bias come
           // from global memory (the same few rows for every workgroup: L1 / L2), k ascending like DwStrideEpilogue: bit-identical.
+          // STREAM (round 6: the hop's C = 256 stage on 32-column carry tiles, its C = 512 stage on whole-stream tiles): the same walk on the FLAT
+          // column space — T % r == 0, so stream b's output o is the flat output b * To + o and reads the flat columns [r O - r, r O + r) —
+          // except that the r samples in front of a stream's t = 0 are its CACHE `hist[b][2C][r]` (the previous hop's last r pointwise
+          // outputs; zeros without one), not the previous stream's columns; the lane that holds a stream's last group stores the next one.
           constexpr int DC = K::DCAR;
-          constexpr int DOFF = K::NCOL + 8 * NB;             // the two halves' carry slots behind a row
+          constexpr int DOFF = K::NCOL + 8 * NB;             // the two halves' carry slots behind a row (carry form)
+          constexpr bool SLOTS = K::CARRYMODE;               // (whole-stream tiles: no slots — whatever lies left of column 0 is a cache)
           const int jl = c4 >> 2;
-          const int t0 = cs.t - c4;                          // the tile's first column (offline: cs.t = t0 + c4 for every lane)
-          const int o = t0 / DR + jl;
+          const int t0 = STREAM ? (int)tile * TO : cs.t - c4;   // the tile's first column (offline: cs.t = t0 + c4 for every lane; STREAM: flat)
+          const int o = t0 / DR + jl;                        // this lane's output (offline: of the clip; STREAM: flat)
           const int base = o * DR - DR - t0;                 // local column of the window's first sample: >= -(2 r - 1)
-          const bool act = out_ok_tile && o < To && o * DR + DR - 1 < t0 + K::NCOL;
-          const int slot = DOFF + DC * h + DC;               // column -k of the tile lives at slot - k
+          [[maybe_unused]] unsigned sb = 0;                  // STREAM: the output's stream, and its index inside it
+          int os = o;
+          if constexpr (STREAM) {
+            const bool in = o < a.B * To;
+            sb = in ? __umulhi((unsigned)(o * DR), a.div_magic) >> a.div_shift : 0u;
+            os = in ? o - (int)sb * To : 1;
+          }
+          [[maybe_unused]] const bool dhead = STREAM && os == 0;
+          const bool act = out_ok_tile && (STREAM ? o < a.B * To : o < To) && o * DR + DR - 1 < t0 + K::NCOL;
+          [[maybe_unused]] const int slot = DOFF + DC * h + DC;               // column -k of the tile lives at slot - k
           // one row per (rolled) iteration — unrolled, hipcc keeps every row's addresses and taps alive (31 spilled registers at C = 512) —
-          // with the NEXT row's taps and bias requested before this row's arithmetic
+          // with the NEXT row's taps and bias (STREAM: and cache words) requested before this row's arithmetic
           lptr_t rowp = (lptr_t)(X + rsub * XS);
           const float* wrow = dn.dw_w + (long)(h * C + rsub) * (2 * DR);
           const float* brow = dn.dw_b + (h * C + rsub);
           float wn[2 * DR], bn;
+          [[maybe_unused]] float hn[STREAM ? DR : 1];
+          [[maybe_unused]] const float* hrow = dn.dw_w;      // STREAM: this lane's stream's cache row (a valid address for every lane)
+          [[maybe_unused]] float* horow = nullptr;           // STREAM: where this lane's group — a stream's last — leaves the next cache
+          [[maybe_unused]] const bool use_hist = STREAM && dn.hist != nullptr;
+          if constexpr (STREAM) {
+            if (use_hist) hrow = dn.hist + ((long)sb * (2 * C) + h * C + rsub) * DR;
+            if (dn.hist_out != nullptr) horow = dn.hist_out + ((long)cs.b * (2 * C) + h * C + rsub) * DR;
+          }
+          [[maybe_unused]] const bool dtail = STREAM && cs.tail && !warm && dn.hist_out != nullptr;
           auto taps_of = [&](const float* wr, const float* br) {
             if constexpr (DR == 8) {
 #pragma unroll
@@ -941,23 +963,47 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
               }
             }
             bn = br[0];
+            if constexpr (STREAM) {
+              if (use_hist) {                                 // uniform
+                if constexpr (DR == 8) {
+#pragma unroll
+                  for (int q = 0; q < 2; ++q) {
+                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(hrow + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hn[4 * q + e] = h4[e];
+                  }
+                } else {
+#pragma unroll
+                  for (int j = 0; j < DR; ++j) hn[j] = hrow[j];
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < DR; ++j) hn[j] = 0.f;
+              }
+            }
           };
           taps_of(wrow, brow);
-          long yo = ((long)cs.b * (2 * C) + h * C + rsub) * (long)To + o;
+          long yo = STREAM ? ((long)sb * (2 * C) + h * C + rsub) * (long)To + os : ((long)cs.b * (2 * C) + h * C + rsub) * (long)To + o;
 #pragma nounroll
           for (int i0 = 0; i0 < RW; ++i0) {
             float v[2 * DR], w[2 * DR];
 #pragma unroll
             for (int j = 0; j < 2 * DR; ++j) w[j] = wn[j];
             const float bb = bn;
+            [[maybe_unused]] float hc[STREAM ? DR : 1];
+            if constexpr (STREAM) {
+#pragma unroll
+              for (int j = 0; j < DR; ++j) hc[j] = hn[j];
+            }
             wrow += RSTEP * (2 * DR);
             brow += RSTEP;
+            if constexpr (STREAM) hrow += use_hist ? RSTEP * DR : 0;
             if (i0 + 1 < RW) taps_of(wrow, brow);
             if constexpr (DR == 8) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const int col = base + 4 * q;
-                const f32x4 x4 = *(lvec_t)(rowp + (col >= 0 ? col : slot + col));
+                const f32x4 x4 = *(lvec_t)(rowp + (col >= 0 ? col : (SLOTS ? slot + col : 0)));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * q + e] = x4[e];
               }
@@ -965,12 +1011,31 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
 #pragma unroll
               for (int j = 0; j < 2 * DR; ++j) {
                 const int col = base + j;
-                v[j] = *(rowp + (col >= 0 ? col : slot + col));
+                v[j] = *(rowp + (col >= 0 ? col : (SLOTS ? slot + col : 0)));
               }
             }
+            if constexpr (STREAM) {
+#pragma unroll
+              for (int j = 0; j < DR; ++j) v[j] = dhead ? hc[j] : v[j];
+            }
             const f32x4 keep = *(lvec_t)(rowp + c4);          // this lane's own group: the tile's last DCAR columns become the carry
-            if (c4 >= K::NCOL - DC)                            // (after every read of the slot: one wave instruction stream per row)
-              *(lvec_t)(rowp + DOFF + DC * h + (c4 - (K::NCOL - DC))) = keep;
+            if constexpr (STREAM) {
+              // a stream's last group (T % 8 == 0: it never sits on column 0, and the r columns end inside this tile): the next hop's cache
+              const f32x4 before = *(lvec_t)(rowp + (c4 >= 4 ? c4 - 4 : 0));
+              if (dtail) {
+                if constexpr (DR == 8) {
+                  *reinterpret_cast<f32x4*>(horow) = before;
+                  *reinterpret_cast<f32x4*>(horow + 4) = keep;
+                } else {
+                  horow[0] = before.w; horow[1] = keep.x; horow[2] = keep.y; horow[3] = keep.z; horow[4] = keep.w;
+                }
+              }
+              horow += RSTEP * DR;
+            }
+            if constexpr (SLOTS) {
+              if (c4 >= K::NCOL - DC)                          // (after every read of the slot: one wave instruction stream per row)
+                *(lvec_t)(rowp + DOFF + DC * h + (c4 - (K::NCOL - DC))) = keep;
+            }
             float s0 = 0.f;
 #pragma unroll
             for (int j = 0; j < 2 * DR; ++j) s0 = fmaf(w[j], v[j], s0);

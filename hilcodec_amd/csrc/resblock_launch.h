@@ -67,7 +67,7 @@ inline void set_div_magic(ResArgs& a) {
 // stride.  Returns HILC_ERR_UNSUPPORTED where the geometry does not fit (the caller launches the blocks one by one).
 template <int C, bool STREAM, int NB, bool W8, int DR = 0, bool POST = false, bool SPEC0 = false>      // DR > 0: + down-sampling phase, DR < 0: + up-sampling phase (r = -DR); POST: + closing conv; SPEC0: + stage-0 input phase
 int launch_chain(ResArgs a, int B, hipStream_t s) {
-  constexpr bool SC = STREAM && C <= 192;         // runs of whole streams with carries (C = 384: flat tiles with a halo; C >= 512: whole-stream tiles, static stride)
+  constexpr bool SC = STREAM && C <= 384;         // runs of whole streams with carries (C = 256 / 384: 32-column tiles; C >= 512: whole-stream tiles, static stride)
   using K = Cfg<C, STREAM, SC, NB, W8, DR, POST, SPEC0>;
   a.B = B;
   set_div_magic(a);

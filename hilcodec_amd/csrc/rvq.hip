@@ -496,11 +496,11 @@ __global__ __launch_bounds__(256) void rvq_ema_num_kernel(EmaUpdateArgs a) {
 extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, const float* codebooks_t,
                                      const float* norms, const int* n_per_clip, int64_t* indices, float* q,
                                      float* frame_err, int B, int C, int T, int K, int Nq, int n, int channel_last,
-                                     int stage_major, void* stream) {
+                                     int stage_major, int flags, void* stream) {
   if (!z || !codebooks || !codebooks_t || !norms || !indices) return HILC_ERR_NULL;
   if (B <= 0 || C <= 0 || T <= 0 || K <= 0 || Nq <= 0) return HILC_ERR_SHAPE;
   if (n < 1 || n > Nq) return HILC_ERR_RANGE;
-  if (C != 128 || K != 256 * CPT) return HILC_ERR_UNSUPPORTED;
+  if (C != 128 || K != 256 * CPT || (flags & ~HILC_RVQ_VALU_ONLY) != 0) return HILC_ERR_UNSUPPORTED;
   RvqArgs a;
   a.z = z; a.cb = codebooks; a.cbt = codebooks_t; a.norms = norms; a.n_clip = n_per_clip; a.indices = indices; a.q = q;
   a.frame_err = frame_err; a.B = B; a.C = C; a.T = T; a.K = K; a.n = n;
@@ -511,11 +511,11 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
   // SIMD to hide the L2 round trips of the code words (256 x 4: 143 us, 512 x 2: 96 us, 1024 x 1: 107 us; 8 / 16 frames per
   // workgroup: 240 / 369 us — profiles/r04_experiments.md)
   // large batches: the score GEMM on the matrix pipe, 32 frames per workgroup (two workgroups per CU)
-  // HILC_RVQ_VALU in the environment (read once) keeps large batches on the VALU form (16 frames per workgroup): the switch an operator has
-  // if a future part's fp32 MFMA should ever stop accumulating as a sequential fmaf chain over ascending k — which is what makes
-  // the two forms, hence offline and streaming indices, identical; tests/test_gpu_rvq.py pins that on every box it runs on, and
-  // runs this branch too.
-  static const bool valu_only = getenv("HILC_RVQ_VALU") != nullptr;
+  // flags & HILC_RVQ_VALU_ONLY keeps large batches on the VALU form (16 frames per workgroup): the switch a caller has if a future
+  // part's fp32 MFMA should ever stop accumulating as a sequential fmaf chain over ascending k — which is what makes the two
+  // forms, hence offline and streaming indices, identical; tests/test_gpu_rvq.py pins that on every box it runs on, and runs
+  // this branch too.  (An argument, not an environment variable: the library keeps no process-global switches.)
+  const bool valu_only = (flags & HILC_RVQ_VALU_ONLY) != 0;
   if (nframes >= 32 * 256 && !valu_only)
     hipLaunchKernelGGL((rvq_encode_mfma_kernel<128>), dim3((unsigned)((nframes + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
   else if (nframes <= 16 * 512)
@@ -528,9 +528,9 @@ extern "C" int hilc_rvq_encode_mixed(const float* z, const float* codebooks, con
 
 extern "C" int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t,
                                const float* norms, int64_t* indices, float* q, float* frame_err, int B, int C,
-                               int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream) {
+                               int T, int K, int Nq, int n, int channel_last, int stage_major, int flags, void* stream) {
   return hilc_rvq_encode_mixed(z, codebooks, codebooks_t, norms, nullptr, indices, q, frame_err, B, C, T, K, Nq, n,
-                               channel_last, stage_major, stream);
+                               channel_last, stage_major, flags, stream);
 }
 
 extern "C" int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream) {

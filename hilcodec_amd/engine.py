@@ -222,7 +222,7 @@ def finalize_spec(spec, streaming: bool = False):
         for rb in st.blocks:
             finalize_block(rb, streaming)
         if (isinstance(st, EncStageSpec) and st.down_lo is None and st.down_pw_wt.device.type in ("cuda", "meta")
-                and st.down_pw_wt.shape[0] in ((64, 128) if streaming else (64, 128, 256, 512)) and st.down_pw_wt.shape[1] == 2 * st.down_pw_wt.shape[0]
+                and st.down_pw_wt.shape[0] in (64, 128, 256, 512) and st.down_pw_wt.shape[1] == 2 * st.down_pw_wt.shape[0]
                 and all(rb.pw1_chain is not None for rb in st.blocks)):
             c = st.down_pw_wt.shape[0]
             st.down_lo = ops.resblock_chain_pack(st.down_pw_wt[:, :c].contiguous(), streaming)

@@ -71,6 +71,7 @@ class ResidualVQ(_CodebookStack):
                  **kwargs):
         super().__init__()
         self.layers = nn.ModuleList([EuclideanCodebook(**kwargs) for _ in range(num_quantizers)])
+        self.rvq_valu_only = False      # launch option, see models/hilcodec/vector_quantize.py
 
     def forward(self, x: Tensor, n: int) -> Tensor:
         sp = self._tables(x.device)
@@ -80,7 +81,7 @@ class ResidualVQ(_CodebookStack):
                 raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
         # else: one n per stream (mixed-bitrate batch); rows >= n_b of the result hold -1
         idx, _, _ = ops.rvq_encode(x.contiguous().float(), sp.codebooks, sp.codebooks_t, sp.norms, n,
-                                   channel_last=True, stage_major=True, want_q=False)
+                                   channel_last=True, stage_major=True, want_q=False, valu_only=self.rvq_valu_only)
         return idx
 
 

@@ -94,6 +94,9 @@ class ResidualVQ(nn.Module):
             dropout_index = list(range(1, num_quantizers + 1))
         self.dropout_index = dropout_index
         self.channel_last = channel_last
+        # per-quantiser launch option (not part of the reference's API): keep batches of 8 192 frames and more on the VALU form of
+        # hilc_rvq_encode (HILC_RVQ_VALU_ONLY) instead of the matrix pipe — same fmaf chains, same indices
+        self.rvq_valu_only = False
         self._key = None
         self._spec = None
 
@@ -120,7 +123,7 @@ class ResidualVQ(nn.Module):
         sp = self.spec(dev)
         xin = x.detach().contiguous().float()
         idx, q, _ = ops.rvq_encode(xin, sp.codebooks, sp.codebooks_t, sp.norms, high, channel_last=self.channel_last,
-                                   stage_major=False, want_q=True)
+                                   stage_major=False, want_q=True, valu_only=self.rvq_valu_only)
         bucket = ops.rvq_ema_stats(xin, sp.codebooks, idx, high, channel_last=self.channel_last, stage_major=False)
         distributed.all_reduce_sum_(bucket)
         decay = layers[0].decay
@@ -184,7 +187,7 @@ class ResidualVQ(nn.Module):
         sp = self.spec(x.device)
         idx, q, loss = ops.rvq_encode(x.contiguous().float(), sp.codebooks, sp.codebooks_t, sp.norms, high,
                                       channel_last=self.channel_last, stage_major=False, want_q=True,
-                                      want_loss=True)
+                                      want_loss=True, valu_only=self.rvq_valu_only)
         if return_indices:
             return q, num_replaces, loss, idx
         return q, num_replaces, loss

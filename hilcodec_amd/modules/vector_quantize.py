@@ -147,6 +147,7 @@ class ResidualVQ(nn.Module):
             dropout_index = list(range(1, num_quantizers + 1))
         self.dropout_index = dropout_index
         self.use_shape_gain = self.layers[0].use_shape_gain
+        self.rvq_valu_only = False      # launch option, see models/hilcodec/vector_quantize.py
         self._key = None
         self._spec = None
 
@@ -188,5 +189,5 @@ class ResidualVQ(nn.Module):
         sp = self.spec(x.device)
         _, q, loss = ops.rvq_encode(x.contiguous().float(), sp.codebooks, sp.codebooks_t, sp.norms, high,
                                     channel_last=self.layers[0].channel_last, stage_major=False, want_q=True,
-                                    want_loss=True)
+                                    want_loss=True, valu_only=self.rvq_valu_only)
         return q, num_replaces, loss

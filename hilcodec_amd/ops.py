@@ -636,7 +636,10 @@ def _zct(z, channel_last):
     return B, Cc, T
 
 
-def _rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss):
+RVQ_VALU_ONLY = 1      # include/hilcodec_amd.h: HILC_RVQ_VALU_ONLY
+
+
+def _rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss, flags):
     B, Cc, T = _zct(z, channel_last)
     Nq, K, _ = codebooks.shape
     rows = max(1, min(n, Nq))
@@ -646,7 +649,7 @@ def _rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage
     with _timed("rvq_encode", 2.0 * B * T * K * Cc * rows):
         check(lib.hilc_rvq_encode_mixed(_ptr(z), _ptr(codebooks), _ptr(codebooks_t), _ptr(norms),
                                         _ptr(n_clip, torch.int32), _ptr(idx, torch.int64), _ptr(q), _ptr(ferr),
-                                        B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), _stream()),
+                                        B, Cc, T, K, Nq, n, int(channel_last), int(stage_major), int(flags), _stream()),
               "hilc_rvq_encode")
     loss = None
     if want_loss:
@@ -656,7 +659,7 @@ def _rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage
     return idx, (q if q is not None else _new(z, 0)), (loss if loss is not None else _new(z, 0))
 
 
-def _rvq_encode_fake(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss):
+def _rvq_encode_fake(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, stage_major, want_q, want_loss, flags):
     B, Cc, T = _zct(z, channel_last)
     rows = max(1, min(n, codebooks.shape[0]))
     idx = z.new_empty(*((rows, B, T) if stage_major else (B, rows, T)), dtype=torch.int64)
@@ -664,7 +667,7 @@ def _rvq_encode_fake(z, codebooks, codebooks_t, norms, n_clip, n, channel_last, 
 
 
 _register("rvq_encode", "(Tensor z, Tensor codebooks, Tensor codebooks_t, Tensor norms, Tensor? n_clip, int n, "
-          "bool channel_last, bool stage_major, bool want_q, bool want_loss) -> (Tensor, Tensor, Tensor)",
+          "bool channel_last, bool stage_major, bool want_q, bool want_loss, int flags) -> (Tensor, Tensor, Tensor)",
           _rvq_encode, _rvq_encode_fake)
 
 
@@ -831,7 +834,7 @@ def resblock_chain_row_classes(C: int, streaming: bool = True) -> int:
     """mirror of hilc_resblock_chain_row_classes(_offline): the row split of the packed weights a chain launch reads"""
     if not streaming:
         return 8 if C in (512, 768) else (4 if C in (256, 384) else (2 if C in (128, 192) else 1))
-    return 8 if C >= 512 else (4 if C in (256, 384) else (1 if C in (64, 96) else 2))
+    return 8 if C >= 512 or C == 256 else (12 if C == 384 else (1 if C in (64, 96) else 2))
 
 
 def resblock_chain_pack(wt: Tensor, streaming: bool = True) -> Tensor:
@@ -871,7 +874,7 @@ def decoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
     if C == 768:
         return stride == 8 and (32 % T == 0 if streaming else nblk == 1)
     if C == 384:
-        return stride == 5 and (not streaming or nblk == 1)
+        return stride == 5
     return (C == 192 and stride == 4) or (C == 96 and stride == 2)
 
 
@@ -952,7 +955,9 @@ def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
         return False
     if (C == 64 and stride == 2) or (C == 128 and stride == 4):
         return True
-    return not streaming and ((C == 256 and stride == 5) or (C == 512 and stride == 8))      # the wide stages of the offline model
+    if not streaming:
+        return (C == 256 and stride == 5) or (C == 512 and stride == 8)                      # the wide stages of the offline model
+    return (C == 256 and stride == 5 and T % 40 == 0) or (C == 512 and stride == 8 and T % 8 == 0 and 32 % T == 0)   # ... of a hop
 
 
 def encoder_stage(x: Tensor, blocks: Sequence[Sequence], down: Sequence, hist: Optional[Sequence[Sequence[Tensor]]] = None,
@@ -1122,13 +1127,14 @@ def per_clip_n(n, B: int, Nq: int, device):
 
 def rvq_encode(z: Tensor, codebooks: Tensor, codebooks_t: Tensor, norms: Tensor, n,
                channel_last: bool = False, stage_major: bool = False, want_q: bool = True,
-               want_loss: bool = False):
+               want_loss: bool = False, valu_only: bool = False):
     """Returns (indices int64, q or None, loss 0-d or None).  `n`: int, or one int per clip (rows of `indices`
-    beyond a clip's own n hold -1)."""
+    beyond a clip's own n hold -1).  `valu_only` (HILC_RVQ_VALU_ONLY of the C ABI): keep batches of 8 192 frames and more on the
+    VALU form instead of the matrix pipe — same fmaf chains, same bits; the quantiser modules pass their `rvq_valu_only` attribute."""
     B = z.shape[0]
     n, n_clip = per_clip_n(n, B, codebooks.shape[0], z.device)
     idx, q, loss = _OPS.rvq_encode(z, codebooks, codebooks_t, norms, n_clip, n, bool(channel_last), bool(stage_major),
-                                   bool(want_q), bool(want_loss))
+                                   bool(want_q), bool(want_loss), RVQ_VALU_ONLY if valu_only else 0)
     return idx, (q if want_q else None), (loss if want_loss else None)
 
 

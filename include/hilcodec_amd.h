@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 14   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post, hilc_encoder_stage0 */
+#define HILC_ABI_VERSION 15   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post, hilc_encoder_stage0; 15: hilc_rvq_encode[_mixed] take `flags` (HILC_RVQ_VALU_ONLY replaces the HILC_RVQ_VALU environment variable) */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -342,10 +342,13 @@ int hilc_l2norm(const float* x, float* y, int B, int C, int T, float eps, float 
  * `models/hilcodec/streaming.py:51-68,89-100`).  Returns HILC_ERR_RANGE unless 1 <= n <= Nq.
  * Every score is one fp32 fmaf chain over the channels in ascending order, whatever the batch size: small batches on the VALU
  * (4 or 16 frames per workgroup), 8 192 frames and more on the matrix pipe (v_mfma_f32_32x32x2_f32, 32 frames per workgroup,
- * the A operand read straight from codebooks_t) — same bits, same indices. */
+ * the A operand read straight from codebooks_t) — same bits, same indices.  flags: 0, or HILC_RVQ_VALU_ONLY = keep large batches
+ * on the VALU form too (16 frames per workgroup; the caller's switch should an fp32 MFMA ever stop being a sequential fmaf chain
+ * over ascending k); any other bit: HILC_ERR_UNSUPPORTED. */
+#define HILC_RVQ_VALU_ONLY 1
 int hilc_rvq_encode(const float* z, const float* codebooks, const float* codebooks_t, const float* norms,
                     int64_t* indices, float* q, float* frame_err, int B, int C, int T, int K, int Nq, int n,
-                    int channel_last, int stage_major, void* stream);
+                    int channel_last, int stage_major, int flags, void* stream);
 
 /* Mixed-bitrate batch (`n` drawn per request from `dropout_index`, configs/hilcodec_*.yaml:38,
  * `infer_n` :117,130): clip b uses stages [0, n_per_clip[b]) (int32 `[B]`, device; values clamped to [1, n]);
@@ -354,7 +357,7 @@ int hilc_rvq_encode(const float* z, const float* codebooks, const float* codeboo
  * n_per_clip == NULL is hilc_rvq_encode. */
 int hilc_rvq_encode_mixed(const float* z, const float* codebooks, const float* codebooks_t, const float* norms,
                           const int* n_per_clip, int64_t* indices, float* q, float* frame_err, int B, int C,
-                          int T, int K, int Nq, int n, int channel_last, int stage_major, void* stream);
+                          int T, int K, int Nq, int n, int channel_last, int stage_major, int flags, void* stream);
 
 /* mean over `count` of frame_err[0..frames) in a fixed order -> loss[0]  (F.mse_loss, `vector_quantize.py:233`) */
 int hilc_mse_finalize(const float* frame_err, float* loss, int frames, double count, void* stream);

@@ -35,8 +35,10 @@ def test_error_codes_without_gpu():
     one = ctypes.c_void_p(16)
     assert lib.hilc_pw_conv(one, one, None, None, one, 0, 8, 8, 8, 1.0, 0, 1.0, None) == -1          # shape
     assert lib.hilc_pw_conv(one, one, None, None, one, 1, 8, 6, 8, 1.0, 0, 1.0, None) == -4          # unsupported
-    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 9, 0, 0, None) == -5
-    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 0, 0, 0, None) == -5
+    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 9, 0, 0, 0, None) == -5
+    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 0, 0, 0, 0, None) == -5
+    # an unknown bit of `flags` (ABI 15) is refused, not ignored
+    assert lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 8, 0, 0, 2, None) == -4
     assert lib.hilc_resblock_supported(96, 24000) == 1 and lib.hilc_resblock_supported(768, 600) == 1 and lib.hilc_resblock_supported(1024, 600) == 0
     from hilcodec_amd import ops
     for c in (32, 64, 80, 96, 128, 160, 192, 256, 768):          # the traceable Python mirror agrees with the library

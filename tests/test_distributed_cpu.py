@@ -148,7 +148,7 @@ def _cpu_rvq_kernels():
     import torch.nn.functional as F
     from oracle import hilcodec_oracle as O
 
-    def rvq_encode(z, cb, cbt, norms, n, channel_last=False, stage_major=False, want_q=True, want_loss=False):
+    def rvq_encode(z, cb, cbt, norms, n, channel_last=False, stage_major=False, want_q=True, want_loss=False, valu_only=False):
         sd = {f"quantizer.layers.{i}.embed": cb[i] for i in range(cb.shape[0])}
         zz = z.transpose(1, 2) if channel_last else z
         q, _, loss, idx = O.rvq_forward(sd, zz, int(n), cb.shape[0])

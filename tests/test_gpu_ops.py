@@ -531,7 +531,11 @@ def test_encoder_stage_offline_equals_blocks_then_down(env, C, r, T, B, n):
 
 
 @pytest.mark.parametrize("C,r,T,B,n", [(64, 2, 320, 5, 2), (128, 4, 160, 7, 2), (64, 2, 320, 1024, 2), (128, 4, 160, 1024, 2), (64, 2, 640, 3, 2),
-                                        (128, 4, 8, 21, 2), (64, 2, 12, 70, 1)])
+                                        (128, 4, 8, 21, 2), (64, 2, 12, 70, 1),
+                                        # round 6: the hop's wide stages — C = 256 / r = 5 on 32-column carry tiles (runs of 4 whole streams),
+                                        # C = 512 / r = 8 on whole-stream tiles; ragged stream counts, several frames per hop, a single block
+                                        (256, 5, 40, 7, 2), (256, 5, 40, 1024, 2), (256, 5, 80, 3, 2), (256, 5, 40, 1, 1), (256, 5, 120, 6, 2), (256, 5, 40, 130, 2),
+                                        (512, 8, 8, 21, 2), (512, 8, 8, 1024, 2), (512, 8, 16, 5, 2), (512, 8, 32, 3, 1), (512, 8, 8, 1, 2)])
 def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
     """hilc_encoder_stage, streaming hop (`streaming.py:497-511`): == the blocks one by one (hilc_resblock_stream) followed by
     hilc_dws_conv_stream with the layer's cache: output, the 2n block caches and the down-sampling cache, bit for bit over three
@@ -561,21 +565,25 @@ def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
 @pytest.mark.parametrize("C,r,Tin,B,n", [(768, 8, 1, 37, 3), (768, 8, 1, 1024, 3), (768, 8, 2, 9, 3), (768, 8, 4, 5, 2), (768, 8, 1, 3, 1),
                                           (192, 4, 40, 7, 3), (192, 4, 40, 1024, 3), (96, 2, 160, 5, 3), (96, 2, 160, 1024, 3), (192, 4, 80, 3, 2),
                                           (96, 2, 2, 70, 3), (192, 4, 1, 33, 3), (384, 5, 8, 19, 1), (384, 5, 8, 1024, 1), (384, 5, 8, 1, 1), (384, 5, 16, 5, 1),
-                                          (384, 5, 4, 3, 1)])
+                                          (384, 5, 4, 3, 1),
+                                          # round 6: the whole C = 384 stage of a hop on 32-column carry tiles (runs of whole streams)
+                                          (384, 5, 8, 19, 3), (384, 5, 8, 1024, 3), (384, 5, 8, 1, 3), (384, 5, 16, 5, 2), (384, 5, 4, 3, 3), (384, 5, 24, 6, 3),
+                                          (384, 5, 8, 130, 3)])
 def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n):
     """hilc_decoder_stage (a decoder stage of a streaming hop — `streaming.py:629-639` — in one launch: C = 768 / r = 8 on whole-stream
-    tiles, C = 192 / r = 4 and C = 96 / r = 2 in the carry form, C = 384 / r = 5: the up-sampling layer + the first block on 64-column flat
-    tiles with a halo) == hilc_up_conv_stream followed by the residual blocks (chain), bit
-    for bit over three hops: output, the up-sampling cache and the 2n block caches."""
+    tiles, C = 192 / r = 4 and C = 96 / r = 2 in the carry form, C = 384 / r = 5: 32-column carry tiles, runs of whole streams — rounds 4-5: the
+    up-sampling layer + the first block on 64-column flat tiles with a halo) == hilc_up_conv_stream followed by the residual blocks (chain;
+    C = 384: block by block, hilc_resblock_stream), bit for bit over three hops: output, the up-sampling cache and the 2n block caches."""
     ops, fold, O, dev = env
     T = Tin * r
     assert ops.decoder_stage_supported(C, T, n, r, B)
-    blocks = []
+    blocks, raw = [], []
     for j in range(n):
         w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
         d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
         d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
         blocks.append((ops.resblock_chain_pack(w1), d1, b1, ops.resblock_chain_pack(w2), d2, b2, 1.0, 0.4 + 0.1 * j))
+        raw.append((w1, w2))
     tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
     wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)                 # k-major [2C][C]
     bu = (rnd(82, C) * 0.1).to(dev)
@@ -590,13 +598,13 @@ def test_decoder_stage_streaming_equals_up_conv_then_blocks(env, C, r, Tin, B, n
         y, flat, ua = ops.decoder_stage(xin, up, blocks, ca, ua)
         ca = [flat[2 * j:2 * j + 2] for j in range(n)]
         y2, ub = ops.up_conv(xin, tw, wu, bu, r, in_scale=0.7071, in_elu=True, hist=ub, want_hist=True)
-        if n >= 2:
+        if n >= 2 and ops.resblock_chain_supported(C, T, n, B):
             y2, f2 = ops.resblock_chain(y2, blocks, cb)
             cb = [f2[2 * j:2 * j + 2] for j in range(n)]
         else:
-            blk = blocks[0]
-            y2, cb[0] = ops.resblock(y2, ops.resblock_pack((rnd(1, C, C) / C ** 0.5).to(dev)), blk[1], blk[2],
-                                     ops.resblock_pack((rnd(4, C, C) / C ** 0.5).to(dev)), blk[4], blk[5], 1.0, blk[7], hist=cb[0])
+            for j, blk in enumerate(blocks):
+                y2, cb[j] = ops.resblock(y2, ops.resblock_pack(raw[j][0]), blk[1], blk[2], ops.resblock_pack(raw[j][1]), blk[4], blk[5],
+                                         1.0, blk[7], hist=cb[j])
         assert torch.equal(y, y2), (h, float((y - y2).abs().max()))
         assert torch.equal(ua, ub), h
         for j in range(n):

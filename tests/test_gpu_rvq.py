@@ -136,34 +136,37 @@ def test_rvq_large_batches_on_the_matrix_pipe_equal_small_ones(B, Tn, nq, mixed)
 
 
 def test_rvq_valu_switch_keeps_large_batches_off_the_matrix_pipe_with_equal_indices():
-    """`HILC_RVQ_VALU=1` (read once per process by the library) keeps batches of 8 192 frames and more on the VALU form with 16 frames
-    per workgroup — the operator's switch should an fp32 MFMA ever stop being a sequential fmaf chain.  A child process with the
-    variable set must print the index / q checksums this process gets on the matrix pipe."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import torch, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "from hilcodec_amd import fold, ops, synth\n"
-        "from tests.test_gpu_rvq import make_codebooks\n"
-        "dev = torch.device('cuda:0'); nq, D, B, Tn = 8, 128, 120, 75\n"
-        "sd = make_codebooks(23, nq)\n"
-        "z = torch.from_numpy(synth.normalish(4242, B * D * Tn)).view(B, D, Tn)\n"
-        "z = torch.nn.functional.normalize(z, dim=1) * D ** 0.5\n"
-        "cb, cbt, norms = [t.to(dev) for t in fold.codebook_tables([sd[f'quantizer.layers.{i}.embed'] for i in range(nq)])]\n"
-        "idx, q, loss = ops.rvq_encode(z.to(dev), cb, cbt, norms, nq, want_loss=True)\n"
-        "w = torch.arange(idx.numel(), device=dev, dtype=torch.int64).view_as(idx) %% 8191 + 1\n"
-        "print('CHK', int((idx * w).sum()), q.double().sum().item().hex(), float(loss).hex())\n"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for env_extra in ({}, {"HILC_RVQ_VALU": "1"}):
-        env = dict(os.environ, **env_extra)
-        env.pop("HILC_RVQ_VALU", None) if not env_extra else None
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([l for l in r.stdout.splitlines() if l.startswith("CHK")][-1])
-    assert outs[0] == outs[1], outs
+    """`flags = HILC_RVQ_VALU_ONLY` (ABI 15; `ops.rvq_encode(valu_only=True)`, the quantiser modules' `rvq_valu_only` attribute) keeps
+    batches of 8 192 frames and more on the VALU form with 16 frames per workgroup — the caller's switch should an fp32 MFMA ever
+    stop being a sequential fmaf chain.  Same process, same inputs: indices, q and loss equal the matrix-pipe form's bit for bit
+    (uniform and per-clip stage counts), and the module attribute reaches the launch."""
+    from hilcodec_amd import fold, ops
+    from hilcodec_amd.models.hilcodec.vector_quantize import ResidualVQ
+    dev = torch.device("cuda:0")
+    nq, D, B, Tn = 8, 128, 120, 75
+    sd = make_codebooks(23, nq)
+    z = torch.from_numpy(synth.normalish(4242, B * D * Tn)).view(B, D, Tn)
+    z = (torch.nn.functional.normalize(z, dim=1) * D ** 0.5).to(dev)
+    cb, cbt, norms = [t.to(dev) for t in fold.codebook_tables([sd[f"quantizer.layers.{i}.embed"] for i in range(nq)])]
+    ns = [1 + (5 * b) % nq for b in range(B)]
+    for n in (nq, ns):
+        a = ops.rvq_encode(z, cb, cbt, norms, n, want_loss=True)
+        b = ops.rvq_encode(z, cb, cbt, norms, n, want_loss=True, valu_only=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and float(a[2]).hex() == float(b[2]).hex()
+    # an unknown flag bit is refused
+    import ctypes
+    from hilcodec_amd import _lib
+    one = ctypes.c_void_p(z.data_ptr())
+    assert _lib.lib.hilc_rvq_encode(one, one, one, one, one, None, None, 1, 128, 4, 1024, 8, 8, 0, 0, 4, None) == -4
+    rvq = ResidualVQ(nq, dim=D, codebook_size=1024).to(dev).eval()
+    for i, l in enumerate(rvq.layers):
+        l.embed.copy_(sd[f"quantizer.layers.{i}.embed"])
+        l.initted = True
+    q0, _, l0, i0 = rvq(z, None, return_indices=True)
+    rvq.rvq_valu_only = True
+    q1, _, l1, i1 = rvq(z, None, return_indices=True)
+    assert torch.equal(i0, i1) and torch.equal(q0, q1) and float(l0).hex() == float(l1).hex()
+    assert torch.equal(i0, ops.rvq_encode(z, cb, cbt, norms, nq)[0])
 
 
 def test_rvq_modules_reference_api():

@@ -54,8 +54,8 @@ for case in range(N):
                 ref = blocks_ref(x, bls, cb)
                 ok = ok and torch.equal(y, ref) and same_caches(ca, cb)
         elif kind == "enc":
-            C, r = rng.choice([(64, 2), (128, 4)]); n = rng.choice([1, 2])
-            T = rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640])
+            C, r = rng.choice([(64, 2), (128, 4), (256, 5), (512, 8)]); n = rng.choice([1, 2])
+            T = rng.choice([8, 16, 32]) if C == 512 else (rng.choice([40, 80, 120, 200]) if C == 256 else rng.choice([4, 8, 40, 120, 160, 164, 320, 324, 640]))
             if T % r or not ops.encoder_stage_supported(C, T, n, r, B):
                 continue
             bls = [block(C, j) for j in range(n)]
@@ -75,7 +75,7 @@ for case in range(N):
                 ref, db_ = ops.dws_conv_stream(y2, wd, dw, db, db_, res=res, stride=r, in_scale=0.7746, in_elu=True)
                 ok = ok and torch.equal(y, ref) and torch.equal(da, db_) and same_caches(ca, cb)
         else:
-            C, r, nmax = rng.choice([(96, 2, 3), (192, 4, 3), (384, 5, 1), (768, 8, 3)]); n = rng.randint(1, nmax)
+            C, r, nmax = rng.choice([(96, 2, 3), (192, 4, 3), (384, 5, 3), (768, 8, 3)]); n = rng.randint(1, nmax)
             Tin = rng.choice([1, 2, 4]) if C == 768 else (rng.choice([4, 8, 12, 16, 24]) if C == 384 else rng.choice([1, 2, 4, 8, 30, 40, 41, 80, 160]))
             T = Tin * r
             if T % 4 or not ops.decoder_stage_supported(C, T, n, r, B):
