@@ -456,10 +456,9 @@ def test_stream_block_options_reach_both_halves():
     # launches of the fused-block kernel per hop: encoder 4 stages x 2 blocks, decoder 4 x 3; without the wide forms the 4 + 6 wide
     # blocks are two GEMM launches each instead.
     assert k_one[:2] == (8, 12) and k_two[:2] == (4, 6), (k_one, k_two)
-    # default: the encoder's C = 64 / 128 stages and the decoder's C = 768 / 192 / 96 stages are ONE launch each (blocks + down- / up-sampling
-    # layer), C = 512 is a chain, C = 256 one launch per block, C = 384: up-sampling layer + first block, then one launch per block.
-    # decoder_stage_narrow off: C = 384 / 192 / 96 get their up-sampling launch back (C = 192 / 96: + a chain; C = 384: three blocks).
-    assert k_chain[:2] == (3 + 2, 3 + 3) and k_split[:2] == (3 + 2, 1 + 3 + 1 + 1) and k_split[2] - k_chain[2] == 3, (k_chain, k_split)
+    # default (round 6): every encoder and every decoder stage is ONE launch (blocks + down- / up-sampling layer; the wide ones — C = 256 / 512,
+    # C = 768 / 384 — in the narrow-tile shapes).  decoder_stage_narrow off: C = 192 / 96 get their up-sampling launch back (+ a chain each).
+    assert k_chain[:2] == (4, 4) and k_split[:2] == (4, 4) and k_split[2] - k_chain[2] == 2, (k_chain, k_split)
     for ref, other in ((chained, one), (chained, two), (chained, inline), (chained, split)):
         for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
             assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
