@@ -42,9 +42,9 @@ SIGNATURES = {
     "hilc_decoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_decoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_decoder_stage_post_supported": [_i, _i, _i, _i, _i],
-    "hilc_decoder_stage_post": [_p, _p, _i, _p, _i, _i, _i, _p],
-    "hilc_encoder_stage0_supported": [_i, _i, _i, _i, _i, _i],
-    "hilc_encoder_stage0": [_p, _p, _i, _p, _i, _i, _p],
+    "hilc_decoder_stage_post": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "hilc_encoder_stage0_supported": [_i, _i, _i, _i, _i, _i, _i],
+    "hilc_encoder_stage0": [_p, _p, _i, _p, _i, _i, _i, _p],
     "hilc_encoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_encoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_resblock_stream": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
@@ -102,13 +102,15 @@ class UpParams(C.Structure):
 class Spec0Params(C.Structure):
     """`hilc_spec0_params` of include/hilcodec_amd.h: first conv + stage-0 SpecBlock as the opening phase of hilc_encoder_stage0"""
     _fields_ = [("wav", _p), ("dft_packed", _p), ("nyq_sin", _p), ("pw_packed", _p), ("bias", _p), ("pre_w", _p), ("pre_b", _p),
+                ("hist", _p), ("hist_len", _i),
                 ("pre_in_scale", _f), ("mean", _f), ("std", _f), ("out_scale", _f), ("normalize", _i), ("n_fft", _i), ("hop", _i),
                 ("pre_ksize", _i)]
 
 
 class PostParams(C.Structure):
     """`hilc_post_params` of include/hilcodec_amd.h: the decoder's closing conv behind its last stage (hilc_decoder_stage_post)"""
-    _fields_ = [("w", _p), ("bias", _p), ("wav", _p), ("in_scale", _f), ("out_scale", _f), ("do_tanh", _i), ("ksize", _i)]
+    _fields_ = [("w", _p), ("bias", _p), ("wav", _p), ("hist", _p), ("hist_out", _p), ("in_scale", _f), ("out_scale", _f), ("do_tanh", _i),
+                ("ksize", _i)]
 
 
 class DownParams(C.Structure):

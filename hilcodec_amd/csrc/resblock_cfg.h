@@ -84,16 +84,19 @@ constexpr int DWS = 12;   // per-row depthwise table in LDS: [w1_0..3 | w1_4, b1
 // as the closing phase of the launch ("Q"): the last block leaves ELU(in_scale * y) in the LDS tile instead of storing y, every lane
 // accumulates its rows' taps over its 4 columns (previous columns: left neighbour or a third carry slot), the row classes' partial sums
 // meet in LDS in a fixed order — the order hilc_conv_post uses, so the two forms agree bit for bit — and 128 threads store the waveform:
-// the stage's [B][C][T] output (2.36 GB at 256 clips) is neither written nor read.  Offline carry form, C = 96.
+// the stage's [B][C][T] output (2.36 GB at 256 clips) is neither written nor read.  Carry form, C = 96: offline, and (round 6) a streaming hop's runs
+// of whole streams — there a stream's first column group takes the conv's cache (the previous hop's last 4 ACTIVATED columns) and its last one leaves the next.
 // SPEC0_: the encoder's FIRST stage with its input computed in the launch ("S" phase, seanet.py:280-286, 220-246, 368-372): per tile the first
 // conv (k = 5, 1 -> 64) and the stage's SpecBlock (STFT n_fft = 64 hop 1 -> log-magnitude -> 1x1 conv) of the waveform segment —
 // hilc_spec_block_conv_pre's arithmetic — produce the x registers; the [B][64][T] tensor between that launch and the stage never exists.
+// STREAM (round 6, runs of whole streams, T >= 128): a tile holds at most one stream start — its waveform segment is then two pieces, each
+// with its own 63 samples of history (the stream's cache in front of t = 0).
 template <int C, bool STREAM, bool SCARRY_ = false, int NB_ = 1, bool W8_ = false, int DR_ = 0, bool POST_ = false, bool SPEC0_ = false>
 struct Cfg {
   static constexpr bool POST = POST_;
   static constexpr bool SPEC0 = SPEC0_;
-  static_assert(!SPEC0_ || (C == 64 && !STREAM && !W8_ && DR_ >= 0), "stage-0 input phase: the offline C = 64 encoder stage (four waves, 128-column tiles)");
-  static_assert(!POST_ || (!STREAM && DR_ <= 0 && C <= 192 && !W8_), "closing conv: the offline carry form of a narrow stage");
+  static_assert(!SPEC0_ || (C == 64 && (!STREAM || SCARRY_) && !W8_ && DR_ >= 0), "stage-0 input phase: the C = 64 encoder stage in the carry form (four waves, 128-column tiles)");
+  static_assert(!POST_ || ((!STREAM || SCARRY_) && DR_ <= 0 && C <= 192 && !W8_), "closing conv: the carry form of a narrow stage (offline, or a hop's runs of whole streams)");
   static constexpr int NB = NB_;
   static constexpr int DR = DR_ > 0 ? DR_ : 0;
   // DR_ < 0: the stage's UP-SAMPLING layer (seanet.py:431-436: [Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C
@@ -207,6 +210,8 @@ struct ResPost {      // the decoder's last layer as the closing phase (POST)
   const float* w;     // [C][5]
   const float* bias;  // [1] or NULL
   float* wav;         // [B][1][T]
+  const float* hist;  // STREAM: [B][C][4] the ACTIVATED last 4 columns of the previous hop (NULL = zeros), and their successor
+  float* hist_out;
   float in_scale, out_scale;
   int do_tanh;
 };
@@ -219,6 +224,8 @@ struct ResSpec0 {     // the encoder's first conv and first SpecBlock as the ope
   const float* bias;  // [64] or NULL
   const float* pre_w; // [64][5]
   const float* pre_b; // [64] or NULL
+  const float* hist;  // STREAM: [B][hist_len] waveform history (the samples before t = 0; NULL = zeros)
+  int hist_len;
   float pre_in_scale, mean, stdv, out_scale;
   int normalize;
 };

@@ -161,30 +161,42 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
 // ---- the encoder's FIRST stage with its input computed in the launch (offline) ------------------------------------------------------------
 // seanet.py:280-286 (first conv), 220-246 (SpecBlock of stage 0), 316-339 (blocks, down-sampling layer): == hilc_spec_block_conv_pre followed by
 // hilc_encoder_stage (C = 64, r = 2), bit for bit; the [B][64][T] tensor between the two never exists (1.57 GB written and read at 256 clips).
-extern "C" int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize) {
-  return nblk >= 1 && nblk <= 2 && stride == 2 && n_fft == 64 && hop == 1 && pre_ksize == 5 && T > 0 && T % 4 == 0;
+// streaming = 1 (ABI 15; streaming.py:490-511): the same for a hop, with the waveform history `spec->hist` in front of every stream's t = 0 and the
+// caches of hilc_encoder_stage(streaming).
+extern "C" int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize, int streaming) {
+  // a hop (ABI 15): runs of whole streams; T >= 128 so that a 128-column tile holds at most one stream start (two waveform pieces)
+  return nblk >= 1 && nblk <= 2 && stride == 2 && n_fft == 64 && hop == 1 && pre_ksize == 5 && T > 0 && T % 4 == 0 && (!streaming || T >= 128);
 }
 
 extern "C" int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
-                                   int B, int T, void* stream) {
+                                   int streaming, int B, int T, void* stream) {
   if (!spec || !blocks || !down) return HILC_ERR_NULL;
   if (!spec->wav || !spec->dft_packed || !spec->nyq_sin || !spec->pw_packed || !spec->pre_w) return HILC_ERR_NULL;
   if (!down->w_lo || !down->w_hi || !down->dw_w || !down->dw_b || !down->y) return HILC_ERR_NULL;
   if (B <= 0 || T <= 0) return HILC_ERR_SHAPE;
-  if (!hilc_encoder_stage0_supported(T, nblk, down->stride, spec->n_fft, spec->hop, spec->pre_ksize)) return HILC_ERR_UNSUPPORTED;
+  if (!hilc_encoder_stage0_supported(T, nblk, down->stride, spec->n_fft, spec->hop, spec->pre_ksize, streaming)) return HILC_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(down->y) & 15) || (reinterpret_cast<uintptr_t>(down->res) & 15) || down->res == down->y) return HILC_ERR_UNSUPPORTED;
+  if (streaming) {
+    if ((reinterpret_cast<uintptr_t>(down->hist) & 15) || (reinterpret_cast<uintptr_t>(down->hist_out) & 15)) return HILC_ERR_UNSUPPORTED;
+    if (down->hist && down->hist == down->hist_out) return HILC_ERR_UNSUPPORTED;
+    if ((long)B * 128 * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;            // 32-bit flat column index / byte offsets
+    if (spec->hist != nullptr && spec->hist_len < spec->n_fft - 1) return HILC_ERR_SHAPE;
+  }
   ResArgs a;
   a.x = spec->wav; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
   a.post = ResPost{};
   ResDown& d = a.dn;
-  d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b; d.hist = nullptr; d.hist_out = nullptr;
+  d.w_lo = down->w_lo; d.w_hi = down->w_hi; d.dw_w = down->dw_w; d.dw_b = down->dw_b;
+  d.hist = streaming ? down->hist : nullptr; d.hist_out = streaming ? down->hist_out : nullptr;
   d.res = down->res; d.y = down->y; d.in_scale = down->in_scale;
   ResSpec0& sp = a.spec;
+  sp.hist = streaming ? spec->hist : nullptr; sp.hist_len = streaming ? spec->hist_len : 0;
   sp.wav = spec->wav; sp.dft = spec->dft_packed; sp.nyq = spec->nyq_sin; sp.pw = spec->pw_packed; sp.bias = spec->bias;
   sp.pre_w = spec->pre_w; sp.pre_b = spec->pre_b; sp.pre_in_scale = spec->pre_in_scale; sp.mean = spec->mean; sp.stdv = spec->std;
   sp.out_scale = spec->out_scale; sp.normalize = spec->normalize;
+  if (streaming) return launch_chain<64, true, 2, false, 2, false, true>(a, B, (hipStream_t)stream);
   return launch_chain<64, false, 2, false, 2, false, true>(a, B, (hipStream_t)stream);
 }
 
@@ -216,18 +228,23 @@ extern "C" int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_
 // seanet.py:453-476 (`[Scale, ELU, SConv1d(C, 1, k = 5)]`, then the model's out_scale / tanh) behind the stage of hilc_decoder_stage: the
 // last block leaves ELU(in_scale * y) in the LDS tile and the launch stores the waveform `[B][1][T]` — the stage's `[B][C][T]` output is
 // never written.  == hilc_decoder_stage followed by hilc_conv_post (k = 5), bit for bit (same row classes, same order of the partial sums).
-// Offline model, C = 96 with r = 2 and three blocks (the hil_speech / hil_music decoders' last stage).
+// C = 96 with r = 2 and three blocks (the hil_speech / hil_music decoders' last stage): the offline model, and (ABI 15) a streaming hop —
+// streaming.py:639-648 — whose closing conv takes its cache `post->hist` [B][C][4] (the previous hop's last 4 ACTIVATED columns, as
+// hilc_conv_post's) at a stream's t = 0 and leaves `post->hist_out`.
 extern "C" int hilc_decoder_stage_post_supported(int C, int T, int nblk, int stride, int ksize) {
   return C == 96 && stride == 2 && nblk == 3 && ksize == 5 && T > 0 && T % 4 == 0;
 }
 
 extern "C" int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, const hilc_post_params* post,
-                                       int B, int C, int T, void* stream) {
+                                       int streaming, int B, int C, int T, void* stream) {
   if (!post || !post->w || !post->wav) return HILC_ERR_NULL;
   if (!up) return HILC_ERR_NULL;
   if (!hilc_decoder_stage_post_supported(C, T, nblk, up->stride, post->ksize)) return HILC_ERR_UNSUPPORTED;
-  if (reinterpret_cast<uintptr_t>(post->wav) & 15) return HILC_ERR_UNSUPPORTED;
-  return decoder_stage_entry(up, blocks, nblk, post->wav, post, 0, B, C, T, stream);
+  if ((reinterpret_cast<uintptr_t>(post->wav) & 15) || (reinterpret_cast<uintptr_t>(post->hist) & 15) ||
+      (reinterpret_cast<uintptr_t>(post->hist_out) & 15))
+    return HILC_ERR_UNSUPPORTED;
+  if (streaming && post->hist && post->hist == post->hist_out) return HILC_ERR_UNSUPPORTED;
+  return decoder_stage_entry(up, blocks, nblk, post->wav, post, streaming, B, C, T, stream);
 }
 
 namespace {
@@ -253,7 +270,9 @@ int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* bl
   if (post != nullptr) {
     a.post.w = post->w; a.post.bias = post->bias; a.post.wav = post->wav; a.post.in_scale = post->in_scale;
     a.post.out_scale = post->out_scale; a.post.do_tanh = post->do_tanh;
-    return launch_chain<96, false, 3, false, -2, true>(a, B, s);
+    a.post.hist = streaming ? post->hist : nullptr;
+    a.post.hist_out = streaming ? post->hist_out : nullptr;
+    return streaming ? launch_chain<96, true, 3, false, -2, true>(a, B, s) : launch_chain<96, false, 3, false, -2, true>(a, B, s);
   }
   if (streaming) {
     switch (C) {

@@ -52,8 +52,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   __shared__ __attribute__((aligned(16))) float PR[POST ? POST_CLASSES * K::NCOL : 4];
   static_assert(!POST || (K::RPI * K::NW == POST_CLASSES), "a row class of the closing conv = the rows one half-wave walks");
   // SPEC0: the tile's waveform segment (127 + 64 samples) and the same scaled for the first conv
-  __shared__ __attribute__((aligned(16))) float SEG[SPEC0 ? 192 : 4];
-  __shared__ __attribute__((aligned(16))) float SEGS[SPEC0 ? 192 : 4];
+  __shared__ __attribute__((aligned(16))) float SEG[SPEC0 ? (STREAM ? 256 : 192) : 4];     // (STREAM: two pieces, 63 + split and 63 + 128 - split samples)
+  __shared__ __attribute__((aligned(16))) float SEGS[SPEC0 ? (STREAM ? 256 : 192) : 4];
   float* const X = Xbuf + 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar loads below
@@ -464,6 +464,31 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
       //      fmaf chains and roundings: bit-identical; the result goes to the x registers instead of HBM.
       const ResSpec0& sp = a.spec;
       constexpr int N = 64, NBIN = 33, SROWS = 40, KP0 = 4, DEPTH0 = 2;
+      // STREAM: frames are flat columns; a tile that holds a stream's t = 0 at local column `split` (T >= 128: at most one, and a run
+      // starts on one: split = 0 never occurs with a predecessor) stages TWO pieces — the first stream's last samples, then the
+      // second stream's 63 samples of history and its first 128 - split samples — and a column right of the split reads 63 further on.
+      [[maybe_unused]] int split = K::NCOL;
+      if constexpr (STREAM) {
+        const int F0 = (int)tile * TO;
+        const unsigned bA = __umulhi((unsigned)F0, a.div_magic) >> a.div_shift;
+        const int tA0 = F0 - (int)bA * T;
+        const int nxt = T - tA0;                               // columns until the next stream's t = 0
+        split = nxt < K::NCOL ? nxt : K::NCOL;
+        const int lenA = (N - 1) + split;
+        for (int i = tid; i < 2 * (N - 1) + K::NCOL; i += NT) {
+          const bool second = i >= lenA;
+          const unsigned b = bA + (second ? 1u : 0u);
+          const int t = second ? i - lenA - (N - 1) : tA0 - (N - 1) + i;
+          float v = 0.f;
+          if (b < (unsigned)a.B) {
+            if (t >= 0) v = sp.wav[(long)b * T + t];
+            else if (sp.hist != nullptr && t >= -sp.hist_len) v = sp.hist[(long)b * sp.hist_len + sp.hist_len + t];
+          }
+          SEG[i] = v;
+          SEGS[i] = v * sp.pre_in_scale;
+        }
+        for (int i = tid; i < (SROWS - NBIN) * 128; i += NT) X[(NBIN + (i >> 7)) * XS + (i & 127)] = 0.f;   // zero rows of the conv's padded K
+      } else {
       const int f0 = cs.t - c4;                              // the tile's first frame (offline: cs.t = f0 + c4 for every lane)
       {
         const int s0 = f0 - (N - 1);
@@ -476,19 +501,21 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         }
         for (int i = tid; i < (SROWS - NBIN) * 128; i += NT) X[(NBIN + (i >> 7)) * XS + (i & 127)] = 0.f;   // zero rows of the conv's padded K
       }
+      }
       lds_barrier();
       const int kh = lane >> 5, col = colblk * 32 + (lane & 31);
+      const int colx = col + ((STREAM && col >= split) ? N - 1 : 0);      // this column's window starts here in SEG
       f32x16 acc[CBW];
       {
         int off[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) off[p] = col + 2 * p + kh;
+        for (int p = 0; p < 8; ++p) off[p] = colx + 2 * p + kh;
         auto bop = [&](int P) -> float { return SEG[off[P & 7] + 16 * (P >> 3)]; };
         stream_gemm<CBW, KP0, DEPTH0, N / 2 / KP0>(sp.dft, acc, lane, bop);
       }
       float nyq_im = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < N; ++k) nyq_im = fmaf(sp.nyq[k], SEG[col + k], nyq_im);
+      for (int k = 0; k < N; ++k) nyq_im = fmaf(sp.nyq[k], SEG[colx + k], nyq_im);
       const SpecFinish finish = SpecFinish::make(sp.mean, sp.stdv, sp.normalize);
 #pragma unroll
       for (int i = 0; i < CBW; ++i) {
@@ -520,8 +547,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         lptr_t xp = (lptr_t)(X + rsub * XS + c4);
         // column c of the tile is time f0 + c = segment sample c + N - 1: the first conv's taps read samples c + N - 5 .. c + N - 1
         float sm[8];
+        const int c4x = c4 + ((STREAM && c4 >= split) ? N - 1 : 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sm[j] = SEGS[c4 + j + N - 5];
+        for (int j = 0; j < 8; ++j) sm[j] = SEGS[c4x + j + N - 5];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
           const int m = rsub + RSTEP * i;
@@ -800,6 +828,20 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
       lptr_t xq = (lptr_t)(X + rsub * XS + c4);
       lptr_t pq = lane0 ? (lptr_t)(X + rsub * XS + PSLOT) : (lptr_t)(X + rsub * XS + c4 - 4);
       const float* wq = a.post.w + rsub * 5;
+      // STREAM: a stream's first group takes the 4 columns in front of t = 0 from the conv's cache [B][C][4] (activated samples; zeros
+      // without one), its last group leaves the next hop's.  Only tiles that hold a stream's t = 0 pay the cache loads (uniform test).
+      [[maybe_unused]] bool any_head = false;
+      [[maybe_unused]] const float* hq = a.post.w;
+      [[maybe_unused]] float* hqo = nullptr;
+      [[maybe_unused]] bool qtail = false;
+      if constexpr (STREAM) {
+        const int first = (int)tile * TO, last = first + K::NCOL - 1;
+        const unsigned bl = __umulhi((unsigned)last, a.div_magic) >> a.div_shift;      // stream of the tile's last column
+        any_head = (int)bl * T >= first || first % T == 0;                              // a stream starts inside this tile
+        if (a.post.hist != nullptr) hq = a.post.hist + cs.hoff + rsub * 4;             // (hoff = 0 outside the tensor: a valid address for every lane)
+        qtail = cs.tail && !warm && a.post.hist_out != nullptr;
+        if (a.post.hist_out != nullptr) hqo = a.post.hist_out + cs.hoff + rsub * 4;
+      }
       // (rolled: unrolled, hipcc hoists every batch's tap loads to the top of the phase — 60 registers, spills)
 #pragma nounroll
       for (int i0 = 0; i0 < RW; i0 += RB) {
@@ -813,6 +855,24 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
           for (int j = 0; j < 5; ++j) w[i][j] = wq[i * RSTEP * 5 + j];
         }
         wq += RB * RSTEP * 5;
+        if constexpr (STREAM) {
+          if (any_head) {
+            f32x4 hv[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+              hv[i] = a.post.hist != nullptr ? *reinterpret_cast<const f32x4*>(hq + i * RSTEP * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) prev[i][e] = cs.head ? hv[i][e] : prev[i][e];
+          }
+          if (qtail) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(hqo + i * RSTEP * 4) = cur[i];
+          }
+          hq += a.post.hist != nullptr ? RB * RSTEP * 4 : 0;
+          hqo += RB * RSTEP * 4;
+        }
         if (lane_last) {
 #pragma unroll
           for (int i = 0; i < RB; ++i) *(lvec_t)(xq + i * RSTEP * XS + 4 + 8 * NB) = cur[i];
@@ -839,8 +899,13 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         if (a.post.bias != nullptr) sacc = __fadd_rn(sacc, a.post.bias[0]);
         sacc = __fmul_rn(sacc, a.post.out_scale);
         if (a.post.do_tanh) sacc = tanhf(sacc);
-        const int t = cs.t - c4 + tid;                         // offline: cs.t = the tile's first column + c4
-        if (!warm && t < T) a.post.wav[cs.b * (long)T + t] = sacc;
+        if constexpr (STREAM) {
+          const long flat = (long)tile * TO + tid;               // [B][1][T] is the flat column space itself
+          if (!warm && flat < (long)a.B * T) a.post.wav[flat] = sacc;
+        } else {
+          const int t = cs.t - c4 + tid;                         // offline: cs.t = the tile's first column + c4
+          if (!warm && t < T) a.post.wav[cs.b * (long)T + t] = sacc;
+        }
       }
       cs = cn;             // (PR is next written seven barriers from here)
     }

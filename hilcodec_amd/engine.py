@@ -468,19 +468,21 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                 and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2])
                 and (wav_hist is None or wav_hist.shape[-1] >= 63))
     st0 = es.stages[0]
-    fuse_stage0 = (fuse_pre and not streaming and FUSE_RESBLOCK and opts.stage_launches and st0.down_lo is not None and st0.down_dw_b is not None
+    fuse_stage0 = (fuse_pre and (not streaming or FUSE_STREAM) and FUSE_RESBLOCK and opts.stage_launches and st0.down_lo is not None and st0.down_dw_b is not None
                    and st0.down_dw_w.shape[1] == 2 * st0.ratio and wav.shape[2] % st0.ratio == 0
                    and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                            and rb.dw2_b is not None for rb in st0.blocks)
-                   and ops.encoder_stage0_supported(wav.shape[2], len(st0.blocks), st0.ratio, 64, 1, es.pre_w.shape[1]))
-    if fuse_stage0:
+                   and ops.encoder_stage0_supported(wav.shape[2], len(st0.blocks), st0.ratio, 64, 1, es.pre_w.shape[1], wav.shape[0], streaming))
+    blocks0 = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st0.blocks] if fuse_stage0 else None
+    if fuse_stage0 and not streaming:
         # first conv + first SpecBlock + the whole first stage in one launch: neither the [64 x T] tensor in front of the stage nor the one
         # behind its blocks ever exists
         x = ops.encoder_stage0(
             wav, (sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b, es.pre_in_scale, sb0.mean, sb0.std, sb0.normalize,
                   sb0.out_scale),
-            [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st0.blocks],
-            (st0.down_lo, st0.down_hi, st0.down_dw_w, st0.down_dw_b, st0.down_in_scale, st0.ratio))
+            blocks0, (st0.down_lo, st0.down_hi, st0.down_dw_w, st0.down_dw_b, st0.down_in_scale, st0.ratio))
+    elif fuse_stage0:
+        x = None      # launched below, once the side branch that computes stage 1's SpecBlock has been forked
     elif fuse_pre:
         # first conv + first SpecBlock in one launch: the [64 x T] tensor between them never exists
         x = ops.spec_block_conv_pre(wav, sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b,
@@ -508,6 +510,20 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
 
     for si, st in enumerate(es.stages):
         if fuse_stage0 and si == 0:
+            if streaming:
+                # a hop's first conv + first SpecBlock + first stage (streaming.py:490-511) in one launch, with the waveform cache in front
+                # of every stream's t = 0, the blocks' caches and the down-sampling layer's
+                nb0 = len(st.blocks)
+                x, cs_, c = ops.encoder_stage0(
+                    wav, (sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b, es.pre_in_scale, sb0.mean, sb0.std,
+                          sb0.normalize, sb0.out_scale),
+                    blocks0, (st.down_lo, st.down_hi, st.down_dw_w, st.down_dw_b, st.down_in_scale, st.ratio),
+                    res=branch_of(later[0]) if defer else None,
+                    hist=[caches[ci + 2 * i: ci + 2 * i + 2] for i in range(nb0)],
+                    hist_out=[caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(nb0)] if caches_out is not None else None,
+                    down_hist=caches[ci + 2 * nb0], down_hist_out=out(ci + 2 * nb0), wav_hist=wav_hist)
+                new_caches.extend(cs_)
+                new_caches.append(c)
             ci += 2 * len(st.blocks) + 1
             continue
         if not (fuse_pre and si == 0) and not (defer and si > 0):
@@ -609,6 +625,21 @@ def run_decoder(ds: DecoderSpec, q: Tensor, caches: Optional[Sequence[Tensor]] =
             # (C = 384: the up-sampling layer and the FIRST block; the other two follow as launches of their own)
             nb = _stage_fusable_blocks(st, x, True, opts.decoder_stage_narrow)
             up_w = st.tr_w if st.taps is None else st.taps
+            if (st is ds.stages[-1] and nb == len(st.blocks) and ds.post_w.dim() == 2 and ds.post_w.shape[0] == st.pw_wt.shape[1]
+                    and ops.decoder_stage_post_supported(st.pw_wt.shape[1], x.shape[2] * st.ratio, nb, st.ratio, ds.post_w.shape[1])):
+                # the LAST stage and the closing conv (streaming.py:639-648) in one launch: the stage's output — the hop's largest tensor —
+                # is neither written nor read; the conv's cache is read at a stream's t = 0 and written by its last column group
+                cp = ci + 1 + 2 * nb
+                wav, cs_, c, cpost = ops.decoder_stage_post(
+                    x, (up_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
+                    [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks],
+                    (ds.post_w, ds.post_b, ds.post_in_scale, ds.post_out_scale, ds.tanh),
+                    [caches[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)], caches[ci], caches[cp],
+                    [caches_out[ci + 1 + 2 * i: ci + 3 + 2 * i] for i in range(nb)] if caches_out is not None else None, out(ci), out(cp))
+                new_caches.append(c)
+                new_caches.extend(cs_)
+                new_caches.append(cpost)
+                return wav, new_caches
             x, cs_, c = ops.decoder_stage(
                 x, (up_w, st.up_lo, st.up_hi, st.pw_b, st.in_scale, st.ratio),
                 [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks[:nb]],

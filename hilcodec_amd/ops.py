@@ -389,71 +389,92 @@ _register("decoder_stage", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, 
           xin.new_empty(xin.shape[0], xin.shape[1] // 2, xin.shape[2] * stride))
 
 
-def _encoder_stage0(wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, pre_scales,
-                    out_scales, w_lo, w_hi, ddw_w, ddw_b, dres, in_scale, stride):
+def _encoder_stage0(wav, wav_hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, hist_in,
+                    hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale, stride):
     import ctypes
     from ._lib import DownParams, ResblockParams, Spec0Params
     B, one, T = wav.shape
     Cc, k = pre_w.shape
     n = len(pre_scales)
+    streaming = dhist_out is not None
     if one != 1 or Cc != 64 or len(params) != 6 * n or len(out_scales) != n or T % stride != 0:
         raise RuntimeError("encoder_stage0: wav [B,1,T], a 64-channel first conv, 6 parameter tensors per block, T a multiple of the stride")
+    if len(hist_in) != (2 * n if streaming else 0) or len(hist_out) != len(hist_in):
+        raise RuntimeError("encoder_stage0: (streaming) 2 caches in and 2 caches out per block")
+    if wav_hist is not None and (wav_hist.shape[0] != B or wav_hist.numel() // B < 63):
+        raise RuntimeError(f"encoder_stage0: the waveform history must be [{B},1,>=63], got {tuple(wav_hist.shape)}")
     blocks = (ResblockParams * n)()
     for i in range(n):
         w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
-        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), None, None, None, None,
+        h = [_ptr(t) for t in (hist_in[2 * i], hist_in[2 * i + 1], hist_out[2 * i], hist_out[2 * i + 1])] if streaming else [None] * 4
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
                                    float(pre_scales[i]), float(out_scales[i]))
     To = T // stride
-    if dres is not None and tuple(dres.shape) != (B, 2 * Cc, To):
-        raise RuntimeError(f"encoder_stage0: res must be {(B, 2 * Cc, To)}, got {tuple(dres.shape)}")
+    for t, shape in ((dhist, (B, 2 * Cc, stride)), (dhist_out, (B, 2 * Cc, stride)), (dres, (B, 2 * Cc, To))):
+        if t is not None and tuple(t.shape) != shape:
+            raise RuntimeError(f"encoder_stage0: expected {shape}, got {tuple(t.shape)}")
     y = torch.empty(B, 2 * Cc, To, device=wav.device, dtype=torch.float32)
+    wh = wav_hist.reshape(B, -1) if wav_hist is not None else None
     spec = Spec0Params(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(pre_w), _ptr(pre_b),
-                       float(pre_in_scale), float(mean), float(std), float(out_scale), int(normalize), 64, 1, int(k))
-    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), None, None, _ptr(dres), _ptr(y), float(in_scale), int(stride))
+                       _ptr(wh), int(wh.shape[1]) if wh is not None else 0, float(pre_in_scale),
+                       float(mean), float(std), float(out_scale), int(normalize), 64, 1, int(pre_w.shape[1]))
+    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y), float(in_scale), int(stride))
     work = 2.0 * B * T * 64 * (64 + 1 + 32 + 1) + 2.0 * B * T * Cc * k + 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc
-    with _timed("resblock", work, f"C{Cc} T{T} conv_pre + spec N64 + stage x{n} + down s{stride}"):
+    with _timed("resblock", work, f"C{Cc} T{T}" + (" stream" if streaming else "") + f" conv_pre + spec N64 + stage x{n} + down s{stride}"):
         check(lib.hilc_encoder_stage0(ctypes.cast(ctypes.pointer(spec), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n,
-                                      ctypes.cast(ctypes.pointer(down), ctypes.c_void_p), B, T, _stream()), "hilc_encoder_stage0")
+                                      ctypes.cast(ctypes.pointer(down), ctypes.c_void_p), int(streaming), B, T, _stream()), "hilc_encoder_stage0")
     return y
 
 
-_register("encoder_stage0", "(Tensor wav, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor pre_w, Tensor? pre_b, "
-          "float pre_in_scale, float mean, float std, int normalize, float out_scale, Tensor[] params, float[] pre_scales, float[] out_scales, "
-          "Tensor w_lo, Tensor w_hi, Tensor ddw_w, Tensor ddw_b, Tensor? dres, float in_scale, int stride) -> Tensor", _encoder_stage0,
-          lambda wav, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, pre_scales,
-          out_scales, w_lo, w_hi, ddw_w, ddw_b, dres, in_scale, stride: wav.new_empty(wav.shape[0], 2 * pre_w.shape[0], wav.shape[2] // stride))
+_register("encoder_stage0", "(Tensor wav, Tensor? wav_hist, Tensor dft_packed, Tensor nyq_sin, Tensor pw_packed, Tensor? bias, Tensor pre_w, Tensor? pre_b, "
+          "float pre_in_scale, float mean, float std, int normalize, float out_scale, Tensor[] params, Tensor[] hist_in, Tensor(a!)[] hist_out, "
+          "float[] pre_scales, float[] out_scales, Tensor w_lo, Tensor w_hi, Tensor ddw_w, Tensor ddw_b, Tensor? dhist, Tensor(b!)? dhist_out, "
+          "Tensor? dres, float in_scale, int stride) -> Tensor", _encoder_stage0,
+          lambda wav, wav_hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, pre_in_scale, mean, std, normalize, out_scale, params, hist_in,
+          hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale, stride:
+          wav.new_empty(wav.shape[0], 2 * pre_w.shape[0], wav.shape[2] // stride))
 
 
-def _decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, in_scale, stride, params, pre_scales, out_scales, post_w, post_b, post_in_scale,
-                        post_out_scale, do_tanh):
+def _decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, uhist, uhist_out, in_scale, stride, params, hist_in, hist_out, pre_scales, out_scales,
+                        post_w, post_b, post_hist, post_hist_out, post_in_scale, post_out_scale, do_tanh):
     import ctypes
     from ._lib import PostParams, ResblockParams, UpParams
     B, K2, Tin = xin.shape
     Cc, T = K2 // 2, Tin * stride
     n = len(pre_scales)
-    if len(params) != 6 * n or len(out_scales) != n:
-        raise RuntimeError("decoder_stage_post: 6 parameter tensors per block")
+    streaming = len(hist_in) > 0 or uhist_out is not None or post_hist_out is not None      # no caches at all: the offline causal model
+    if len(params) != 6 * n or len(out_scales) != n or len(hist_in) != (2 * n if streaming else 0) or len(hist_out) != len(hist_in):
+        raise RuntimeError("decoder_stage_post: 6 parameter tensors per block, and (streaming) 2 caches in and 2 caches out per block")
     if post_w.dim() != 2 or post_w.shape[0] != Cc:
         raise RuntimeError(f"decoder_stage_post: the closing conv's taps must be [{Cc}, k], got {tuple(post_w.shape)}")
+    for h in (uhist, uhist_out):
+        if h is not None and h.numel() != B * K2:
+            raise RuntimeError(f"decoder_stage_post: the up-sampling cache must be [{B},{K2},1], got {tuple(h.shape)}")
+    for h in (post_hist, post_hist_out):
+        if h is not None and tuple(h.shape) != (B, Cc, post_w.shape[1] - 1):
+            raise RuntimeError(f"decoder_stage_post: the closing conv's cache must be [{B},{Cc},{post_w.shape[1] - 1}], got {tuple(h.shape)}")
     blocks = (ResblockParams * n)()
     for i in range(n):
         w1p, d1w, d1b, w2p, d2w, d2b = params[6 * i:6 * i + 6]
-        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), None, None, None, None,
+        h = [_ptr(t) for t in (hist_in[2 * i], hist_in[2 * i + 1], hist_out[2 * i], hist_out[2 * i + 1])] if streaming else [None] * 4
+        blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
                                    float(pre_scales[i]), float(out_scales[i]))
-    up = UpParams(_ptr(xin), _ptr(tr_w), _ptr(w_lo), _ptr(w_hi), _ptr(bias), None, None, float(in_scale), int(stride))
+    up = UpParams(_ptr(xin), _ptr(tr_w), _ptr(w_lo), _ptr(w_hi), _ptr(bias), _ptr(uhist), _ptr(uhist_out), float(in_scale), int(stride))
     wav = torch.empty(B, 1, T, device=xin.device, dtype=torch.float32)
-    post = PostParams(_ptr(post_w), _ptr(post_b), _ptr(wav), float(post_in_scale), float(post_out_scale), int(do_tanh), int(post_w.shape[1]))
-    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T} up r{stride} + stage x{n} + conv_post"):
+    post = PostParams(_ptr(post_w), _ptr(post_b), _ptr(wav), _ptr(post_hist), _ptr(post_hist_out), float(post_in_scale), float(post_out_scale),
+                      int(do_tanh), int(post_w.shape[1]))
+    with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, f"C{Cc} T{T}" + (" stream" if streaming else "") + f" up r{stride} + stage x{n} + conv_post"):
         check(lib.hilc_decoder_stage_post(ctypes.cast(ctypes.pointer(up), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n,
-                                          ctypes.cast(ctypes.pointer(post), ctypes.c_void_p), B, Cc, T, _stream()), "hilc_decoder_stage_post")
+                                          ctypes.cast(ctypes.pointer(post), ctypes.c_void_p), int(streaming), B, Cc, T, _stream()), "hilc_decoder_stage_post")
     return wav
 
 
-_register("decoder_stage_post", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, Tensor? bias, float in_scale, int stride, Tensor[] params, "
-          "float[] pre_scales, float[] out_scales, Tensor post_w, Tensor? post_b, float post_in_scale, float post_out_scale, bool do_tanh) -> Tensor",
+_register("decoder_stage_post", "(Tensor xin, Tensor tr_w, Tensor w_lo, Tensor w_hi, Tensor? bias, Tensor? uhist, Tensor(a!)? uhist_out, float in_scale, "
+          "int stride, Tensor[] params, Tensor[] hist_in, Tensor(b!)[] hist_out, float[] pre_scales, float[] out_scales, Tensor post_w, Tensor? post_b, "
+          "Tensor? post_hist, Tensor(c!)? post_hist_out, float post_in_scale, float post_out_scale, bool do_tanh) -> Tensor",
           _decoder_stage_post,
-          lambda xin, tr_w, w_lo, w_hi, bias, in_scale, stride, params, pre_scales, out_scales, post_w, post_b, post_in_scale, post_out_scale, do_tanh:
-          xin.new_empty(xin.shape[0], 1, xin.shape[2] * stride))
+          lambda xin, tr_w, w_lo, w_hi, bias, uhist, uhist_out, in_scale, stride, params, hist_in, hist_out, pre_scales, out_scales, post_w, post_b,
+          post_hist, post_hist_out, post_in_scale, post_out_scale, do_tanh: xin.new_empty(xin.shape[0], 1, xin.shape[2] * stride))
 
 
 def _resblock_pack_rc(wt, row_classes):
@@ -908,25 +929,41 @@ def decoder_stage(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], hist: O
     return y, hout, uout
 
 
-def encoder_stage0_supported(T: int, nblk: int, stride: int, n_fft: int, hop: int, pre_ksize: int) -> bool:
-    """mirror of hilc_encoder_stage0_supported: the offline encoder's FIRST stage with the first conv and its SpecBlock in the same launch"""
-    return 1 <= nblk <= 2 and stride == 2 and n_fft == 64 and hop == 1 and pre_ksize == 5 and T > 0 and T % 4 == 0
+def encoder_stage0_supported(T: int, nblk: int, stride: int, n_fft: int, hop: int, pre_ksize: int, B: int = 1, streaming: bool = False) -> bool:
+    """mirror of hilc_encoder_stage0_supported: the encoder's FIRST stage with the first conv and its SpecBlock in the same launch (a hop: T >= 128
+    so that a tile holds at most one stream start, and the 32-bit offsets of the streaming form)"""
+    if not (1 <= nblk <= 2 and stride == 2 and n_fft == 64 and hop == 1 and pre_ksize == 5 and T > 0 and T % 4 == 0):
+        return False
+    return not streaming or (T >= 128 and B * 128 * T * 4 < (1 << 32))
 
 
-def encoder_stage0(wav: Tensor, spec: Sequence, blocks: Sequence[Sequence], down: Sequence, res: Optional[Tensor] = None) -> Tensor:
-    """The offline encoder's first conv, stage-0 SpecBlock, residual blocks and down-sampling layer in ONE launch (hilc_encoder_stage0):
+def encoder_stage0(wav: Tensor, spec: Sequence, blocks: Sequence[Sequence], down: Sequence, res: Optional[Tensor] = None,
+                   hist: Optional[Sequence[Sequence[Tensor]]] = None, hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None,
+                   down_hist: Optional[Tensor] = None, down_hist_out: Optional[Tensor] = None, wav_hist: Optional[Tensor] = None):
+    """The encoder's first conv, stage-0 SpecBlock, residual blocks and down-sampling layer in ONE launch (hilc_encoder_stage0):
     `spec` = (dft_packed, nyq_sin, pw_packed, bias, pre_w `[64,5]`, pre_b, pre_in_scale, mean, std, normalize, out_scale) as given to
-    `spec_block_conv_pre`; `blocks`, `down`, `res` as in `encoder_stage` (offline).  wav `[B,1,T]` -> `[B,128,T/2]`, equal bit for bit to
-    `encoder_stage(spec_block_conv_pre(wav, ...), blocks, down)`."""
+    `spec_block_conv_pre`; `blocks`, `down`, `res` as in `encoder_stage`.  Offline (hist None): wav `[B,1,T]` -> `[B,128,T/2]`, equal bit for
+    bit to `encoder_stage(spec_block_conv_pre(wav, ...), blocks, down)`.  A streaming hop (round 6): `wav_hist` `[B,1,H >= 63]` = the waveform
+    cache, `hist` / `hist_out` / `down_hist` / `down_hist_out` as in `encoder_stage` -> (y, [block caches...], down cache)."""
     dft, nyq, pw, bias, pre_w, pre_b, pre_in, mean, std, normalize, out_scale = spec
     w_lo, w_hi, ddw_w, ddw_b, in_scale, stride = down
-    params, pre, post = [], [], []
-    for blk in blocks:
+    B, Cc = wav.shape[0], pre_w.shape[0]
+    params, hin, hout, pre, post = [], [], [], [], []
+    for i, blk in enumerate(blocks):
         params.extend(blk[:6])
         pre.append(float(blk[6]))
         post.append(float(blk[7]))
-    return _OPS.encoder_stage0(wav, dft, nyq, pw, bias, pre_w, pre_b, float(pre_in), float(mean), float(std), int(normalize), float(out_scale),
-                               params, pre, post, w_lo, w_hi, ddw_w, ddw_b, res, float(in_scale), int(stride))
+        if hist is not None:
+            hin.extend(hist[i])
+            given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
+            hout.extend([_state_out(given[0], wav, B, Cc, 4), _state_out(given[1], wav, B, Cc, 4)])
+    if hist is None:
+        return _OPS.encoder_stage0(wav, None, dft, nyq, pw, bias, pre_w, pre_b, float(pre_in), float(mean), float(std), int(normalize), float(out_scale),
+                                   params, [], [], pre, post, w_lo, w_hi, ddw_w, ddw_b, None, None, res, float(in_scale), int(stride))
+    dout = _state_out(down_hist_out, wav, B, 2 * Cc, int(stride))
+    y = _OPS.encoder_stage0(wav, wav_hist, dft, nyq, pw, bias, pre_w, pre_b, float(pre_in), float(mean), float(std), int(normalize), float(out_scale),
+                            params, hin, hout, pre, post, w_lo, w_hi, ddw_w, ddw_b, down_hist, dout, res, float(in_scale), int(stride))
+    return y, hout, dout
 
 
 def decoder_stage_post_supported(C: int, T: int, nblk: int, stride: int, ksize: int) -> bool:
@@ -934,19 +971,36 @@ def decoder_stage_post_supported(C: int, T: int, nblk: int, stride: int, ksize: 
     return C == 96 and stride == 2 and nblk == 3 and ksize == 5 and T > 0 and T % 4 == 0
 
 
-def decoder_stage_post(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], post: Sequence) -> Tensor:
-    """The offline decoder's last stage AND its closing layer in ONE launch (hilc_decoder_stage_post): `up`, `blocks` as in
-    `decoder_stage` (offline), `post` = (w `[C,5]`, bias `[1]` or None, in_scale, out_scale, do_tanh) as given to `conv_post`.
-    xin `[B,2C,T/r]` -> wav `[B,1,T]`, equal bit for bit to `conv_post(decoder_stage(...))`."""
+def decoder_stage_post(xin: Tensor, up: Sequence, blocks: Sequence[Sequence], post: Sequence, hist: Optional[Sequence[Sequence[Tensor]]] = None,
+                       up_hist: Optional[Tensor] = None, post_hist: Optional[Tensor] = None,
+                       hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None, up_hist_out: Optional[Tensor] = None,
+                       post_hist_out: Optional[Tensor] = None):
+    """The decoder's last stage AND its closing layer in ONE launch (hilc_decoder_stage_post): `up`, `blocks` as in `decoder_stage`,
+    `post` = (w `[C,5]`, bias `[1]` or None, in_scale, out_scale, do_tanh) as given to `conv_post`.  Offline (hist None):
+    xin `[B,2C,T/r]` -> wav `[B,1,T]`, equal bit for bit to `conv_post(decoder_stage(...))`.  Streaming hop (round 6): `hist` / `up_hist` /
+    `hist_out` / `up_hist_out` as in `decoder_stage`, `post_hist` `[B,C,4]` = the closing conv's cache ->
+    (wav, [block caches...], up-sampling cache, closing conv's cache), equal bit for bit to `decoder_stage` + `conv_post` with the same caches."""
     tr_w, w_lo, w_hi, bias, in_scale, stride = up
-    params, pre, post_s = [], [], []
-    for blk in blocks:
+    B, K2, _ = xin.shape
+    Cc = K2 // 2
+    params, hin, hout, pre, post_s = [], [], [], [], []
+    for i, blk in enumerate(blocks):
         params.extend(blk[:6])
         pre.append(float(blk[6]))
         post_s.append(float(blk[7]))
+        if hist is not None:
+            hin.extend(hist[i])
+            given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
+            hout.extend([_state_out(given[0], xin, B, Cc, 4), _state_out(given[1], xin, B, Cc, 4)])
     pw, pb, p_in, p_out, p_tanh = post
-    return _OPS.decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, float(in_scale), int(stride), params, pre, post_s, pw, pb, float(p_in),
-                                   float(p_out), bool(p_tanh))
+    if hist is None:
+        return _OPS.decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, None, None, float(in_scale), int(stride), params, [], [], pre, post_s, pw, pb,
+                                       None, None, float(p_in), float(p_out), bool(p_tanh))
+    uout = _state_out(up_hist_out, xin, B, K2, 1)
+    pout = _state_out(post_hist_out, xin, B, Cc, pw.shape[1] - 1)
+    wav = _OPS.decoder_stage_post(xin, tr_w, w_lo, w_hi, bias, up_hist, uout, float(in_scale), int(stride), params, hin, hout, pre, post_s, pw, pb,
+                                  post_hist, pout, float(p_in), float(p_out), bool(p_tanh))
+    return wav, hout, uout, pout
 
 
 def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, streaming: bool = True) -> bool:

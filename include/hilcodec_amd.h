@@ -198,18 +198,23 @@ int hilc_decoder_stage(const hilc_up_params* up, const hilc_resblock_params* blo
  * `seanet.py:453-476`: `[Scale, ELU, SConv1d(C, 1, k = 5, bias)]`, then the model's final scale / tanh — hilc_conv_post — as the closing
  * phase of the hilc_decoder_stage launch of the offline model's last stage (C = 96, r = 2, three blocks): the last block leaves
  * ELU(in_scale * y) in the LDS tile, the launch stores `wav` `[B][1][T]`; the stage's `[B][C][T]` output never reaches HBM.  Equals
- * hilc_decoder_stage followed by hilc_conv_post bit for bit (same row classes c mod 8, same order of the partial sums).  `up->hist`
- * is ignored (offline).  hilc_decoder_stage_post_supported names the shapes; everything else: HILC_ERR_UNSUPPORTED. */
+ * hilc_decoder_stage followed by hilc_conv_post bit for bit (same row classes c mod 8, same order of the partial sums).  streaming = 0:
+ * the offline model (`up->hist`, the blocks' caches and `post->hist` are ignored).  streaming = 1 (ABI 15): a hop (`streaming.py:639-648`) on the
+ * carry form's runs of whole streams, with every cache of hilc_decoder_stage plus the closing conv's — equal, bit for bit, to
+ * hilc_decoder_stage(streaming) followed by hilc_conv_post with the same caches.  hilc_decoder_stage_post_supported names the shapes;
+ * everything else: HILC_ERR_UNSUPPORTED. */
 typedef struct hilc_post_params {
   const float* w;      /* [C][ksize] */
   const float* bias;   /* [1] or NULL */
   float* wav;          /* [B][1][T] */
+  const float* hist;   /* streaming (ABI 15): [B][C][ksize-1] the conv's cache = hilc_conv_post's (activated samples; NULL = zeros) */
+  float* hist_out;     /* streaming: receives the next hop's cache (may be NULL) */
   float in_scale, out_scale;
   int do_tanh, ksize;
 } hilc_post_params;
 int hilc_decoder_stage_post_supported(int C, int T, int nblk, int stride, int ksize);
 int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params* blocks, int nblk, const hilc_post_params* post,
-                            int B, int C, int T, void* stream);
+                            int streaming, int B, int C, int T, void* stream);
 
 /* ---- an ENCODER STAGE in one launch (ABI 11): its residual blocks and its down-sampling layer ------------------------------
  * `seanet.py:316-339` (`self.blocks[i]`, then `self.downsample[i]` = [Scale, ELU, 1x1 conv C -> 2C without bias, depthwise conv
@@ -238,12 +243,14 @@ typedef struct hilc_spec0_params {
   const float* dft_packed; const float* nyq_sin; const float* pw_packed; const float* bias;
   const float* pre_w;       /* [64][5] */
   const float* pre_b;       /* [64] or NULL */
+  const float* hist;        /* streaming (ABI 15): [B][hist_len] waveform history, as hilc_spec_block_conv_pre's (NULL = zeros) */
+  int hist_len;
   float pre_in_scale, mean, std, out_scale;
   int normalize, n_fft, hop, pre_ksize;
 } hilc_spec0_params;
-int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize);
+int hilc_encoder_stage0_supported(int T, int nblk, int stride, int n_fft, int hop, int pre_ksize, int streaming);
 int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down,
-                        int B, int T, void* stream);
+                        int streaming, int B, int T, void* stream);
 
 /* ---- depthwise causal convolution, kernel `ksize`, stride `stride` ----------------------------
  * pad = (ksize-1) - (stride-1);  T_out = ceil(T / stride)

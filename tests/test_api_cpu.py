@@ -67,8 +67,9 @@ def test_error_codes_without_gpu():
                 for r in (2, 4):
                     for k in (5, 7):
                         assert ops.decoder_stage_post_supported(c, t, n, r, k) == bool(lib.hilc_decoder_stage_post_supported(c, t, n, r, k)), (c, t, n, r, k)
-                        assert ops.encoder_stage0_supported(t, n, r, c, 1, k) == bool(lib.hilc_encoder_stage0_supported(t, n, r, c, 1, k)), (t, n, r, c, k)
-    assert lib.hilc_decoder_stage_post(None, None, 3, None, 1, 96, 8, None) == -2 and lib.hilc_encoder_stage0(None, None, 2, None, 1, 8, None) == -2
+                        for st in (0, 1):
+                            assert ops.encoder_stage0_supported(t, n, r, c, 1, k, 1, bool(st)) == bool(lib.hilc_encoder_stage0_supported(t, n, r, c, 1, k, st)), (t, n, r, c, k, st)
+    assert lib.hilc_decoder_stage_post(None, None, 3, None, 0, 1, 96, 8, None) == -2 and lib.hilc_encoder_stage0(None, None, 2, None, 0, 1, 8, None) == -2
     assert lib.hilc_resblock(one, one, one, one, one, one, one, one, 1, 96, 16, 1.0, 1.0, None) == -4  # y aliases x
 
 

@@ -761,6 +761,52 @@ def test_decoder_stage_post_equals_stage_then_conv_post_and_oracle(env, Tin, B):
         close(wav, ref, 2e-5, f"decoder stage + conv_post Tin{Tin} B{B}")
 
 
+@pytest.mark.parametrize("Tin,B", [(160, 5), (160, 1024), (160, 1), (2, 70), (80, 7), (320, 3), (6, 33)])
+def test_decoder_stage_post_streaming_equals_stage_then_conv_post(env, Tin, B):
+    """hilc_decoder_stage_post(streaming = 1), round 6: the LAST decoder stage of a hop (C = 96, r = 2, three blocks; `streaming.py:639-648`) with the
+    closing conv as the closing phase of the launch == hilc_decoder_stage(streaming) followed by hilc_conv_post with the conv's cache, bit for
+    bit over three hops: the waveform, the up-sampling cache, the six block caches and the closing conv's cache — ragged stream counts,
+    hops shorter than a tile, several frames per hop, the full 1 024 streams."""
+    ops, fold, O, dev = env
+    C, r, n = 96, 2, 3
+    T = Tin * r
+    assert ops.decoder_stage_post_supported(C, T, n, r, 5) and ops.decoder_stage_supported(C, T, n, r, B)
+    blocks = []
+    for j in range(n):
+        w1, w2 = (rnd(10 * j + 1, C, C) / C ** 0.5).to(dev), (rnd(10 * j + 4, C, C) / C ** 0.5).to(dev)
+        d1, b1 = (rnd(10 * j + 2, C, 5) * 0.5).to(dev), (rnd(10 * j + 3, C) * 0.2).to(dev)
+        d2, b2 = (rnd(10 * j + 5, C, 5) * 0.5).to(dev), (rnd(10 * j + 6, C) * 0.2).to(dev)
+        blocks.append((ops.resblock_chain_pack(w1), d1, b1, ops.resblock_chain_pack(w2), d2, b2, 1.0, 0.4 + 0.1 * j))
+    tw = (rnd(80, 2 * C, 2 * r) * 0.3).to(dev)
+    wu = (rnd(81, 2 * C, C) / (2 * C) ** 0.5).to(dev)
+    bu = (rnd(82, C) * 0.1).to(dev)
+    up = (tw, ops.resblock_chain_pack(wu[:C].contiguous()), ops.resblock_chain_pack(wu[C:].contiguous()), bu, 0.7071, r)
+    post = ((rnd(83, C, 5) * 0.2).to(dev), (rnd(84, 1) * 0.1).to(dev), 0.5, 0.1122, True)
+    ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
+    cb = [[c.clone() for c in pair] for pair in ca]
+    ua = (rnd(30, B, 2 * C, 1) * 0.6).to(dev)
+    ub = ua.clone()
+    pa = (rnd(31, B, C, 4) * 0.6).to(dev)
+    pb_ = pa.clone()
+    for h in range(3):
+        xin = rnd(100 + h, B, 2 * C, Tin).to(dev)
+        if h == 1:      # caller-owned destinations (the ping-pong state block)
+            outs = [[torch.full_like(c, 9.0) for c in pair] for pair in ca]
+            uo, po = torch.full_like(ua, 9.0), torch.full_like(pa, 9.0)
+            wav, flat, ua, pa = ops.decoder_stage_post(xin, up, blocks, post, ca, ua, pa, hist_out=outs, up_hist_out=uo, post_hist_out=po)
+            assert ua is uo and pa is po and all(flat[2 * j] is outs[j][0] and flat[2 * j + 1] is outs[j][1] for j in range(n))
+        else:
+            wav, flat, ua, pa = ops.decoder_stage_post(xin, up, blocks, post, ca, ua, pa)
+        ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+        y, f2, ub = ops.decoder_stage(xin, up, blocks, cb, ub)
+        cb = [f2[2 * j:2 * j + 2] for j in range(n)]
+        wav2, pb_ = ops.conv_post(y, post[0], post[1], in_scale=0.5, in_elu=True, out_scale=0.1122, do_tanh=True, hist=pb_, want_hist=True)
+        assert wav.shape == (B, 1, T) and torch.equal(wav, wav2), (h, float((wav - wav2).abs().max()))
+        assert torch.equal(ua, ub) and torch.equal(pa, pb_), h
+        for j in range(n):
+            assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
+
+
 @pytest.mark.parametrize("T,B,n", [(24000, 3, 2), (1000, 5, 2), (124, 40, 2), (8, 300, 1), (9280, 24, 2)])
 def test_encoder_stage0_equals_conv_pre_spec_then_stage(env, T, B, n):
     """hilc_encoder_stage0: the offline encoder's first conv and stage-0 SpecBlock (`seanet.py:280-286, 220-246`) as the opening phase of the
@@ -789,6 +835,44 @@ def test_encoder_stage0_equals_conv_pre_spec_then_stage(env, T, B, n):
         x0 = ops.spec_block_conv_pre(wav, dft_p, nyq, pw_p, sb, pre_w, pb, 1 / 0.1122080159, n_fft, 1, -4.0, 2.8, True, 0.37)
         y2 = ops.encoder_stage(x0, blocks, down, res=rs)
         assert y.shape == (B, 2 * C, T // r) and torch.equal(y, y2), float((y - y2).abs().max())
+
+
+@pytest.mark.parametrize("T,B,n", [(320, 5, 2), (320, 1024, 2), (320, 1, 2), (640, 3, 2), (128, 70, 1), (132, 9, 2), (960, 2, 2)])
+def test_encoder_stage0_streaming_equals_conv_pre_spec_then_stage(env, T, B, n):
+    """hilc_encoder_stage0(streaming = 1), round 6: a hop's first conv + stage-0 SpecBlock (`streaming.py:490-497`) as the opening phase of the C = 64
+    stage launch == hilc_spec_block_conv_pre(hist) followed by hilc_encoder_stage(streaming), bit for bit over three hops with the waveform
+    history carried from hop to hop: output, the block caches, the down-sampling cache — tiles that hold a stream's t = 0 (two waveform pieces),
+    ragged stream counts, several frames per hop, hops that are no multiple of the tile, with and without biases / shortcut / history."""
+    ops, fold, O, dev = env
+    C, r, n_fft, H = 64, 2, 64, 1023
+    assert ops.encoder_stage0_supported(T, n, r, 64, 1, 5, B, True) and not ops.encoder_stage0_supported(64, n, r, 64, 1, 5, B, True)
+    basis = synth.stft_basis(n_fft)
+    bt = fold.stft_basis_layout(basis).to(dev)
+    w = rnd(n_fft + 1, C, n_fft // 2 + 1, 1) / (n_fft // 2 + 1) ** 0.5
+    wt = fold.pointwise_layout(w).to(dev)
+    bias = (rnd(n_fft + 2, C) * 0.1).to(dev)
+    dft_p, nyq, pw_p = ops.spec_block_tables(bt, wt, n_fft)
+    pre_w, pre_b = (rnd(71, 64, 5) * 0.5).to(dev), (rnd(72, 64) * 0.1).to(dev)
+    blocks, singles, wd, dw, db, down = _stage_params(ops, dev, C, r, n, True)
+    ca = [[(rnd(7 + j, B, C, 4) * 0.7).to(dev), (rnd(8 + j, B, C, 4) * 0.7).to(dev)] for j in range(n)]
+    cb = [[c.clone() for c in pair] for pair in ca]
+    da = (rnd(30, B, 2 * C, r) * 0.6).to(dev)
+    db_ = da.clone()
+    clip = synth.synth_clips(B, 3 * T + H, seed=T + B).to(dev)
+    for h, (sb, pb, use_res, use_hist) in enumerate(((bias, pre_b, True, True), (None, None, False, True), (bias, None, True, False))):
+        wav = clip[:, :, H + h * T: H + (h + 1) * T].contiguous()
+        hist = clip[:, :, h * T: H + h * T].contiguous() if use_hist else None      # the 1023 samples in front of the hop (spec_post's window)
+        res = (rnd(75 + h, B, 2 * C, T // r) * 0.5).to(dev) if use_res else None
+        spec = (dft_p, nyq, pw_p, sb, pre_w, pb, 1 / 0.1122080159, -4.0, 2.8, True, 0.37)
+        y, flat, da = ops.encoder_stage0(wav, spec, blocks, down, res=res, hist=ca, down_hist=da, wav_hist=hist)
+        ca = [flat[2 * j:2 * j + 2] for j in range(n)]
+        x0 = ops.spec_block_conv_pre(wav, dft_p, nyq, pw_p, sb, pre_w, pb, 1 / 0.1122080159, n_fft, 1, -4.0, 2.8, True, 0.37, hist=hist)
+        y2, f2, db_ = ops.encoder_stage(x0, blocks, down, hist=cb, down_hist=db_, res=res)
+        cb = [f2[2 * j:2 * j + 2] for j in range(n)]
+        assert y.shape == (B, 2 * C, T // r) and torch.equal(y, y2), (h, float((y - y2).abs().max()))
+        assert torch.equal(da, db_), h
+        for j in range(n):
+            assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
 
 
 def test_resblock_chain_shapes_it_does_not_take(env):

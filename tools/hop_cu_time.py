@@ -22,10 +22,7 @@ def tiles_per_wg(name, wgs, streams):
     if not m or m.group(2) != "true":
         return None
     c, scarry = int(m.group(1)), m.group(3) == "true"
-    ncol = 128 if c <= 192 else (32 if c >= 512 else 64)
-    m32 = re.search(r",N32\b", name)
-    if m32:
-        ncol = 32
+    ncol = 128 if c <= 192 else (32 if (c >= 512 or scarry) else 64)       # (C = 256 / 384 in the carry form: 32-column tiles)
     halo = 0 if (scarry or c >= 512) else 8
     to = ncol - halo
     tiles = -(-streams * T_OF_C[c] // to)
