@@ -457,8 +457,9 @@ def test_stream_block_options_reach_both_halves():
     # blocks are two GEMM launches each instead.
     assert k_one[:2] == (8, 12) and k_two[:2] == (4, 6), (k_one, k_two)
     # default (round 6): every encoder and every decoder stage is ONE launch (blocks + down- / up-sampling layer; the wide ones — C = 256 / 512,
-    # C = 768 / 384 — in the narrow-tile shapes).  decoder_stage_narrow off: C = 192 / 96 get their up-sampling launch back (+ a chain each).
-    assert k_chain[:2] == (4, 4) and k_split[:2] == (4, 4) and k_split[2] - k_chain[2] == 2, (k_chain, k_split)
+    # C = 768 / 384 — in the narrow-tile shapes; the first with the first conv and stage 0's SpecBlock as its opening phase, the last with the closing
+    # conv as its closing phase).  decoder_stage_narrow off: C = 192 / 96 get their up-sampling launch back (+ a chain each), and the closing conv its own.
+    assert k_chain[:2] == (4, 4) and k_split[:2] == (4, 4) and k_split[2] - k_chain[2] == 3, (k_chain, k_split)
     for ref, other in ((chained, one), (chained, two), (chained, inline), (chained, split)):
         for (z1, i1, w1), (z2, i2, w2) in zip(ref, other):
             assert torch.equal(z1, z2) and torch.equal(i1, i2) and torch.equal(w1, w2)
