@@ -116,7 +116,7 @@ class PostParams(C.Structure):
 class DownParams(C.Structure):
     """`hilc_down_params` of include/hilcodec_amd.h: the down-sampling layer of an encoder stage launch"""
     _fields_ = [("w_lo", _p), ("w_hi", _p), ("dw_w", _p), ("dw_b", _p), ("hist", _p), ("hist_out", _p), ("res", _p), ("y", _p),
-                ("x_add", _p), ("in_scale", _f), ("stride", _i)]
+                ("in_scale", _f), ("stride", _i)]
 
 
 class HilcodecLibraryError(RuntimeError):

@@ -27,7 +27,7 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
     return HILC_ERR_UNSUPPORTED;             // callers fall back to two hilc_dws_conv launches
   ResArgs a;
   ResBlk& b0 = a.blk[0];
-  a.x = x; a.xadd = nullptr; b0.w1t = w1t; b0.dw1_w = dw1_w; b0.dw1_b = dw1_b; b0.w2t = w2t; b0.dw2_w = dw2_w; b0.dw2_b = dw2_b;
+  a.x = x; b0.w1t = w1t; b0.dw1_w = dw1_w; b0.dw1_b = dw1_b; b0.w2t = w2t; b0.dw2_w = dw2_w; b0.dw2_b = dw2_b;
   a.y = y; a.T = T; a.tiles = 0; b0.pre_scale = pre_scale; b0.out_scale = out_scale;
   b0.hist1 = hist1; b0.hist2 = hist2; b0.hist1_out = hist1_out; b0.hist2_out = hist2_out;
   a.nblk = 1; a.run_tiles = 0;

@@ -99,8 +99,6 @@ struct Cfg {
   static_assert(!POST_ || ((!STREAM || SCARRY_) && DR_ <= 0 && C <= 192 && !W8_), "closing conv: the carry form of a narrow stage (offline, or a hop's runs of whole streams)");
   static constexpr int NB = NB_;
   static constexpr int DR = DR_ > 0 ? DR_ : 0;
-  // `xadd` input (ResArgs): the hop's SECOND encoder stage only (C = 128) — the one whose branch would otherwise make the hop's first launch wait
-  static constexpr bool XADD = STREAM && DR_ > 0 && C == 128;
   // DR_ < 0: the stage's UP-SAMPLING layer (seanet.py:431-436: [Scale, ELU, depthwise transposed conv k = 2r stride r, 1x1 conv 2C -> C
   // with bias]) as the FIRST phase of the launch ("U", r = -DR_): the tile's x is not read but computed — the up-sampled operand of
   // the 2C rows is built in the LDS tile one half (C rows) at a time from the input frames, their cache and the 2r taps (two FMAs per
@@ -239,7 +237,6 @@ constexpr int DDS = 12;   // per-row table of the down-sampling taps in LDS: [w_
 
 struct ResArgs {
   const float* x;
-  const float* xadd;  // STREAM encoder stages (DR > 0): optional [B][C][T] added to x as it is loaded (x + xadd = the stage's input: its own SpecBlock branch)
   ResBlk blk[MAXBLK];
   int nblk;
   ResDown dn;

@@ -78,7 +78,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
   ResArgs a;
-  a.x = x; a.xadd = nullptr; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
+  a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   a.up = ResUp{};
   a.post = ResPost{};
@@ -132,10 +132,9 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
     return HILC_ERR_UNSUPPORTED;
   if (down->hist && down->hist == down->hist_out) return HILC_ERR_UNSUPPORTED;
   if (down->res == down->y) return HILC_ERR_UNSUPPORTED;
-  if (down->x_add != nullptr && (!streaming || C != 128 || (reinterpret_cast<uintptr_t>(down->x_add) & 15))) return HILC_ERR_UNSUPPORTED;   // (C = 128: the one stage that takes it)
   if (streaming && (long)B * 2 * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
   ResArgs a;
-  a.x = x; a.xadd = streaming ? down->x_add : nullptr; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
+  a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
   a.post = ResPost{};
@@ -184,7 +183,7 @@ extern "C" int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_res
     if (spec->hist != nullptr && spec->hist_len < spec->n_fft - 1) return HILC_ERR_SHAPE;
   }
   ResArgs a;
-  a.x = spec->wav; a.xadd = nullptr; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
+  a.x = spec->wav; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
   a.post = ResPost{};
@@ -259,7 +258,7 @@ int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* bl
   if (up->hist && up->hist == up->hist_out) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
   ResArgs a;
-  a.x = up->x; a.xadd = nullptr; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
+  a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   ResUp& u = a.up;

@@ -624,26 +624,6 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
     }
     Pipe wp;
     wp.prefetch(w1t, lane);                  // GEMM1's first weight slices travel while P0 runs
-    if constexpr (K::XADD) {
-      // x + xadd = the stage's input (round 6): the stage's OWN SpecBlock branch — `x.add_(branch)` in front of the blocks, streaming.py:497-503 —
-      // added as x arrives instead of by the previous stage's epilogue, so that the previous launch does not wait for the branch (computed
-      // beside it on the capture's side stream).  One rounding, fadd(x, branch): the bits of the epilogue form.  RB rows at a time (the kernel
-      // sits at its register limit: all RW rows in flight spill).
-      if (blk == 0 && a.xadd != nullptr) {   // uniform
-#pragma unroll
-        for (int i0 = 0; i0 < RW; i0 += RB) {
-          f32x4 t[RB];
-#pragma unroll
-          for (int i = 0; i < RB; ++i)
-            t[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.xadd) + (cs.boff + (unsigned)(rsub + RSTEP * (i0 + i)) * row_b));
-#pragma unroll
-          for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xr[i0 + i][e] = __fadd_rn(xr[i0 + i][e], t[i][e]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
     // ---- P0: the prologue on the x registers (they stay live: shortcut of P6)
     {
       lptr_t xp = (lptr_t)(X + rsub * XS + c4);   // walks down the tile RB rows at a time (laundered: see gemm_phase)

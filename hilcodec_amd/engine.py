@@ -96,9 +96,6 @@ def spectra_side_stream(stream):
 
 
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
-# streaming hop, deferred SpecBlock branches: stage 1's branch is added by stage 1's OWN launch as it loads x (`x_add`) instead of by stage 0's
-# epilogue (`res`) — the hop's first launch then does not wait for the side stream (round 6: the branch, 128 us alone, was the head of the chain)
-STREAM_LATE_BRANCH = True
 
 
 @dataclass
@@ -511,21 +508,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
             return r
         return _spec_branch(sb, wav, wav_hist)
 
-    def one_launch(st, c, t):
-        """is this stage — residual blocks and down-sampling layer — ONE launch (`ops.encoder_stage`) at input shape [B, c, t]?"""
-        return bool(FUSE_RESBLOCK and opts.stage_launches and st.down_lo is not None and st.down_dw_b is not None
-                    and st.down_dw_w.shape[1] == 2 * st.ratio and t % st.ratio == 0 and (not streaming or FUSE_STREAM)
-                    and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
-                            and rb.dw2_b is not None for rb in st.blocks)
-                    and (c <= FUSE_RESBLOCK_MAX_C or opts.wide_blocks)
-                    and ops.encoder_stage_supported(c, t, len(st.blocks), st.ratio, wav.shape[0], streaming))
-
-    # stage 1's branch as stage 1's `x_add` (see STREAM_LATE_BRANCH): where stage 1 is a stage launch of this hop
-    late1 = bool(defer and STREAM_LATE_BRANCH and len(es.stages) > 1 and wav.shape[2] % st0.ratio == 0 and st0.down_dw_w.shape[0] == 128     # (hilc_encoder_stage takes x_add at C = 128)
-                 and one_launch(es.stages[1], st0.down_dw_w.shape[0], wav.shape[2] // st0.ratio))
-    x_add = None
     for si, st in enumerate(es.stages):
-        res_sb = None if (si == 0 and late1) else (later[si] if defer else None)      # the branch THIS stage's epilogue adds
         if fuse_stage0 and si == 0:
             if streaming:
                 # a hop's first conv + first SpecBlock + first stage (streaming.py:490-511) in one launch, with the waveform cache in front
@@ -535,7 +518,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                     wav, (sb0.fused[0], sb0.fused[1], sb0.fused[2], sb0.bias, es.pre_w, es.pre_b, es.pre_in_scale, sb0.mean, sb0.std,
                           sb0.normalize, sb0.out_scale),
                     blocks0, (st.down_lo, st.down_hi, st.down_dw_w, st.down_dw_b, st.down_in_scale, st.ratio),
-                    res=branch_of(res_sb) if res_sb is not None else None,
+                    res=branch_of(later[0]) if defer else None,
                     hist=[caches[ci + 2 * i: ci + 2 * i + 2] for i in range(nb0)],
                     hist_out=[caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(nb0)] if caches_out is not None else None,
                     down_hist=caches[ci + 2 * nb0], down_hist_out=out(ci + 2 * nb0), wav_hist=wav_hist)
@@ -545,8 +528,14 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
             continue
         if not (fuse_pre and si == 0) and not (defer and si > 0):
             x = _spec_block(st.spec, x, wav, wav_hist)
+        nxt = later[si] if defer else None
         nb = len(st.blocks)
-        if one_launch(st, x.shape[1], x.shape[2]):
+        if (FUSE_RESBLOCK and opts.stage_launches and st.down_lo is not None and st.down_dw_b is not None
+                and st.down_dw_w.shape[1] == 2 * st.ratio and x.shape[2] % st.ratio == 0 and (not streaming or FUSE_STREAM)
+                and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
+                        and rb.dw2_b is not None for rb in st.blocks)
+                and (x.shape[1] <= FUSE_RESBLOCK_MAX_C or opts.wide_blocks)
+                and ops.encoder_stage_supported(x.shape[1], x.shape[2], nb, st.ratio, x.shape[0], streaming)):
             # the whole stage — its residual blocks and its down-sampling layer — is one launch; the stage's output never reaches HBM
             blocks = [(rb.pw1_chain, rb.dw1_w, rb.dw1_b, rb.pw2_chain, rb.dw2_w, rb.dw2_b, rb.pre_scale, rb.out_scale) for rb in st.blocks]
             down = (st.down_lo, st.down_hi, st.down_dw_w, st.down_dw_b, st.down_in_scale, st.ratio)
@@ -554,8 +543,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                 x, cs_, c = ops.encoder_stage(
                     x, blocks, down, hist=[caches[ci + 2 * i: ci + 2 * i + 2] for i in range(nb)],
                     hist_out=[caches_out[ci + 2 * i: ci + 2 * i + 2] for i in range(nb)] if caches_out is not None else None,
-                    down_hist=caches[ci + 2 * nb], down_hist_out=out(ci + 2 * nb), res=branch_of(res_sb) if res_sb is not None else None,
-                    x_add=branch_of(st.spec) if (si == 1 and late1) else None)
+                    down_hist=caches[ci + 2 * nb], down_hist_out=out(ci + 2 * nb), res=branch_of(nxt) if defer else None)
                 new_caches.extend(cs_)
                 new_caches.append(c)
             else:
@@ -567,12 +555,12 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         # (a shortcut the fused layer cannot take — a long hop at a stride above 8 — falls through to pointwise GEMM + depthwise conv, which can)
         if streaming and FUSE_STREAM and ops.dws_conv_stream_profitable(x.shape[2], st.down_dw_w.shape[1], st.ratio, defer, x.shape[0],
                                                                          st.down_dw_w.shape[0]):
-            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci], res=branch_of(res_sb) if res_sb is not None else None,
+            x, c = ops.dws_conv_stream(x, st.down_pw_wt, st.down_dw_w, st.down_dw_b, caches[ci], res=branch_of(nxt) if defer else None,
                                        stride=st.ratio, in_scale=st.down_in_scale, in_elu=True, hist_out=out(ci))
             new_caches.append(c)
         elif streaming:
             h = ops.pw_conv(x, st.down_pw_wt, in_scale=st.down_in_scale, in_elu=True)
-            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, res=branch_of(res_sb) if res_sb is not None else None, stride=st.ratio, hist=caches[ci],
+            x, c = ops.dw_conv(h, st.down_dw_w, st.down_dw_b, res=branch_of(nxt) if defer else None, stride=st.ratio, hist=caches[ci],
                                want_hist=True, hist_out=out(ci))
             new_caches.append(c)
         elif FUSE_DWS and st.down_dw_w.shape[1] == 2 * st.ratio:

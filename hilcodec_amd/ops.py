@@ -319,7 +319,7 @@ _register("resblock_chain", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tenso
 
 
 def _encoder_stage(x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale,
-                   stride, x_add):
+                   stride):
     import ctypes
     from ._lib import DownParams, ResblockParams
     B, Cc, T = x.shape
@@ -336,13 +336,11 @@ def _encoder_stage(x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w
         blocks[i] = ResblockParams(_ptr(w1p), _ptr(d1w), _ptr(d1b), _ptr(w2p), _ptr(d2w), _ptr(d2b), h[0], h[1], h[2], h[3],
                                    float(pre_scales[i]), float(out_scales[i]))
     To = T // stride
-    for t, shape in ((dhist, (B, 2 * Cc, stride)), (dhist_out, (B, 2 * Cc, stride)), (dres, (B, 2 * Cc, To)), (x_add, (B, Cc, T))):
+    for t, shape in ((dhist, (B, 2 * Cc, stride)), (dhist_out, (B, 2 * Cc, stride)), (dres, (B, 2 * Cc, To))):
         if t is not None and tuple(t.shape) != shape:
             raise RuntimeError(f"encoder_stage: expected {shape}, got {tuple(t.shape)}")
-    if x_add is not None and not streaming:
-        raise RuntimeError("encoder_stage: x_add is a streaming-hop argument")
     y = torch.empty(B, 2 * Cc, To, device=x.device, dtype=torch.float32)
-    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y), _ptr(x_add),
+    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y),
                       float(in_scale), int(stride))
     tag = f"C{Cc} T{T}" + (" stream" if streaming else "")
     with _timed("resblock", 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc, tag + f" stage x{n} + down s{stride}"):
@@ -353,8 +351,8 @@ def _encoder_stage(x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w
 
 _register("encoder_stage", "(Tensor x, Tensor[] params, Tensor[] hist_in, Tensor(a!)[] hist_out, float[] pre_scales, float[] out_scales, "
           "Tensor w_lo, Tensor w_hi, Tensor ddw_w, Tensor ddw_b, Tensor? dhist, Tensor(b!)? dhist_out, Tensor? dres, float in_scale, "
-          "int stride, Tensor? x_add) -> Tensor", _encoder_stage,
-          lambda x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale, stride, x_add:
+          "int stride) -> Tensor", _encoder_stage,
+          lambda x, params, hist_in, hist_out, pre_scales, out_scales, w_lo, w_hi, ddw_w, ddw_b, dhist, dhist_out, dres, in_scale, stride:
           x.new_empty(x.shape[0], 2 * x.shape[1], x.shape[2] // stride))
 
 
@@ -420,7 +418,7 @@ def _encoder_stage0(wav, wav_hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, 
     spec = Spec0Params(_ptr(wav), _ptr(dft_packed), _ptr(nyq_sin), _ptr(pw_packed), _ptr(bias), _ptr(pre_w), _ptr(pre_b),
                        _ptr(wh), int(wh.shape[1]) if wh is not None else 0, float(pre_in_scale),
                        float(mean), float(std), float(out_scale), int(normalize), 64, 1, int(pre_w.shape[1]))
-    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y), None, float(in_scale), int(stride))
+    down = DownParams(_ptr(w_lo), _ptr(w_hi), _ptr(ddw_w), _ptr(ddw_b), _ptr(dhist), _ptr(dhist_out), _ptr(dres), _ptr(y), float(in_scale), int(stride))
     work = 2.0 * B * T * 64 * (64 + 1 + 32 + 1) + 2.0 * B * T * Cc * k + 4.0 * n * B * T * Cc * Cc + 4.0 * B * T * Cc * Cc
     with _timed("resblock", work, f"C{Cc} T{T}" + (" stream" if streaming else "") + f" conv_pre + spec N64 + stage x{n} + down s{stride}"):
         check(lib.hilc_encoder_stage0(ctypes.cast(ctypes.pointer(spec), ctypes.c_void_p), ctypes.cast(blocks, ctypes.c_void_p), n,
@@ -1018,13 +1016,12 @@ def encoder_stage_supported(C: int, T: int, nblk: int, stride: int, B: int = 1, 
 
 def encoder_stage(x: Tensor, blocks: Sequence[Sequence], down: Sequence, hist: Optional[Sequence[Sequence[Tensor]]] = None,
                   hist_out: Optional[Sequence[Optional[Sequence[Tensor]]]] = None, down_hist: Optional[Tensor] = None,
-                  down_hist_out: Optional[Tensor] = None, res: Optional[Tensor] = None, x_add: Optional[Tensor] = None):
+                  down_hist_out: Optional[Tensor] = None, res: Optional[Tensor] = None):
     """An encoder stage in ONE launch (hilc_encoder_stage): its residual blocks (`blocks[i]` as in `resblock_chain`) and its
     down-sampling layer `down` = (w_lo, w_hi, dw_w `[2C,2r]`, dw_b `[2C]`, in_scale, stride) — w_lo / w_hi = the two column halves
     of the k-major `[C,2C]` pointwise weight, packed with `resblock_chain_pack`.  Offline (hist None): -> y `[B,2C,T/r]`.
     Streaming: hist / hist_out per block as in `resblock_chain`, `down_hist` `[B,2C,r]` -> (y, [block caches...], down cache).
-    `res` `[B,2C,T/r]` is added to the output (the next stage's SpecBlock branch); `x_add` `[B,C,T]` (streaming) is added to x as it is loaded
-    (the stage's own branch: same rounding as the `res` of the stage in front, without making that launch wait for the branch)."""
+    `res` `[B,2C,T/r]` is added to the output (the next stage's SpecBlock branch)."""
     B, Cc, _ = x.shape
     w_lo, w_hi, ddw_w, ddw_b, in_scale, stride = down
     params, hin, hout, pre, post = [], [], [], [], []
@@ -1037,9 +1034,9 @@ def encoder_stage(x: Tensor, blocks: Sequence[Sequence], down: Sequence, hist: O
             given = hist_out[i] if hist_out is not None and hist_out[i] is not None else (None, None)
             hout.extend([_state_out(given[0], x, B, Cc, 4), _state_out(given[1], x, B, Cc, 4)])
     if hist is None:
-        return _OPS.encoder_stage(x, params, [], [], pre, post, w_lo, w_hi, ddw_w, ddw_b, None, None, res, float(in_scale), int(stride), None)
+        return _OPS.encoder_stage(x, params, [], [], pre, post, w_lo, w_hi, ddw_w, ddw_b, None, None, res, float(in_scale), int(stride))
     dout = _state_out(down_hist_out, x, B, 2 * Cc, int(stride))
-    y = _OPS.encoder_stage(x, params, hin, hout, pre, post, w_lo, w_hi, ddw_w, ddw_b, down_hist, dout, res, float(in_scale), int(stride), x_add)
+    y = _OPS.encoder_stage(x, params, hin, hout, pre, post, w_lo, w_hi, ddw_w, ddw_b, down_hist, dout, res, float(in_scale), int(stride))
     return y, hout, dout
 
 

@@ -227,8 +227,6 @@ int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params
 typedef struct hilc_down_params {
   const float* w_lo; const float* w_hi; const float* dw_w; const float* dw_b;
   const float* hist; float* hist_out; const float* res; float* y;
-  const float* x_add;   /* ABI 15, streaming C = 128 only (else must be NULL): optional [B][C][T] added to x as the stage loads it — the stage's OWN
-                         * SpecBlock branch (`x.add_(branch)` in front of the blocks, streaming.py:497-503), instead of `res` of the stage before */
   float in_scale; int stride;
 } hilc_down_params;
 int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streaming);

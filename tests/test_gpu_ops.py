@@ -550,10 +550,9 @@ def test_encoder_stage_streaming_equals_blocks_then_down(env, C, r, T, B, n):
     for h in range(3):
         x = rnd(C + T + h, B, C, T).to(dev)
         res = rnd(40 + h, B, 2 * C, T // r).to(dev) if h != 1 else None
-        xa = rnd(50 + h, B, C, T).to(dev) if (h == 2 and C == 128) else None        # `x_add` (round 6): the stage's own SpecBlock branch, added as x is loaded
-        y, flat, da = ops.encoder_stage(x, blocks, down, hist=ca, down_hist=da, res=res, x_add=xa)
+        y, flat, da = ops.encoder_stage(x, blocks, down, hist=ca, down_hist=da, res=res)
         ca = [flat[2 * j:2 * j + 2] for j in range(n)]
-        y2 = x if xa is None else x + xa
+        y2 = x
         for j, (single, pre, post) in enumerate(singles):
             y2, cb[j] = ops.resblock(y2, *single, pre, post, hist=cb[j])
         ref, db_ = ops.dws_conv_stream(y2, wd, dw, db, db_, res=res, stride=r, in_scale=0.7746, in_elu=True)
