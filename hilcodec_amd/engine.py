@@ -96,6 +96,7 @@ def spectra_side_stream(stream):
 
 
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
+STREAM_STAGE0 = True      # streaming hop: first conv + stage-0 SpecBlock as the opening phase of the first stage launch (hilc_encoder_stage0)
 
 
 @dataclass
@@ -468,7 +469,7 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
                 and es.pre_w.shape == (64, 5) and ops.spec_block_supported(64, 1, 64, wav.shape[2])
                 and (wav_hist is None or wav_hist.shape[-1] >= 63))
     st0 = es.stages[0]
-    fuse_stage0 = (fuse_pre and (not streaming or FUSE_STREAM) and FUSE_RESBLOCK and opts.stage_launches and st0.down_lo is not None and st0.down_dw_b is not None
+    fuse_stage0 = (fuse_pre and (not streaming or (FUSE_STREAM and STREAM_STAGE0)) and FUSE_RESBLOCK and opts.stage_launches and st0.down_lo is not None and st0.down_dw_b is not None
                    and st0.down_dw_w.shape[1] == 2 * st0.ratio and wav.shape[2] % st0.ratio == 0
                    and all(rb.pw1_chain is not None and rb.dw1_w.shape[1] == 5 and rb.dw2_w.shape[1] == 5 and rb.dw1_b is not None
                            and rb.dw2_b is not None for rb in st0.blocks)
