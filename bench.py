@@ -336,7 +336,7 @@ def timed_region(step, steps: int, warmup: int, D, launch_timing: bool):
     return dt, idx, wav, timer
 
 
-def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
+def other_config_lines(dev, D, clips: int = 256, streams: int = 1024, census_clips: int = 0):
     """Short, separately reported runs of BASELINE configs[2] and configs[3] (never part of `value`): the driver sees them in
     the one JSON line of the default invocation."""
     out = {}
@@ -353,6 +353,20 @@ def other_config_lines(dev, D, clips: int = 256, streams: int = 1024):
 
     step, audio, _ctx = offline_workload("hil_music", clips, 0, 24000, dev)
     out["configs[2]"] = line(f"hil_music, batch={clips}x1 s 24 kHz, Nq=12, offline encode+RVQ+decode", "hil_music", step, audio, 10, 2)
+    if census_clips > 0 and clips >= census_clips:
+        # the same comparison the headline model gets from the cpu_baseline leg, after the timed region: the oracle on the batch's first clips,
+        # EVERY RVQ index of them, |dz|, |dwav| on the reference's own indices and end to end (tests/census.py)
+        try:
+            from hilcodec_amd import synth
+            from tests import census
+            idx, wav = step(0)
+            torch.cuda.synchronize()
+            x = synth.synth_clips(census_clips, 24000, seed=1234)
+            z_o, idx_o, wav_o, _, _ = census.oracle_clips("hil_music", _ctx["sd"], _ctx["mk"], x, chunk=min(census_clips, 4))
+            out["configs[2]"]["parity_census"] = parity_census(_ctx["model"], _ctx["sd"], _ctx["mk"]["vq_kwargs"]["num_quantizers"],
+                                                               _ctx["last"]["z"], idx, wav, (z_o, idx_o, wav_o))
+        except Exception as e:                                     # noqa: BLE001
+            out["configs[2]"]["parity_census"] = {"error": f"{type(e).__name__}: {e}"}
     del step, _ctx
     torch.cuda.empty_cache()
     for key, pipeline, groups in (("configs[3] graph", False, 1), ("configs[3] graph, 2 stream groups", False, 2),
@@ -509,7 +523,7 @@ def main():
             # auxiliary lines: a failure here (it would be a bug) must not cost the headline line its measurement — it is reported
             # in place of the lines, and tests/test_gpu_bench.py fails on it
             try:
-                out["other_configs"] = other_config_lines(dev, D, B, 4 * B)
+                out["other_configs"] = other_config_lines(dev, D, B, 4 * B, 0 if args.no_cpu_baseline else min(4, args.cpu_clips))
             except Exception as e:                                     # noqa: BLE001
                 out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -1,6 +1,6 @@
 """GPU, full size: EVERY RVQ index of the first 64 (hil_speech) / 32 (hil_music) clips of BASELINE's 256-clip batch
 against the CPU oracle (= the reference's arithmetic).  Bars (north_star): zero index mismatches that are not fp64
-near-ties, |dz| < 2e-5, decoded waveform within 1e-4 — on the reference's own indices for every clip and end to end on
+near-ties, |dz| < 1e-5 (measured 5.7e-6: a 2 x drift fails), decoded waveform within 1e-4 — on the reference's own indices for every clip and end to end on
 every clip without a near-tie flip.  The counts are printed (and land in profiles/ via tools/census_run.sh)."""
 import json
 
@@ -17,6 +17,6 @@ def test_parity_census(name, n_clips):
     assert r["clips"] == n_clips and r["argmins"] == n_clips * (8 if name == "hil_speech" else 12) * 75
     assert r["genuine_mismatches"] == 0, r["flips"]
     assert r["near_tie_flips"] <= 1, r["flips"]        # measured: 0 in 38 400 + 28 800 argmins (profiles/r02_parity_census_final.json)
-    assert r["dz_max"] < 2e-5
+    assert r["dz_max"] < 1e-5
     assert r["dwav_max_on_reference_indices"] < 1e-4
     assert r["dwav_max_end_to_end"] is not None and r["dwav_max_end_to_end"] < 1e-4

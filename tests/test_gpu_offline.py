@@ -40,7 +40,7 @@ def compare(model, mk, sd, x, z_ref, idx_ref, wav_ref, n=None, fixture=False):
         q, nr, loss, idx = model.quantizer(z, n, return_indices=True)
         wav = model.decoder(q)
     dz = (z.cpu() - z_ref).abs().max().item()
-    assert dz < 2e-5, f"encoder output differs by {dz:.3e}"
+    assert dz < 1e-5, f"encoder output differs by {dz:.3e}"        # measured 3 - 6e-6 (profiles/r05_parity_census_final.json): a 2 x drift fails
     same = idx.cpu() == idx_ref
     flips = 0
     if not same.all():

@@ -837,6 +837,41 @@ def test_encoder_stage0_equals_conv_pre_spec_then_stage(env, T, B, n):
         assert y.shape == (B, 2 * C, T // r) and torch.equal(y, y2), float((y - y2).abs().max())
 
 
+@pytest.mark.parametrize("T,B,n", [(8, 300, 1), (372, 5, 2), (124, 33, 2)])
+def test_encoder_stage0_vs_oracle_composition(env, T, B, n):
+    """hilc_encoder_stage0 against the ORACLE at shapes no model-level golden reaches (clips shorter than a tile and ragged batches, a clip
+    that ends inside a tile, runs that start inside a clip): first conv `Scale(1 / wav_std) -> SConv1d(1, 64, 5)` (`seanet.py:280-286`), stage 0's
+    SpecBlock (`:220-246`), the stage's residual blocks (`:129-148`), `self.downsample[0]` (`:330-339`) and the next stage's branch."""
+    ops, fold, O, dev = env
+    C, r, n_fft = 64, 2, 64
+    assert ops.encoder_stage0_supported(T, n, r, 64, 1, 5)
+    basis = synth.stft_basis(n_fft)
+    bt = fold.stft_basis_layout(basis).to(dev)
+    w = rnd(n_fft + 1, C, n_fft // 2 + 1, 1) / (n_fft // 2 + 1) ** 0.5
+    bias = rnd(n_fft + 2, C) * 0.1
+    dft_p, nyq, pw_p = ops.spec_block_tables(bt, fold.pointwise_layout(w).to(dev), n_fft)
+    pre_w, pre_b = rnd(71, 64, 1, 5) * 0.5, rnd(72, 64) * 0.1
+    sds, raw = _oracle_blocks(O, C, n)
+    wd = rnd(70, 2 * C, C, 1) / C ** 0.5
+    dw, db = rnd(73, 2 * C, 1, 2 * r) * 0.3, rnd(74, 2 * C) * 0.1
+    wav = synth.synth_clips(B, T, seed=T + B)
+    res = rnd(75, B, 2 * C, T // r) * 0.5
+    isc, in_scale = 1 / 0.1122080159, (1 + n * RS ** 2) ** -0.5
+    # the oracle: conv_pre, x + scale * (W log|STFT| + b), blocks, [Scale, ELU, 1x1 conv, strided depthwise conv] + the next branch
+    ref = O.sconv1d(wav * isc, pre_w, pre_b)
+    mag = O.causal_stft_mag(wav, basis, 1, pad=True, clamp=True)
+    ref = ref + (F.conv1d((torch.log(mag.clamp_min(1e-5)) - (-4.0)) / 2.8, w) + bias.view(1, -1, 1)) * 0.37
+    for j, sd in enumerate(sds):
+        ref = O.resblock(sd, "p", ref, RS, j)
+    ref = O.sconv1d(F.conv1d(F.elu(ref * in_scale), wd), dw, db, stride=r, groups=2 * C) + res
+    wt = wd[:, :, 0].t().contiguous().to(dev)
+    down = (ops.resblock_chain_pack(wt[:, :C].contiguous(), False), ops.resblock_chain_pack(wt[:, C:].contiguous(), False),
+            dw[:, 0].contiguous().to(dev), db.to(dev), in_scale, r)
+    spec = (dft_p, nyq, pw_p, bias.to(dev), pre_w[:, 0].contiguous().to(dev), pre_b.to(dev), isc, -4.0, 2.8, True, 0.37)
+    y = ops.encoder_stage0(wav.to(dev), spec, _chain_params(ops, raw, dev), down, res=res.to(dev))
+    close(y, ref, 2e-4, f"encoder stage 0 (conv_pre + SpecBlock + blocks + down) T{T} B{B}")
+
+
 @pytest.mark.parametrize("T,B,n", [(320, 5, 2), (320, 1024, 2), (320, 1, 2), (640, 3, 2), (128, 70, 1), (132, 9, 2), (960, 2, 2)])
 def test_encoder_stage0_streaming_equals_conv_pre_spec_then_stage(env, T, B, n):
     """hilc_encoder_stage0(streaming = 1), round 6: a hop's first conv + stage-0 SpecBlock (`streaming.py:490-497`) as the opening phase of the C = 64
