@@ -25,7 +25,7 @@ int resblock_entry(bool streaming, const float* x, const float* w1t, const float
   if (x == y) return HILC_ERR_UNSUPPORTED;   // neighbouring tiles read each other's halo: not in place
   if (T % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
     return HILC_ERR_UNSUPPORTED;             // callers fall back to two hilc_dws_conv launches
-  ResArgs a;
+  ResArgs a{};
   ResBlk& b0 = a.blk[0];
   a.x = x; b0.w1t = w1t; b0.dw1_w = dw1_w; b0.dw1_b = dw1_b; b0.w2t = w2t; b0.dw2_w = dw2_w; b0.dw2_b = dw2_b;
   a.y = y; a.T = T; a.tiles = 0; b0.pre_scale = pre_scale; b0.out_scale = out_scale;

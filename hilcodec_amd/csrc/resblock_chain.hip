@@ -77,7 +77,7 @@ extern "C" int hilc_resblock_chain(const float* x, float* y, const hilc_resblock
   if (!hilc_resblock_chain_supported(C, T, nblk, streaming)) return HILC_ERR_UNSUPPORTED;
   if (x == y || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;   // 32-bit flat column index / byte offsets
-  ResArgs a;
+  ResArgs a{};
   a.x = x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   a.up = ResUp{};
@@ -133,7 +133,7 @@ extern "C" int hilc_encoder_stage(const float* x, const hilc_resblock_params* bl
   if (down->hist && down->hist == down->hist_out) return HILC_ERR_UNSUPPORTED;
   if (down->res == down->y) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * 2 * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
-  ResArgs a;
+  ResArgs a{};
   a.x = x; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
@@ -182,7 +182,7 @@ extern "C" int hilc_encoder_stage0(const hilc_spec0_params* spec, const hilc_res
     if ((long)B * 128 * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;            // 32-bit flat column index / byte offsets
     if (spec->hist != nullptr && spec->hist_len < spec->n_fft - 1) return HILC_ERR_SHAPE;
   }
-  ResArgs a;
+  ResArgs a{};
   a.x = spec->wav; a.y = down->y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
   a.up = ResUp{};
@@ -257,7 +257,7 @@ int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* bl
   if ((reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(up->tr_w) & 15)) return HILC_ERR_UNSUPPORTED;
   if (up->hist && up->hist == up->hist_out) return HILC_ERR_UNSUPPORTED;
   if (streaming && (long)B * C * T * 4 >= (1L << 32)) return HILC_ERR_UNSUPPORTED;
-  ResArgs a;
+  ResArgs a{};
   a.x = up->x; a.y = y; a.T = T; a.tiles = 0; a.nblk = nblk; a.sched = nullptr; a.dbg = HILC_CHAIN_DBG;
   a.dn = ResDown{};
   if (const int rc = fill_blocks(a, blocks, nblk)) return rc;
