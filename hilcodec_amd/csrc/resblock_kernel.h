@@ -61,7 +61,26 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   const int colblk = wave % NCB;
   const int wclass = wave / NCB;                         // row class (0 unless RH == 2)
   const int rowblk0 = wclass * CBW;
-#ifdef HILC_DEBUG_STAMPS
+#if defined(HILC_DEBUG_WAVE_STAMPS)
+  // tools/narrow_phase_waits.py (round 6): EVERY wave stamps every barrier of a tile — end of its own issue (t0), its LDS operations drained
+  // (t1, after s_waitcnt lgkmcnt(0)), the barrier passed (t2) — into dbg[((tile * NW + wave) * WS_MAXB + k) * 3 ...]; slot WS_MAXB - 1 holds
+  // (blockIdx, barriers of the tile, tile start).  Never in the product.
+  constexpr int WS_MAXB = 48;
+  unsigned long long* ws_base = nullptr;
+  int ws_k = 0;
+#define STAMP(i) do { } while (0)
+#define lds_barrier() do {                                                                                          \
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                 \
+    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();                                                   \
+    if (ws_base != nullptr && lane == 0 && ws_k < WS_MAXB - 1) {                                                   \
+      ws_base[ws_k * 3] = t0_; ws_base[ws_k * 3 + 1] = t1_; ws_base[ws_k * 3 + 2] = t2_;                           \
+    }                                                                                                              \
+    ++ws_k;                                                                                                        \
+  } while (0)
+#elif defined(HILC_DEBUG_STAMPS)
 #define STAMP(i) do { if (a.dbg && tid == 0) a.dbg[stamp_tile * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   long stamp_tile = blockIdx.x;
 #else
@@ -341,7 +360,14 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
       // the critical path)
       if (TICKETS && a.sched != nullptr && tid == 0) s_next = (long)gridDim.x + atomicAdd(a.sched, 1);   // read after P0's barrier
     }
-#ifdef HILC_DEBUG_STAMPS
+#if defined(HILC_DEBUG_WAVE_STAMPS)
+    if (a.dbg != nullptr) {
+      if (ws_base != nullptr && lane == 0) ws_base[(WS_MAXB - 1) * 3 + 1] = (unsigned long long)ws_k;      // barriers of the tile just finished
+      ws_base = a.dbg + ((tile * NW + wave) * (long)WS_MAXB) * 3;
+      if (lane == 0) { ws_base[(WS_MAXB - 1) * 3] = blockIdx.x; ws_base[(WS_MAXB - 1) * 3 + 2] = __builtin_amdgcn_s_memtime(); }
+    }
+    ws_k = 0;
+#elif defined(HILC_DEBUG_STAMPS)
     stamp_tile = tile;
 #endif
     STAMP(0);
@@ -1209,6 +1235,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
     }
   }
   if (touch == 1.2345678e-30f) a.y[0] = touch;   // keeps the touch loads alive; never true in practice
+#if defined(HILC_DEBUG_WAVE_STAMPS)
+  if (ws_base != nullptr && lane == 0) ws_base[(WS_MAXB - 1) * 3 + 1] = (unsigned long long)ws_k;
+#undef lds_barrier
+#endif
 #undef STAMP
 }
 
