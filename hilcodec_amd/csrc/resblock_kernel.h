@@ -41,7 +41,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   __shared__ __attribute__((aligned(16))) float Xbuf[4 + C * XS];
   // tap tables: all blocks of a chain resident (loaded once per workgroup) — except where the NARROW shapes' tables (C >= 256: 12 - 36 KB
   // per block) do not fit beside the tile (C = 384 x 3 offline, C = 768 x 3 in a hop): those reload the one table at the start of every block
-  constexpr bool DW_RELOAD = NB > 1 && K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024;
+  constexpr bool DW_RELOAD = NB > 1 && ((K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024) || K::HALF);
   __shared__ __attribute__((aligned(16))) float DW[(DW_RELOAD ? 1 : NB) * C * DWS];
   constexpr bool DWIDE = DR == 5 || DR == 8;            // the wide stages' down-sampling phase: taps straight from global memory (no LDS left)
   __shared__ __attribute__((aligned(16))) float DWD[(DR > 0 && !DWIDE) ? 2 * C * DDS : 4];
@@ -85,6 +85,18 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   long stamp_tile = blockIdx.x;
 #else
 #define STAMP(i) do { } while (0)
+#endif
+  // wave priority per phase kind (tuning builds only, -DHILC_RES_SETPRIO=1: element-wise phases high / GEMM phases low; 2: the reverse).
+  // Measured in round 3 (+-0) and again in round 6 on the stage kernels (profiles/r06_experiments.md): not in the product build.
+#if defined(HILC_RES_SETPRIO) && HILC_RES_SETPRIO == 1
+#define PRIO_EW() __builtin_amdgcn_s_setprio(3)
+#define PRIO_MM() __builtin_amdgcn_s_setprio(0)
+#elif defined(HILC_RES_SETPRIO) && HILC_RES_SETPRIO == 2
+#define PRIO_EW() __builtin_amdgcn_s_setprio(0)
+#define PRIO_MM() __builtin_amdgcn_s_setprio(3)
+#else
+#define PRIO_EW() do { } while (0)
+#define PRIO_MM() do { } while (0)
 #endif
   const int T = a.T;
   const int nblk = NB == 1 ? 1 : a.nblk;                 // uniform; NB == 1: the block loop below folds away
@@ -305,7 +317,16 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   constexpr int LPR = K::NCOL / 32;                 // 128-B lines per tile row
   // (STREAM: no touch loads — a hop's activations were written by the previous launch a few hundred microseconds ago, and the
   // registers of the address arithmetic are what the cache handling needs)
-  constexpr int NTOUCH = STREAM ? 1 : (C * LPR + NT - 1) / NT;
+  // (UTOUCH, round 6: the offline carry form of the narrow decoder stages touches the next tile's INPUT FRAMES of the up-sampling phase —
+  //  2C rows x NCOL / r frames — the same way: by the per-wave stamps the two operand builds of a C = 96 tile were 13 % of it, two exposed HBM
+  //  round trips per half)
+#ifdef HILC_RES_NO_UTOUCH      // A/B builds of tools/
+  constexpr bool UTOUCH = false;
+#else
+  constexpr bool UTOUCH = !STREAM && UR > 0 && !K::NARROW && (K::NCOL / (UR > 0 ? UR : 1)) % 32 == 0;
+#endif
+  constexpr int LPRU = UTOUCH ? K::NCOL / UR / 32 : 1;     // 128-B lines of input frames per tile row
+  constexpr int NTOUCH = STREAM ? 1 : (UTOUCH ? (2 * C * LPRU + NT - 1) / NT : (C * LPR + NT - 1) / NT);
   float tv[NTOUCH];                                 // L2 touch loads in flight across the tile boundary
 #pragma unroll
   for (int i = 0; i < NTOUCH; ++i) tv[i] = 0.f;
@@ -391,7 +412,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
           // the operands of UB rows first (one exposed round trip per batch, not one per row), then their arithmetic.
           // r = 8 / 4: the lane's 4 columns share one input frame q0 (phases p0 .. p0 + 3); r = 2: they are frames q0, q0, q0 + 1, q0 + 1
           // (phases 0, 1, 0, 1) — the same cases as UpB<R> in gemm_lin.h.
-          constexpr int UB = RW % 6 == 0 ? 6 : RB;
+          constexpr int UB = RW % 6 == 0 ? 6 : RB;      // (round 6: all 12 rows of a C = 96 half in ONE batch measured +-0 — the build is issue-, not latency-bound)
           // r = 5 (any stride that does not divide 4 columns into whole frames): the EXPANDED tap table of hilc_up_conv_expand_taps,
           // `[2C][r][8]` — for the phase p0 = t mod r of a 4-column group its eight taps as two 16-B words — and three input frames per
           // row (q0 - 1, q0, q0 + 1): column e belongs to frame q0 + 1 where p0 + e >= r.  The expression of UpB<1> (gemm_lin.h).
@@ -465,8 +486,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         Pipe wp;
         wp.prefetch(wu, lane);
         lds_barrier();
+        PRIO_MM();
         if constexpr (K::NARROW) gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
         else gemm_phase<K, false>(wu, X, acc, wp, colblk, lane);
+        PRIO_EW();
         lds_barrier();
       }
       acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -681,8 +704,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
 
     f32x16 acc[CBW];
     // ---- P1, P2
+    PRIO_MM();
     if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
+    PRIO_EW();
     lds_barrier();
     STAMP(2);
     acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -739,8 +764,10 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
     STAMP(4);
 
     // ---- P4
+    PRIO_MM();
     if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
+    PRIO_EW();
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     have_next = next_tile < run1;
@@ -768,6 +795,23 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
         tv[i] = nx[(long)(e / LPR) * T + tt];
       }
+      }
+    }
+    if constexpr (UTOUCH) {
+      if (final_blk) {
+        const long nt = have_next ? next_tile : tile;
+        const long nb = nt / a.tiles;
+        const int Tin = T / UR;
+        const int nq0 = (int)(nt - nb * a.tiles) * TO / UR;            // the next tile's first input frame
+        const float* nx = a.up.xin + nb * (long)(2 * C) * Tin;
+#pragma unroll
+        for (int i = 0; i < NTOUCH; ++i) {
+          int e = tid + NT * i;
+          e = e < 2 * C * LPRU ? e : 2 * C * LPRU - 1;
+          int ff = nq0 + (e % LPRU) * 32;
+          ff = ff > Tin - 1 ? Tin - 1 : ff;
+          tv[i] = nx[(long)(e / LPRU) * Tin + ff];
+        }
       }
     }
     // ---- P5
@@ -967,12 +1011,16 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
       // (one more ELU pass: ~1 % of the two GEMMs), GEMM, conv; the next tile's rows then travel under the second GEMM.
       f32x16 acc0[CBW];
       [[maybe_unused]] f32x16 acc1[DWIDE ? 1 : CBW];
+      PRIO_MM();
       if constexpr (K::NARROW) gemm_phase_rolled<K>(wd0, X, acc0, wp, colblk, lane);
       else gemm_phase<K>(wd0, X, acc0, wp, colblk, lane);
+      PRIO_EW();
       if constexpr (!DWIDE) {
         wp.prefetch(wd1, lane);
+        PRIO_MM();
         if constexpr (K::NARROW) gemm_phase_rolled<K>(wd1, X, acc1, wp, colblk, lane);
         else gemm_phase<K>(wd1, X, acc1, wp, colblk, lane);
+        PRIO_EW();
       }
       const bool out_ok = !warm && (STREAM ? cs.t_in : cs.t < T);
       [[maybe_unused]] const bool out_ok_tile = !warm;
@@ -989,7 +1037,9 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
               for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
             }
             lds_barrier();
+            PRIO_MM();
             gemm_phase_rolled<K>(wd1, X, acc0, wp, colblk, lane);
+            PRIO_EW();
           }
         }
         lds_barrier();
@@ -1239,6 +1289,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   if (ws_base != nullptr && lane == 0) ws_base[(WS_MAXB - 1) * 3 + 1] = (unsigned long long)ws_k;
 #undef lds_barrier
 #endif
+#undef PRIO_EW
+#undef PRIO_MM
 #undef STAMP
 }
 
