@@ -338,39 +338,29 @@ static int up_conv_entry(const float* x, const float* hist, float* hist_out, con
     ld.in_elu = in_elu;
     return launch_gemm(wt, M, K, M, (ncols + BN - 1) / BN, false, ld, ep, (hipStream_t)stream);
   };
-  if (lin_ok(B, K, Tin)) {   // linear-addressing core (gemm_lin.h): same arithmetic, far fewer VALU per K slice
-    const bool lds_epi = ncols < (1L << 31) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  // linear-addressing core (gemm_lin.h): same arithmetic, far fewer VALU per K slice.  Instantiated for what the models launch (round 6 pruning:
+  // 160 -> 32 kernels): ELU in front (`seanet.py:431-436`: every up-sampling layer has one), 16-B aligned taps and output (the allocator's), the
+  // strides with a vector tap path (8 / 4 / 2) or the expanded table (5).  Everything else — no ELU, a misaligned view, another stride — takes
+  // the generic core below: the same fmaf chains, bit-identical.
+  const bool lds_epi = ncols < (1L << 31) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  if (lin_ok(B, K, Tin) && in_elu && lds_epi && w_aligned) {
     PwLdsEpilogue el;
     el.y = y; el.bias = bias; el.res = nullptr; el.M = M; el.T = (int)Tout; el.ncols = ncols; el.out_scale = 1.0f;
     div_magic((int)Tout, el.t_magic, el.t_shift);
     auto lin = [&](auto bop) {
       bop.x = x; bop.w = decltype(bop)::kExpanded ? tr_w_expanded : tr_w; bop.hist = hist; bop.K = K; bop.Tin = Tin; bop.r = stride; bop.ncols = ncols;
       bop.in_scale = in_scale;
-      if (lds_epi) return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, el, (hipStream_t)stream);
-      return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, ep, (hipStream_t)stream);
+      return launch_lin(wt, M, K, M, (ncols + BN - 1) / BN, bop, el, (hipStream_t)stream);
     };
-    const int rsel = !w_aligned ? 0 : stride == 8 ? 8 : stride == 4 ? 4 : stride == 2 ? 2 : 0;
-#define HILC_UP(RV)                                                                         \
-  do {                                                                                      \
-    if (in_elu) return hist ? lin(UpB<RV, true, true>{}) : lin(UpB<RV, true, false>{});     \
-    return hist ? lin(UpB<RV, false, true>{}) : lin(UpB<RV, false, false>{});               \
-  } while (0)
-    if (rsel == 8) HILC_UP(8);
-    if (rsel == 4) HILC_UP(4);
-    if (rsel == 2) HILC_UP(2);
+#define HILC_UP(RV) do { return hist ? lin(UpB<RV, true, true>{}) : lin(UpB<RV, true, false>{}); } while (0)
+    if (stride == 8) HILC_UP(8);
+    if (stride == 4) HILC_UP(4);
+    if (stride == 2) HILC_UP(2);
     if (tr_w_expanded != nullptr && (reinterpret_cast<uintptr_t>(tr_w_expanded) & 15) == 0) HILC_UP(1);
-    HILC_UP(0);
 #undef HILC_UP
   }
-  if (hist != nullptr) {
-    if (w_aligned && stride == 8) return go(UpLoader<8, true>{});
-    if (w_aligned && stride == 4) return go(UpLoader<4, true>{});
-    if (w_aligned && stride == 2) return go(UpLoader<2, true>{});
-    return go(UpLoader<0, true>{});
-  }
-  if (w_aligned && stride == 8) return go(UpLoader<8>{});
-  if (w_aligned && stride == 4) return go(UpLoader<4>{});
-  if (w_aligned && stride == 2) return go(UpLoader<2>{});
+  // (the generic core keeps ONE loader per cache mode — scalar tap loads, any stride: it is the fall-back of shapes no model launches)
+  if (hist != nullptr) return go(UpLoader<0, true>{});
   return go(UpLoader<0>{});
 }
 

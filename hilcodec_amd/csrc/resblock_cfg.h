@@ -127,11 +127,7 @@ struct Cfg {
   // layer — one launch.  Every wave owns ONE 32-row block (C = 256: 8 waves, C = 384: 12 waves = three per SIMD).
   static constexpr bool N32 = STREAM && SCARRY_ && NARROW;
   static_assert(!N32 || C == 256 || C == 384, "32-column carry form: the C = 256 / C = 384 stages of a hop");
-  // HALF (tuning builds only, -DHILC_RES_HALF192; round 6, measured and rejected — profiles/r06_experiments.md): the C = 192 stage as TWO four-wave
-  // workgroups per CU on 64-column carry tiles (one tap table resident, reloaded per block) instead of one eight-wave workgroup on 128 columns.
-  // Spelled W8_ = true at C = 192, where that flag has no other meaning (the width always runs eight waves).
-  static constexpr bool HALF = C == 192 && W8_ && !STREAM;
-  static constexpr int NCOL = NARROW ? ((C >= 512 || N32) ? 32 : 64) : (HALF ? 64 : 128);      // tile width = LDS row stride (floats)
+  static constexpr int NCOL = NARROW ? ((C >= 512 || N32) ? 32 : 64) : 128;      // tile width = LDS row stride (floats)
   static constexpr int XS = NCOL + ((!STREAM || SCARRY_) ? 8 * NB_ + 2 * DCAR + (POST_ ? 4 : 0) : 0);   // LDS row stride: the tile's columns (+ carry form: two 4-float slots, H1 and H2)
   // Offline (CARRYMODE): no halo — a workgroup walks a CONTIGUOUS run of tiles and carries the last 4 columns of both pointwise
   // outputs from one tile to the next in LDS, exactly what the streaming caches do from hop to hop.  (Until round 3 every tile
@@ -143,7 +139,7 @@ struct Cfg {
   static constexpr bool CARRYMODE = !STREAM || SCARRY_;
   static constexpr int HALO = CARRYMODE ? 0 : ((NARROW && C >= 512) ? 0 : 8);   // left halo of two causal k=5 convs, recomputed per tile
   static constexpr int TO = NCOL - HALO;             // output samples per tile
-  static constexpr int NW = HALF ? 4 : ((N32 && C == 384) ? 12 : ((C >= 192 || W8_) ? 8 : 4));           // waves per workgroup
+  static constexpr int NW = (N32 && C == 384) ? 12 : ((C >= 192 || W8_) ? 8 : 4);           // waves per workgroup
   static constexpr int NT = 64 * NW;
   static constexpr int RH = NW / (NCOL / 32);        // row classes: waves w and w + NCOL/32 share a column block
   static constexpr int CBW = CB / RH;                // 32-row MFMA blocks per wave

@@ -284,9 +284,6 @@ int decoder_stage_entry(const hilc_up_params* up, const hilc_resblock_params* bl
   }
   if (C == 768) return launch_chain<768, false, 1, false, -8>(a, B, s);
   if (C == 384) return launch_chain<384, false, 3, false, -5>(a, B, s);
-#ifdef HILC_RES_HALF192        // A/B builds of tools/: the C = 192 stage as two half-width workgroups per CU (resblock_cfg.h: HALF)
-  if (C == 192) return launch_chain<192, false, 3, true, -4>(a, B, s);
-#endif
   return C == 192 ? launch_chain<192, false, 3, false, -4>(a, B, s) : launch_chain<96, false, 3, false, -2>(a, B, s);
 }
 }  // namespace

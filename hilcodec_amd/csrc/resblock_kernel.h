@@ -41,7 +41,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   __shared__ __attribute__((aligned(16))) float Xbuf[4 + C * XS];
   // tap tables: all blocks of a chain resident (loaded once per workgroup) — except where the NARROW shapes' tables (C >= 256: 12 - 36 KB
   // per block) do not fit beside the tile (C = 384 x 3 offline, C = 768 x 3 in a hop): those reload the one table at the start of every block
-  constexpr bool DW_RELOAD = NB > 1 && ((K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024) || K::HALF);
+  constexpr bool DW_RELOAD = NB > 1 && K::NARROW && (4 + C * XS + NB * C * DWS) * 4 > 156 * 1024;
   __shared__ __attribute__((aligned(16))) float DW[(DW_RELOAD ? 1 : NB) * C * DWS];
   constexpr bool DWIDE = DR == 5 || DR == 8;            // the wide stages' down-sampling phase: taps straight from global memory (no LDS left)
   __shared__ __attribute__((aligned(16))) float DWD[(DR > 0 && !DWIDE) ? 2 * C * DDS : 4];
@@ -86,18 +86,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
 #else
 #define STAMP(i) do { } while (0)
 #endif
-  // wave priority per phase kind (tuning builds only, -DHILC_RES_SETPRIO=1: element-wise phases high / GEMM phases low; 2: the reverse).
-  // Measured in round 3 (+-0) and again in round 6 on the stage kernels (profiles/r06_experiments.md): not in the product build.
-#if defined(HILC_RES_SETPRIO) && HILC_RES_SETPRIO == 1
-#define PRIO_EW() __builtin_amdgcn_s_setprio(3)
-#define PRIO_MM() __builtin_amdgcn_s_setprio(0)
-#elif defined(HILC_RES_SETPRIO) && HILC_RES_SETPRIO == 2
-#define PRIO_EW() __builtin_amdgcn_s_setprio(0)
-#define PRIO_MM() __builtin_amdgcn_s_setprio(3)
-#else
-#define PRIO_EW() do { } while (0)
-#define PRIO_MM() do { } while (0)
-#endif
+  // (s_setprio per phase kind — element-wise high / GEMM low and the reverse — measured +-0 in round 3 and again on the stage kernels in round 6:
+  //  profiles/r06_ab_setprio.txt, commit 8c897d4)
   const int T = a.T;
   const int nblk = NB == 1 ? 1 : a.nblk;                 // uniform; NB == 1: the block loop below folds away
   // depthwise taps / biases -> LDS once per workgroup (read back as half-wave broadcasts in P3 / P6)
@@ -486,10 +476,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
         Pipe wp;
         wp.prefetch(wu, lane);
         lds_barrier();
-        PRIO_MM();
         if constexpr (K::NARROW) gemm_phase_rolled<K, false>(wu, X, acc, wp, colblk, lane);
         else gemm_phase<K, false>(wu, X, acc, wp, colblk, lane);
-        PRIO_EW();
         lds_barrier();
       }
       acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -704,10 +692,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
 
     f32x16 acc[CBW];
     // ---- P1, P2
-    PRIO_MM();
     if constexpr (K::NARROW) gemm_phase_rolled<K>(w1t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w1t, X, acc, wp, colblk, lane);
-    PRIO_EW();
     lds_barrier();
     STAMP(2);
     acc_to_x<K>(acc, X, rowblk0, colblk, lane);
@@ -764,10 +750,8 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
     STAMP(4);
 
     // ---- P4
-    PRIO_MM();
     if constexpr (K::NARROW) gemm_phase_rolled<K>(w2t, X, acc, wp, colblk, lane);
     else gemm_phase<K>(w2t, X, acc, wp, colblk, lane);
-    PRIO_EW();
     // L2 touch of the next tile's x rows: one dword per 128-B line, issued after the second GEMM, consumed by a
     // never-true test at the end of the kernel; the real loads of P6 then hit this XCD's L2
     have_next = next_tile < run1;
@@ -1011,16 +995,12 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
       // (one more ELU pass: ~1 % of the two GEMMs), GEMM, conv; the next tile's rows then travel under the second GEMM.
       f32x16 acc0[CBW];
       [[maybe_unused]] f32x16 acc1[DWIDE ? 1 : CBW];
-      PRIO_MM();
       if constexpr (K::NARROW) gemm_phase_rolled<K>(wd0, X, acc0, wp, colblk, lane);
       else gemm_phase<K>(wd0, X, acc0, wp, colblk, lane);
-      PRIO_EW();
       if constexpr (!DWIDE) {
         wp.prefetch(wd1, lane);
-        PRIO_MM();
         if constexpr (K::NARROW) gemm_phase_rolled<K>(wd1, X, acc1, wp, colblk, lane);
         else gemm_phase<K>(wd1, X, acc1, wp, colblk, lane);
-        PRIO_EW();
       }
       const bool out_ok = !warm && (STREAM ? cs.t_in : cs.t < T);
       [[maybe_unused]] const bool out_ok_tile = !warm;
@@ -1037,9 +1017,7 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
               for (int i = 0; i < RW; ++i) xr[i] = *xrow(cn, rsub + RSTEP * i);
             }
             lds_barrier();
-            PRIO_MM();
             gemm_phase_rolled<K>(wd1, X, acc0, wp, colblk, lane);
-            PRIO_EW();
           }
         }
         lds_barrier();
@@ -1289,8 +1267,6 @@ __global__ __launch_bounds__((Cfg<C, STREAM, SCARRY, NB, W8, DRU, POST, SPEC0>::
   if (ws_base != nullptr && lane == 0) ws_base[(WS_MAXB - 1) * 3 + 1] = (unsigned long long)ws_k;
 #undef lds_barrier
 #endif
-#undef PRIO_EW
-#undef PRIO_MM
 #undef STAMP
 }
 
