@@ -57,9 +57,12 @@ allk = {}
 for (obj, _), d in zip(names, dem):
     allk.setdefault(short(d), obj)
 miss = sorted(k for k in allk if k not in seen)
-print(f"## {len(allk)} kernel instantiations in the library, {len(allk) - len(miss)} reached by the scenarios above, {len(miss)} not:")
+print(f"## {len(allk)} kernel instantiations in the library, {len(allk) - len(miss)} reached by the scenarios above, {len(miss)} not")
+print("## (MB = the row-tile height 1..4 that pick_mb chooses per shape: other shapes reach the other heights; the rest are the entry points'")
+print("##  forms for arguments no shipped model passes — no ELU, misaligned views, a stage without its end phase, the training-side RVQ kernels —")
+print("##  each pinned by tests/test_gpu_ops.py / test_gpu_rvq.py, several as the bit-equality witness of the launch that replaced them):")
 import collections
-fam = collections.Counter(re.sub(r"<(\d+),", "<MB,", k) if k.startswith(("gemm_lin_kernel", "gemm_kernel")) else k for k in miss)
+fam = collections.Counter(re.sub(r"^(gemm_lin_kernel|gemm_kernel)<(\d+),", r"\1<MB,", k) for k in miss)
 for k, n in sorted(fam.items()):
     print(f"   {n:2d} x {k}   [{allk.get(k, '')}]")
 PY
