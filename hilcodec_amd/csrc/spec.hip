@@ -67,6 +67,7 @@ struct SpecArgs {
   const float* pre_b;
   float pre_in_scale;
   float* y;              // [B][N][Tf]
+  int B;                 // FLAT: clips / streams (tiles walk the flat frame space b * Tf + j)
   int T, Tf, hop, tiles;
   float mean, stdv, out_scale;
   int normalize;
@@ -92,13 +93,23 @@ __device__ __forceinline__ int padded(int u) { return PAD ? u + (u >> 4) : u; }
 // x[m][t] = sum_j pre_w[m][j] * (pre_in_scale * wav[t-4+j]) + pre_b[m]   (seanet.py:280-286; hilc_conv_pre's arithmetic),
 // evaluated from the LDS segment in the epilogue: the [64 x T] tensor conv_pre would write and this kernel re-read
 // (2 x 1.57 GB at B = 256) never exists.
-template <int N, bool PRE>
+// FLAT (round 6: the SpecBlock branches of a streaming hop, 40 - 320 frames per stream): a tile is 128 frames of the FLAT frame space
+// b * Tf + j instead of 128 frames of one clip — at 40 frames per stream the per-clip tile was a third full (the hop took the two-launch
+// path on the generic STFT loader instead: 59 TF), at 160 it was 62 % full.  A tile then touches up to FLAT_MAXP streams; each contributes its
+// own piece of waveform ((frames - 1) * hop + n_fft samples, the first n_fft - 1 of them history in front of t = 0 where the piece starts a
+// stream), the pieces sit back to back in `seg`, and a frame's window starts at its piece's base + (frame - first frame of the piece) * hop.
+// Per-frame arithmetic is untouched: bit-identical to the per-clip form.
+constexpr int FLAT_MAXP = 5;     // Tf >= 32: 128 frames touch at most 5 streams
+
+template <int N, bool PRE, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   using K = SpecCfg<N>;
+  static_assert(!(PRE && FLAT), "the first conv rides on the per-clip form");
   constexpr int CB = K::CB, NB = K::NB;
   constexpr int HOP = K::HOP;
   constexpr bool PAD = K::PAD;
-  constexpr int SEG_MAX = (((TF - 1) * HOP + N) * (PAD ? 17 : 16)) / 16 + 2;
+  constexpr int SEG_SAMPLES = FLAT ? TF * HOP + FLAT_MAXP * (N - HOP) : (TF - 1) * HOP + N;
+  constexpr int SEG_MAX = (SEG_SAMPLES * (PAD ? 17 : 16)) / 16 + 2;
   constexpr int SE_FLOATS = K::SROWS * TF > 64 * ES ? K::SROWS * TF : 64 * ES;                      // S, later the epilogue tile
   __shared__ __attribute__((aligned(16))) float seg[SEG_MAX];
   __shared__ __attribute__((aligned(16))) float segs[PRE ? SEG_MAX : 4];   // PRE: pre_in_scale * segment (the first conv's input)
@@ -107,11 +118,34 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = lane >> 5, l31 = lane & 31;
   constexpr int hop = HOP;
-  const long b = blockIdx.x / a.tiles;
-  const int f0 = (int)(blockIdx.x - b * a.tiles) * TF;
+  const long b = FLAT ? ((long)blockIdx.x * TF) / a.Tf : blockIdx.x / a.tiles;          // FLAT: the tile's first stream
+  const int f0 = FLAT ? (int)((long)blockIdx.x * TF - b * a.Tf) : (int)(blockIdx.x - b * a.tiles) * TF;   // ... and its first frame in it
+  [[maybe_unused]] const int nf0 = a.Tf - f0 < TF ? a.Tf - f0 : TF;                       // FLAT: frames of the first piece
+  [[maybe_unused]] const int len0 = (nf0 - 1) * hop + N, lenf = (a.Tf - 1) * hop + N;     // samples of the first / of a whole-stream piece
 
   // ---- S0: waveform segment (zero outside [0, T)); padding rows of the spectrogram tile
-  {
+  if constexpr (FLAT) {
+    const int rest = TF - nf0, whole = rest / a.Tf, tail = rest - whole * a.Tf;
+    const int total = len0 + whole * lenf + (tail > 0 ? (tail - 1) * hop + N : 0);
+    for (int i = tid; i < total; i += 256) {
+      int p = 0, idx = i, jstart = f0;
+      if (i >= len0) {
+        const int q = i - len0;
+        p = 1 + q / lenf;
+        idx = q - (p - 1) * lenf;
+        jstart = 0;
+      }
+      const long bp = b + p;
+      const int t = jstart * hop - (N - 1) + idx;
+      float v = 0.f;
+      if (bp < a.B) {
+        if (t >= 0) { if (t < a.T) v = a.wav[bp * (long)a.T + t]; }
+        else if (a.hist != nullptr && t >= -a.hist_len) v = a.hist[bp * (long)a.hist_len + a.hist_len + t];
+      }
+      seg[padded<PAD>(i)] = v;
+    }
+    for (int i = tid; i < (K::SROWS - NB) * TF; i += 256) SE[NB * TF + i] = 0.f;
+  } else {
     const int s0 = f0 * hop - (N - 1);
     const int len = (TF - 1) * hop + N;
     const float* wb = a.wav + b * (long)a.T;
@@ -129,24 +163,28 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
   lds_barrier();
 
   const int col = wave * 32 + l31;                       // this lane's frame of the tile
+  // first sample of this frame's window in `seg` (FLAT: inside its stream's piece)
+  int u0 = col * hop;
+  if constexpr (FLAT) {
+    const int fr = f0 + col;                               // frame index counted from the first stream's frame 0
+    const int p = fr / a.Tf, j = fr - p * a.Tf;
+    u0 = p == 0 ? (j - f0) * hop : len0 + (p - 1) * lenf + j * hop;
+  }
   f32x16 acc[CB];
   // ---- A: DFT.  B element of k-pair P (k = 2P + kh) = seg[padded(col*hop + k)]: 8 per-lane offsets per 16-sample
   //      slice, slices advance by the constant 17 words
   {
     int off[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) off[p] = padded<PAD>(col * hop + 2 * p + kh);
+    for (int p = 0; p < 8; ++p) off[p] = padded<PAD>(u0 + 2 * p + kh);
     // (col*hop + 2p + kh) + 16*kt: padded() adds exactly 17*kt because the slice step is a multiple of 16
     auto bop = [&](int P) -> float { return seg[off[P & 7] + (PAD ? 17 : 16) * (P >> 3)]; };
     stream_gemm<CB, K::KP, K::DEPTH, K::SETS_A>(a.dft, acc, lane, bop);
   }
   // ---- Nyquist bin's imaginary part: scalar chain in k order (lanes 0..31 own rows 0/1 = cos_0 / cos_{N/2})
   float nyq_im = 0.f;
-  {
-    const int u0 = col * hop;
 #pragma unroll 8
-    for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded<PAD>(u0 + k)], nyq_im);
-  }
+  for (int k = 0; k < N; ++k) nyq_im = fmaf(a.nyq[k], seg[padded<PAD>(u0 + k)], nyq_im);
   // ---- B: magnitude -> log -> normalise -> S[bin][frame]
   const SpecFinish finish = SpecFinish::make(a.mean, a.stdv, a.normalize);
   float* S = SE;
@@ -209,16 +247,30 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
         pb = a.pre_b != nullptr ? a.pre_b[m] : 0.f;
       }
       const float* er = E + row * ES + c0;
-      const long off0 = ybase + (long)m * a.Tf + f0 + c0;
+      // where the four 4-frame groups of this 16-column segment live (Tf % 4 == 0: a group never straddles clips / streams)
+      long offg[4];
+      bool okg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if constexpr (FLAT) {
+          const int fr = f0 + c0 + 4 * g;                 // counted from the first stream's frame 0
+          const int p = fr / a.Tf, j = fr - p * a.Tf;
+          okg[g] = b + p < a.B;
+          offg[g] = ((b + p) * (long)N + m) * a.Tf + j;
+        } else {
+          okg[g] = f0 + c0 + 4 * g < a.Tf;
+          offg[g] = ybase + (long)m * a.Tf + f0 + c0 + 4 * g;
+        }
+      }
       f32x4 rq[4];
       if constexpr (!PRE) {       // all residual loads before the first store (x may alias y: later loads would wait behind it)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          if (a.x != nullptr && f0 + c0 + 4 * g < a.Tf) rq[g] = *reinterpret_cast<const f32x4*>(a.x + off0 + 4 * g);
+          if (a.x != nullptr && okg[g]) rq[g] = *reinterpret_cast<const f32x4*>(a.x + offg[g]);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (f0 + c0 + 4 * g < a.Tf) {                    // Tf % 4 == 0: whole groups
+        if (okg[g]) {                                    // Tf % 4 == 0: whole groups
           f32x4 v = *reinterpret_cast<const f32x4*>(er + 4 * g);
           f32x4 rr;
           if constexpr (PRE) {
@@ -243,18 +295,29 @@ __global__ __launch_bounds__(256, 2) void spec_block_kernel(SpecArgs a) {
             t = __fmul_rn(t, a.out_scale);
             v[e] = (PRE || a.x != nullptr) ? __fadd_rn(t, rr[e]) : t;   // separate roundings: y.mul_(scale); x.add_(y)  (x NULL: the branch alone)
           }
-          *reinterpret_cast<f32x4*>(a.y + off0 + 4 * g) = v;
+          *reinterpret_cast<f32x4*>(a.y + offg[g]) = v;
         }
       }
     }
   }
 }
 
+// short clips — a streaming hop's 40 ... 320 frames per stream — tile the flat frame space (see FLAT above)
+inline bool flat_tiles(int Tf) { return Tf >= 32 && Tf < 4 * TF && Tf % TF != 0; }
+
 template <int N, bool PRE = false>
 int launch_spec(const SpecArgs& a, int B, hipStream_t s) {
-  const long blocks = (long)B * a.tiles;
+  const bool flat = !PRE && flat_tiles(a.Tf);
+  const long blocks = flat ? ((long)B * a.Tf + TF - 1) / TF : (long)B * a.tiles;
   if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
   HILC_CLEAR_ERROR();
+  if constexpr (!PRE) {
+    if (flat) {
+      hipLaunchKernelGGL((spec_block_kernel<N, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      HILC_CHECK_LAUNCH();
+      return HILC_OK;
+    }
+  }
   hipLaunchKernelGGL((spec_block_kernel<N, PRE>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   HILC_CHECK_LAUNCH();
   return HILC_OK;
@@ -306,7 +369,7 @@ extern "C" int hilc_spec_block(const float* wav, const float* hist, int hist_len
   SpecArgs a;
   a.wav = wav; a.hist = hist; a.hist_len = hist_len;
   a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = x; a.y = y;
-  a.T = T; a.Tf = (T - 1) / hop + 1; a.hop = hop; a.tiles = (a.Tf + TF - 1) / TF;
+  a.B = B; a.T = T; a.Tf = (T - 1) / hop + 1; a.hop = hop; a.tiles = (a.Tf + TF - 1) / TF;
   a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
   a.pre_w = nullptr; a.pre_b = nullptr; a.pre_in_scale = 1.f;
   switch (n_fft) {
@@ -329,7 +392,7 @@ extern "C" int hilc_spec_block_conv_pre(const float* wav, const float* hist, int
   a.wav = wav; a.hist = hist; a.hist_len = hist_len;
   a.dft = dft_packed; a.nyq = nyq_sin; a.pw = pw_packed; a.bias = bias; a.x = nullptr; a.y = y;
   a.pre_w = pre_w; a.pre_b = pre_b; a.pre_in_scale = pre_in_scale;
-  a.T = T; a.Tf = T; a.hop = 1; a.tiles = (a.Tf + TF - 1) / TF;
+  a.B = B; a.T = T; a.Tf = T; a.hop = 1; a.tiles = (a.Tf + TF - 1) / TF;
   a.mean = mean; a.stdv = stdv; a.out_scale = out_scale; a.normalize = normalize;
   return launch_spec<64, true>(a, B, (hipStream_t)stream);
 }

@@ -1114,11 +1114,13 @@ def spec_block_supported(n_fft: int, hop: int, C: int, T: int) -> bool:
 
 
 def spec_block_profitable(n_fft: int, hop: int, C: int, T: int) -> bool:
-    """supported, and the clip fills its 128-frame tiles to >= 60 % (a 320-sample streaming hop has 40 frames at
-    n_fft = 256: a third of a tile — the two-launch path with flat columns is faster there, measured)"""
+    """supported, and the launch fills its 128-frame tiles: clips of 32 ... 511 frames (a streaming hop: 40 frames per stream at n_fft = 256)
+    walk the flat frame space, longer ones per-clip tiles that must be >= 60 % full"""
     if not spec_block_supported(n_fft, hop, C, T):
         return False
     tf = (T - 1) // hop + 1
+    if 32 <= tf < 512:          # round 6: short clips (a streaming hop) tile the FLAT frame space — every tile full (csrc/spec.hip: FLAT)
+        return True
     return tf * 10 >= ((tf + 127) // 128) * 128 * 6
 
 

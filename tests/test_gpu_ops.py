@@ -1037,7 +1037,11 @@ def test_up_conv_stream_vs_unfused_and_offline(env, K, M, Tin, r, B):
 
 
 @pytest.mark.parametrize("n_fft,hop,B,T", [(64, 1, 2, 1000), (128, 2, 2, 2400), (256, 8, 3, 4000), (64, 1, 1, 128),
-                                           (128, 2, 1, 24), (256, 8, 1, 24000)])
+                                           (128, 2, 1, 24), (256, 8, 1, 24000),
+                                           # round 6: short clips tile the FLAT frame space (a streaming hop: 40 / 160 / 320 frames per stream; tiles that
+                                           # touch 2 - 5 streams, a last tile that ends inside the batch, several frames' worth of hop)
+                                           (256, 8, 37, 320), (256, 8, 1024, 320), (128, 2, 33, 320), (128, 2, 1024, 320), (64, 1, 9, 320),
+                                           (256, 8, 5, 1280), (128, 2, 3, 640), (256, 8, 2, 288), (256, 8, 70, 256)])
 def test_fused_spec_block_equals_unfused_and_oracle(env, n_fft, hop, B, T):
     """hilc_spec_block (STFT -> log-magnitude -> normalise -> 1x1 conv -> += in one launch, exactly n_fft DFT rows)
     against hilc_stft_logmag + hilc_pw_conv bit for bit, and against the oracle's spec_block()."""
