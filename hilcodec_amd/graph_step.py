@@ -260,11 +260,11 @@ class PipelinedHop:
         m = self.model
         lo, hi = self.bounds[g]
         st = self.gstate[g]
-        # beside the encoder's chain the narrow decoder stages stay chain + separate up-sampling launch (same results): their
-        # one-launch form holds every CU with one long workgroup and leaves the other chain nothing to co-reside with (measured:
-        # pipelined 4.72 ms without, 4.82 with; the plain graph gains 0.15 ms from it).  Context-local override, nothing is written
-        # into the model's options.  The same holds for the C = 384 stage's up-sampling layer + first block (4.716 vs 4.73 - 4.76 ms).
-        with ops.sched_workspace(self.sched_dec[g]), engine.exec_overrides(decoder_stage_narrow=False):
+        # (rounds 4-5 captured this chain with `engine.exec_overrides(decoder_stage_narrow=False)`: beside the encoder's chain the narrow decoder
+        # stages were faster as up-sampling launch + chain.  Round 6, with EVERY stage of a hop one launch and the closing conv inside the last:
+        # 4.64 ms with that override, 4.49 without (tools/ab_pipelined_overrides.py) — the model's own options stand.  The plain replay
+        # (`GraphedHop`, no added latency) is at 4.46 ms: the two-chain schedule no longer buys anything at 1 024 streams.)
+        with ops.sched_workspace(self.sched_dec[g]):
             wav, _ = m.decoder(m.dequantizer(self.idx[p ^ 1][:, lo:hi].contiguous(), self.n), *st[p ^ 1].dec,
                                cache_out=st[p].dec)
         return wav
