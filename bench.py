@@ -95,6 +95,23 @@ def parse():
     return a
 
 
+def smi_index_of(device_index: int, smi: str) -> int:
+    """rocm-smi's index of the HIP device `device_index`: matched by PCI bus id — under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remapping
+    (common under launchers) a rank's HIP ordinal is NOT rocm-smi's physical index.  Falls back to the ordinal where either side does not say."""
+    import re
+    import subprocess
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        txt = subprocess.run([smi, "--showbus"], capture_output=True, text=True, timeout=10).stdout
+        for m in re.finditer(r"GPU\[(\d+)\][^\n]*PCI Bus:\s*([0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2})", txt):
+            if m.group(2).lower() == want:
+                return int(m.group(1))
+    except Exception:
+        pass
+    return device_index
+
+
 def sustained_clock(step, first_index: int, seconds: float = 2.5, device_index: int = 0):
     """Shader clock and socket power while the benchmark's own steps run back to back: `rocm-smi` sampled from a
     thread (≈3 samples per second).  Returns medians, or None where rocm-smi is missing / prints something else."""
@@ -106,11 +123,12 @@ def sustained_clock(step, first_index: int, seconds: float = 2.5, device_index: 
     if not os.path.exists(smi):
         return None
     sclk, power, cap, stop = [], [], [], [False]
+    smi_dev = smi_index_of(device_index, smi)
 
     def sampler():
         while not stop[0]:
             try:
-                txt = subprocess.run([smi, "-d", str(device_index), "--showclocks", "--showpower", "--showmaxpower"], capture_output=True,
+                txt = subprocess.run([smi, "-d", str(smi_dev), "--showclocks", "--showpower", "--showmaxpower"], capture_output=True,
                                      text=True, timeout=10).stdout
             except Exception:
                 return
@@ -421,7 +439,7 @@ def main():
     dt, idx, wav, timer = timed_region(step, args.steps, args.warmup, D, not args.no_launch_timing)
 
     per_rank = D.gather_counters({"clips": float((hi - lo) * args.steps), "audio_s": audio_per_step * args.steps,
-                                  "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)   # the ONLY collective
+                                  "wall_s": dt, "index_checksum": float(idx.sum().item())}, dev)   # the data path has NO collective: this gathers the counters (a second gather below carries each rank's clock / power)
     rank_sustained = None
     if world > 1 and not args.no_clock_probe:
         # all ranks keep stepping together for 2.5 s (the node's power budget is shared: a sub-linear curve can then be told apart

@@ -299,6 +299,14 @@ class PipelinedHop:
         return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
 
     @property
+    def cache_enc_unsynced(self) -> List[Tensor]:
+        """The encoder caches as of the LAST ENCODED hop, also while a hop is pending (then the decoder's caches are one hop older: this
+        list alone is a valid encoder snapshot, a (cache_enc_unsynced, cache_dec) pair is not a resumable state — `flush()` first for
+        that).  For callers that checkpoint the encoder side only; rounds 2-4's `cache_enc` behaved like this."""
+        per_group = [blocks[self.parity].enc for blocks in self.gstate]
+        return per_group[0] if len(per_group) == 1 else [torch.cat(cs, dim=0) for cs in zip(*per_group)]
+
+    @property
     def cache_dec(self) -> List[Tensor]:
         """CURRENT decoder caches (only after `flush()`, see `cache_enc`: then both cache lists describe the same instant)"""
         self._no_pending("cache_dec")

@@ -117,11 +117,12 @@ def test_cpu_input_fails_loudly():
         model(synth.synth_clips(1, 640))
 
 
-def test_whole_model_weight_standardization(golden):
+@pytest.mark.parametrize("gname", ["ws_hil_speech", "ws125_hil_speech"])      # weight_scale 0.8 and 1.25 (large activations through the stage kernels)
+def test_whole_model_weight_standardization(golden, gname):
     """`HILCodec(norm="weight_standardization", norm_kwargs=...)` model-wide (`conv.py:36-37`,
     `modules/weight_standardization.py:30-41`) against the REAL reference's output for the same constructor call."""
     import hilcodec_amd
-    g = golden("ws_hil_speech")
+    g = golden(gname)
     kw = {"eps": float(g["ws_eps"]), "scale": float(g["ws_scale"])}
     mk = dict(synth.model_kwargs("hil_speech"), norm="weight_standardization", norm_kwargs=kw)
     sd = synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"]))

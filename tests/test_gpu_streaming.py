@@ -467,13 +467,16 @@ def test_stream_block_options_reach_both_halves():
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(a, e)
 
 
-def test_streaming_weight_standardised_checkpoint(golden):
+@pytest.mark.parametrize("gname", ["ws_hil_speech", "ws125_hil_speech"])
+def test_streaming_weight_standardised_checkpoint(golden, gname):
     """A checkpoint of the offline `HILCodec(norm="weight_standardization")` through the streaming model, hop by hop, against
     the REAL reference's streaming model carrying the weights its own `WeightStandardization.compute_weight` produced
     (tests/golden/ws_hil_speech.npz; the reference's streaming classes know weight_norm only, so folded plain weights are
-    the only way in — `oracle/make_golden.py: ws_golden`): z, indices, wav and all 52 caches after 5 hops."""
+    the only way in — `oracle/make_golden.py: ws_golden`): z, indices, wav and all 52 caches after 5 hops — at `weight_scale` 0.8 (every cache O(1):
+    the absolute 5e-5 of every other cache test) and at 1.25 (the decoder's caches reach |x| = 30: the one model-level case that drives large
+    activations through the fused stage kernels and the caches; its bar is 5e-5 relative to the cache's largest value)."""
     from hilcodec_amd.models.hilcodec.streaming import HILCodec
-    g = golden("ws_hil_speech")
+    g = golden(gname)
     dev = torch.device("cuda:0")
     mk = {k: v for k, v in synth.model_kwargs("hil_speech").items() if k not in ("spec_learnable", "causal", "pad_mode")}
     sd = synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"]))
@@ -496,5 +499,5 @@ def test_streaming_weight_standardised_checkpoint(golden):
     assert (torch.cat(ws, 2).cpu() - T(g["s_wav"])).abs().max() < 1e-4
     for i, c in enumerate(list(ce) + list(cd)):
         ref = T(g[f"e_out{i}"] if i < 22 else g[f"d_out{i - 22}"])
-        # (the golden's weight_scale is 0.8 since round 5: every cache is O(1), so the bar is the ABSOLUTE 5e-5 of every other cache test)
-        assert c.shape == ref.shape and (c.cpu() - ref).abs().max() < 5e-5, i
+        bar = 5e-5 * max(1.0, float(ref.abs().max()))          # absolute at weight_scale 0.8 (|cache| <= 2.4), relative at 1.25 (<= 30)
+        assert c.shape == ref.shape and (c.cpu() - ref).abs().max() < bar, (i, float((c.cpu() - ref).abs().max()), bar)

@@ -239,11 +239,12 @@ def test_shard_rank7_prefix(golden):
     assert torch.equal(wav[:, :, ::25], T(g["wav_probe"])[3:5])
 
 
-def test_weight_standardization_whole_model(golden):
+@pytest.mark.parametrize("gname", ["ws_hil_speech", "ws125_hil_speech"])      # weight_scale 0.8 (O(1) activations) and 1.25 (|x| ~ 30)
+def test_weight_standardization_whole_model(golden, gname):
     """`HILCodec(norm="weight_standardization")` (`conv.py:36-37`, `modules/weight_standardization.py:30-41`), offline and —
     through folded plain weights, the only way the reference's weight_norm-only streaming classes can carry such a
     checkpoint — streaming with every cache."""
-    g = golden("ws_hil_speech")
+    g = golden(gname)
     mk = synth.model_kwargs("hil_speech")
     sd = O.with_weight_standardization(synth.synth_state_dict("hil_speech", seed=int(g["weight_seed"])), float(g["ws_scale"]))
     x = synth.synth_clips(2, int(g["samples"]), seed=int(g["clip_seed"]))
