@@ -44,8 +44,6 @@ SIGNATURES = {
     "hilc_decoder_stage_post_supported": [_i, _i, _i, _i, _i],
     "hilc_decoder_stage_post": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "hilc_encoder_stage0_supported": [_i, _i, _i, _i, _i, _i, _i],
-    "hilc_encoder_tail_supported": [_i, _i, _i],
-    "hilc_encoder_tail": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _f, _p],
     "hilc_encoder_stage0": [_p, _p, _i, _p, _i, _i, _i, _p],
     "hilc_encoder_stage_supported": [_i, _i, _i, _i, _i],
     "hilc_encoder_stage": [_p, _p, _i, _p, _i, _i, _i, _i, _p],

@@ -22,21 +22,3 @@ struct Frame1Args {
 
 // HILC_OK / HILC_ERR_*; B up to 65535 * 32 streams
 int launch_frame1(const Frame1Args& a, hipStream_t stream);
-
-// The streaming encoder's single-frame tail (depthwise conv with its cache -> 1x1 conv K -> 128 -> L2Norm) in one launch: see frame1.hip.
-struct EncTailArgs {
-  const float* x;        // [B][K] the frame of every stream
-  const float* hist;     // [B][K][4] depthwise cache (activated samples) or null (zeros)
-  float* hist_out;       // [B][K][4] or null; must not alias hist
-  const float* dw_w;     // [K][5]
-  const float* wt;       // [K][128] k-major pointwise weight
-  const float* bias;     // [128] or null
-  float* z;              // [B][128]
-  long B;
-  int K;
-  float in_scale;
-  int in_elu;
-  float eps, scale;
-  int l2norm;
-};
-int launch_encoder_tail(const EncTailArgs& a, hipStream_t stream);

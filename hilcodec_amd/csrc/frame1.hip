@@ -97,110 +97,7 @@ __global__ __launch_bounds__(256) void frame1_kernel(Frame1Args a) {
   }
 }
 
-// ---- the streaming encoder's single-frame TAIL in one launch (round 6) --------------------------------------------------------------
-// streaming.py:512-517: `conv_post` = [ELU, depthwise conv k = 5 over [cache | frame], 1x1 conv K -> 128 + bias], then L2Norm over the 128
-// channels.  As four launches (hilc_dw_conv + its cache update, hilc_pw_conv = frame1_kernel, hilc_l2norm) this was 77 us of a 4.46 ms hop at
-// ~0 matrix utilisation.  Here a workgroup owns 32 streams and ALL 128 outputs: its four waves split K four ways exactly like frame1_kernel
-// (same k ranges, same ascending k-pair order, the four partial tiles added in wave order) and feed the MFMAs of the four 32-row output tiles
-// from ONE depthwise-convolved operand, which they compute on the fly — fmaf chain over the taps j = 0..4 on [cache | ELU(in_scale * x)], the
-// expression of dw_generic_kernel — and whose new cache they store; the epilogue adds the bias and runs hilc_l2norm's arithmetic (one fmaf
-// chain over the channels in ascending order, sqrt, max with eps, divide, multiply).  Same chains, same roundings: bit-identical to the
-// four launches.
-constexpr int TAIL_M = 128;
-constexpr int TAIL_UP = 8;     // k-pairs per group (4 weight words + a cache quad + 5 taps per k-pair in flight)
-
-__global__ __launch_bounds__(256) void encoder_tail_kernel(EncTailArgs a) {
-  __shared__ float red[4][32][TAIL_M + 1];   // [wave][stream][channel]
-  __shared__ float hs[32][TAIL_M + 1];       // summed, + bias
-  __shared__ float dn[32];                   // per stream: max(||h||, eps)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
-  const long b0 = (long)blockIdx.x * 32;
-  const int K = a.K;
-  const long bl = b0 + l32 < a.B ? b0 + l32 : a.B - 1;       // streams past the edge compute on a clamped address and store nothing
-  const bool own = b0 + l32 < a.B;
-  const int kw = (((K + 3) >> 2) + 1) & ~1;                  // frame1_kernel's split of K over the four waves
-  const int kb = wave * kw;
-  const int ke = kb + kw < K ? kb + kw : K;
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  // the operand of k: h = sum_j w[k][j] * v_j, v = [cache[b][k][0..3] | pro(x[b][k])]; the lane that computes it also stores the new cache
-  for (int k = kb; k < ke; k += 2 * TAIL_UP) {
-    float av[TAIL_UP][4], xv[TAIL_UP], w5[TAIL_UP][5];
-    f32x4 cv[TAIL_UP];
-#pragma unroll
-    for (int i = 0; i < TAIL_UP; ++i) {
-      const int kk = k + 2 * i + half;
-      const bool ok = kk < ke;
-      const int kc = ok ? kk : ke - 1;
-      xv[i] = a.x[bl * K + kc];
-      cv[i] = a.hist != nullptr ? *reinterpret_cast<const f32x4*>(a.hist + (bl * K + kc) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 5; ++j) w5[i][j] = a.dw_w[kc * 5 + j];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) av[i][m] = ok ? a.wt[(long)kc * TAIL_M + 32 * m + l32] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < TAIL_UP; ++i) {
-      const int kk = k + 2 * i + half;
-      const bool ok = kk < ke;
-      const float v4 = prologue(xv[i], a.in_scale, a.in_elu);
-      float h = 0.f;
-      h = fmaf(w5[i][0], cv[i].x, h);
-      h = fmaf(w5[i][1], cv[i].y, h);
-      h = fmaf(w5[i][2], cv[i].z, h);
-      h = fmaf(w5[i][3], cv[i].w, h);
-      h = fmaf(w5[i][4], v4, h);
-      if (ok && own && a.hist_out != nullptr)
-        *reinterpret_cast<f32x4*>(a.hist_out + (bl * K + kk) * 4) = f32x4{cv[i].y, cv[i].z, cv[i].w, v4};
-      const float bop = ok ? h : 0.f;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][m], bop, acc[m], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][l32][32 * m + acc_row1(r, lane)] = acc[m][r];
-  __syncthreads();
-  // the four partial tiles in wave order (frame1_kernel's order), + bias
-  for (int e = tid; e < 32 * TAIL_M; e += 256) {
-    const int col = e / TAIL_M, m = e - col * TAIL_M;
-    float h = __fadd_rn(__fadd_rn(__fadd_rn(red[0][col][m], red[1][col][m]), red[2][col][m]), red[3][col][m]);
-    if (a.bias != nullptr) h = __fadd_rn(h, a.bias[m]);
-    hs[col][m] = h;
-  }
-  __syncthreads();
-  if (a.l2norm) {
-    if (tid < 32) {                      // hilc_l2norm: ONE fmaf chain over the channels in ascending order
-      float ss = 0.f;
-      for (int m = 0; m < TAIL_M; ++m) ss = fmaf(hs[tid][m], hs[tid][m], ss);
-      dn[tid] = fmaxf(sqrtf(ss), a.eps);
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < 32 * TAIL_M; e += 256) {
-    const int col = e / TAIL_M, m = e - col * TAIL_M;
-    const long b = b0 + col;
-    if (b >= a.B) continue;
-    const float v = hs[col][m];
-    a.z[b * TAIL_M + m] = a.l2norm ? __fmul_rn(__fdiv_rn(v, dn[col]), a.scale) : v;
-  }
-}
-
 }  // namespace
-
-int launch_encoder_tail(const EncTailArgs& a, hipStream_t stream) {
-  if (a.B <= 0 || a.K <= 0) return HILC_ERR_SHAPE;
-  const long blocks = (a.B + 31) / 32;
-  if (blocks > 0x7fffffffL) return HILC_ERR_SHAPE;
-  HILC_CLEAR_ERROR();
-  hipLaunchKernelGGL(encoder_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  HILC_CHECK_LAUNCH();
-  return HILC_OK;
-}
 
 int launch_frame1(const Frame1Args& a, hipStream_t stream) {
   if (a.B <= 0 || a.K <= 0 || a.M <= 0) return HILC_ERR_SHAPE;

@@ -251,22 +251,6 @@ struct UpLoader {
 
 }  // namespace
 
-extern "C" int hilc_encoder_tail_supported(int K, int M, int ksize) { return M == 128 && ksize == 5 && K > 0 && K % 2 == 0; }
-
-extern "C" int hilc_encoder_tail(const float* x, const float* hist, float* hist_out, const float* dw_w, const float* wt, const float* bias,
-                                 float* z, int B, int K, int M, int ksize, float in_scale, int in_elu, int l2norm, float eps, float scale,
-                                 void* stream) {
-  if (!x || !dw_w || !wt || !z) return HILC_ERR_NULL;
-  if (B <= 0 || K <= 0 || M <= 0) return HILC_ERR_SHAPE;
-  if (!hilc_encoder_tail_supported(K, M, ksize)) return HILC_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(hist) & 15) || (reinterpret_cast<uintptr_t>(hist_out) & 15) || (hist && hist == hist_out))
-    return HILC_ERR_UNSUPPORTED;
-  EncTailArgs a{};
-  a.x = x; a.hist = hist; a.hist_out = hist_out; a.dw_w = dw_w; a.wt = wt; a.bias = bias; a.z = z; a.B = B; a.K = K;
-  a.in_scale = in_scale; a.in_elu = in_elu; a.eps = eps; a.scale = scale; a.l2norm = l2norm;
-  return launch_encoder_tail(a, (hipStream_t)stream);
-}
-
 extern "C" int hilc_pw_conv(const float* x, const float* wt, const float* bias, const float* res, float* y,
                             int B, int K, int M, int T, float in_scale, int in_elu, float out_scale,
                             void* stream) {

@@ -97,7 +97,6 @@ def spectra_side_stream(stream):
 
 FUSE_SPECBLOCK = True     # long encoder stages (n_fft <= 256): STFT -> log-mag -> 1x1 conv -> += in one launch
 STREAM_STAGE0 = True      # streaming hop: first conv + stage-0 SpecBlock as the opening phase of the first stage launch (hilc_encoder_stage0)
-STREAM_TAIL = True        # streaming hop of one frame: the encoder's [depthwise conv, 1x1 conv, L2Norm] tail as one launch (hilc_encoder_tail)
 
 
 @dataclass
@@ -574,13 +573,6 @@ def run_encoder(es: EncoderSpec, wav: Tensor, caches: Optional[Sequence[Tensor]]
         ci += 1
     if not defer:
         x = _spec_block(es.spec_post, x, wav, wav_hist)
-    if (streaming and FUSE_STREAM and STREAM_TAIL and es.post_dw_w.dim() == 2
-            and ops.encoder_tail_supported(x.shape[1], es.post_pw_wt.shape[1], es.post_dw_w.shape[1], x.shape[2])):
-        # a one-frame hop: [ELU, depthwise conv with its cache, 1x1 conv -> dim, L2Norm] in ONE launch (streaming.py:512-517)
-        z, c = ops.encoder_tail(x, es.post_dw_w, es.post_pw_wt, es.post_pw_b, caches[ci], out(ci), in_scale=1.0, in_elu=True, l2norm=es.l2norm,
-                                eps=1e-12, scale=float(es.dim) ** 0.5, channel_last_out=channel_last_out)
-        new_caches.append(c)
-        return z, new_caches
     if streaming:
         h, c = ops.dw_conv(x, es.post_dw_w, None, in_elu=True, hist=caches[ci], want_hist=True, hist_out=out(ci))
         new_caches.append(c)

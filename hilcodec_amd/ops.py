@@ -649,27 +649,6 @@ _register("l2norm", "(Tensor x, float eps, float scale, bool channel_last_out) -
 # ======================================================================================================
 # residual VQ
 # ======================================================================================================
-def _encoder_tail(x, hist, hist_out, dw_w, wt, bias, in_scale, in_elu, l2, eps, scale, channel_last_out):
-    B, K, one = x.shape
-    M = wt.shape[1]
-    if one != 1 or tuple(dw_w.shape) != (K, 5) or wt.shape[0] != K:
-        raise RuntimeError(f"encoder_tail: x [B,K,1], dw_w [K,5], wt [K,M]; got {tuple(x.shape)}, {tuple(dw_w.shape)}, {tuple(wt.shape)}")
-    for h in (hist, hist_out):
-        if h is not None and tuple(h.shape) != (B, K, 4):
-            raise RuntimeError(f"encoder_tail: the depthwise cache must be [{B},{K},4], got {tuple(h.shape)}")
-    z = _new(x, *((B, 1, M) if channel_last_out else (B, M, 1)))
-    with _timed("enc_tail", 2.0 * B * K * M, f"K{K} M{M} T1 dw k5 + pw" + (" + l2norm" if l2 else "")):
-        check(lib.hilc_encoder_tail(_ptr(x), _ptr(hist), _ptr(hist_out), _ptr(dw_w), _ptr(wt), _ptr(bias), _ptr(z), B, K, M, 5, float(in_scale),
-                                    int(in_elu), int(l2), float(eps), float(scale), _stream()), "hilc_encoder_tail")
-    return z
-
-
-_register("encoder_tail", "(Tensor x, Tensor? hist, Tensor(a!)? hist_out, Tensor dw_w, Tensor wt, Tensor? bias, float in_scale, bool in_elu, bool l2, "
-          "float eps, float scale, bool channel_last_out) -> Tensor", _encoder_tail,
-          lambda x, hist, hist_out, dw_w, wt, bias, in_scale, in_elu, l2, eps, scale, channel_last_out:
-          x.new_empty(*((x.shape[0], 1, wt.shape[1]) if channel_last_out else (x.shape[0], wt.shape[1], 1))))
-
-
 def _zct(z, channel_last):
     if channel_last:
         B, T, Cc = z.shape
@@ -1170,22 +1149,6 @@ def spec_block_conv_pre(wav: Tensor, dft_packed: Tensor, nyq_sin: Tensor, pw_pac
     """First encoder stage in one launch: conv_pre(wav) + SpecBlock branch (hilc_spec_block_conv_pre)."""
     return _OPS.spec_block_conv_pre(wav, hist, dft_packed, nyq_sin, pw_packed, bias, pre_w, pre_b, float(pre_in_scale), int(n_fft),
                                     int(hop), float(mean), float(std), int(normalize), float(out_scale))
-
-
-def encoder_tail_supported(K: int, M: int, ksize: int, T: int) -> bool:
-    """mirror of hilc_encoder_tail_supported (+ the single-frame condition): the streaming encoder's tail of a one-frame hop in one launch"""
-    return T == 1 and M == 128 and ksize == 5 and K > 0 and K % 2 == 0
-
-
-def encoder_tail(x: Tensor, dw_w: Tensor, wt: Tensor, bias: Optional[Tensor], hist: Optional[Tensor], hist_out: Optional[Tensor] = None,
-                 in_scale: float = 1.0, in_elu: bool = True, l2norm: bool = True, eps: float = 1e-12, scale: float = 1.0,
-                 channel_last_out: bool = False):
-    """The streaming encoder's single-frame tail in ONE launch (hilc_encoder_tail, `streaming.py:512-517`): [ELU, depthwise conv k = 5 over
-    [cache | frame], 1x1 conv K -> 128 + bias], L2Norm.  x `[B,K,1]`, hist `[B,K,4]` -> (z `[B,128,1]` or `[B,1,128]`, new cache) — equal bit for bit to
-    `dw_conv(x, dw_w, None, in_elu=True, hist=hist, want_hist=True)` -> `pw_conv(., wt, bias)` -> `l2norm(.)`."""
-    hout = _state_out(hist_out, x, x.shape[0], x.shape[1], 4)
-    z = _OPS.encoder_tail(x, hist, hout, dw_w, wt, bias, float(in_scale), bool(in_elu), bool(l2norm), float(eps), float(scale), bool(channel_last_out))
-    return z, hout
 
 
 def tail(x: Tensor, hist: Optional[Tensor], pad: int, out: Optional[Tensor] = None) -> Tensor:

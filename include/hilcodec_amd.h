@@ -37,7 +37,7 @@ extern "C" {
 #define HILC_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels cover   */
 #define HILC_ERR_RANGE (-5)       /* n outside 1..Nq (reference: AssertionError)    */
 
-#define HILC_ABI_VERSION 15   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post, hilc_encoder_stage0; 15: hilc_rvq_encode[_mixed] take `flags` (HILC_RVQ_VALU_ONLY replaces the HILC_RVQ_VALU environment variable); hilc_encoder_stage0 / hilc_decoder_stage_post take a streaming hop; the wide stages of a hop in hilc_encoder_stage / hilc_decoder_stage; hilc_encoder_tail */
+#define HILC_ABI_VERSION 15   /* 2: packed residual-block weights; 3: hilc_spec_block; 4: hilc_spec_block_conv_pre; 5: waveform history in both; 6-7: *_x3 (experimental; REMOVED in 14); 8: hilc_dws_conv_wave_row; 9: hilc_resblock_stream_supported (wide blocks in hilc_resblock_stream); 10: hilc_resblock_chain; 11: hilc_encoder_stage; 12: batched cache updates (REMOVED in 14); 13: hilc_decoder_stage; 14: the entry points that only served rejected experiments are gone (split-bf16 decoder GEMMs, batched cache updates); hilc_decoder_stage_post, hilc_encoder_stage0; 15: hilc_rvq_encode[_mixed] take `flags` (HILC_RVQ_VALU_ONLY replaces the HILC_RVQ_VALU environment variable) */
 
 int hilc_abi_version(void);
 const char* hilc_error_string(int code);
@@ -331,19 +331,6 @@ int hilc_spec_block_conv_pre(const float* wav, const float* hist, int hist_len, 
  * (`causal_layers.py:160-162`, waveform cache `streaming.py:486-488`). hist may be NULL (zeros). */
 int hilc_tail(const float* x, const float* hist, float* out, long rows, int T, int pad, int hist_len,
               void* stream);
-
-/* ---- the streaming encoder's single-frame TAIL in one launch (ABI 15) -----------------------------------------------------
- * `streaming.py:512-517` for hops of ONE frame per stream: `conv_post` = [ELU, depthwise conv k = 5 over [cache | frame] (no bias),
- * 1x1 conv K -> 128 + bias] and L2Norm (`streaming.py:279-286`):
- *   h[b,k] = sum_j dw_w[k][j] * v_j,  v = [hist[b,k,0..3] | pro(x[b,k])];  hist_out[b,k] = v[1..4]
- *   y[b,m] = sum_k wt[k][m] * h[b,k] + bias[m];   z[b,:] = l2norm ? y / max(||y||_2, eps) * scale : y
- * x `[B][K][1]`, hist / hist_out `[B][K][4]` (NULL = zeros / not stored), z `[B][128]` (= `[B][1][128]` = `[B][128][1]`).
- * Equals hilc_dw_conv(in_elu, hist, hist_out) -> hilc_pw_conv -> hilc_l2norm bit for bit (same K split over the waves, same chains).
- * M = 128, ksize = 5, K even: hilc_encoder_tail_supported; everything else HILC_ERR_UNSUPPORTED. */
-int hilc_encoder_tail_supported(int K, int M, int ksize);
-int hilc_encoder_tail(const float* x, const float* hist, float* hist_out, const float* dw_w, const float* wt, const float* bias,
-                      float* z, int B, int K, int M, int ksize, float in_scale, int in_elu, int l2norm, float eps, float scale,
-                      void* stream);
 
 /* ---- L2 normalisation over channels: y = x / max(||x||_2, eps) * scale ---------------------------
  * x `[B][C][T]`; y `[B][C][T]` or, if channel_last_out, `[B][T][C]` (streaming encoder output).

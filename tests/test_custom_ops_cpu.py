@@ -10,7 +10,7 @@ from hilcodec_amd import engine, ops, synth
 
 OPS = ["spec_block", "spec_block_conv_pre", "spec_block_pack", "pw_conv", "dws_conv", "dws_conv_stream", "up_conv_expand_taps", "up_conv", "resblock_pack", "resblock", "dw_conv",
        "dw_convtr", "conv_pre", "conv_post", "stft_logmag", "tail", "l2norm", "rvq_encode", "rvq_decode",
-       "rvq_ema_stats", "rvq_ema_update", "resblock_chain", "encoder_stage", "decoder_stage", "decoder_stage_post", "encoder_stage0", "resblock_pack_rc", "encoder_tail"]
+       "rvq_ema_stats", "rvq_ema_update", "resblock_chain", "encoder_stage", "decoder_stage", "decoder_stage_post", "encoder_stage0", "resblock_pack_rc"]
 
 
 def test_every_op_is_registered_with_schema_and_refuses_cpu():

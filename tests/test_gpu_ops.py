@@ -910,37 +910,6 @@ def test_encoder_stage0_streaming_equals_conv_pre_spec_then_stage(env, T, B, n):
             assert torch.equal(ca[j][0], cb[j][0]) and torch.equal(ca[j][1], cb[j][1]), (h, j)
 
 
-@pytest.mark.parametrize("B,K", [(1024, 1024), (37, 1024), (1, 1024), (33, 512), (70, 130)])
-def test_encoder_tail_equals_three_launches(env, B, K):
-    """hilc_encoder_tail (round 6): the streaming encoder's single-frame tail — `conv_post` = [ELU, depthwise conv k = 5 over [cache | frame], 1x1 conv
-    K -> 128 + bias], L2Norm (`streaming.py:512-517, 279-286`) — in one launch == hilc_dw_conv with its cache -> hilc_pw_conv (the single-frame kernel:
-    same K split over the waves) -> hilc_l2norm, bit for bit over three hops: z in both layouts and the depthwise cache; with / without cache, bias and
-    L2Norm; ragged stream counts; and against the oracle's causal conv + 1x1 conv + normalisation."""
-    ops, fold, O, dev = env
-    M = 128
-    assert ops.encoder_tail_supported(K, M, 5, 1)
-    dw = (rnd(1, K, 5) * 0.5).to(dev)
-    w = rnd(2, M, K, 1) / K ** 0.5
-    wt = w[:, :, 0].t().contiguous().to(dev)
-    bias = (rnd(3, M) * 0.1).to(dev)
-    ca = (rnd(4, B, K, 4) * 0.7).to(dev)
-    cb = ca.clone()
-    for h, (use_hist, b_, l2, cl) in enumerate(((True, bias, True, True), (True, None, True, False), (False, bias, False, False))):
-        x = rnd(10 + h, B, K, 1).to(dev)
-        z, ca2 = ops.encoder_tail(x, dw, wt, b_, ca if use_hist else None, in_elu=True, l2norm=l2, eps=1e-12, scale=M ** 0.5, channel_last_out=cl)
-        g, cb2 = ops.dw_conv(x, dw, None, in_elu=True, hist=cb if use_hist else None, want_hist=True)
-        y = ops.pw_conv(g, wt, b_)
-        ref = ops.l2norm(y, eps=1e-12, scale=M ** 0.5, channel_last_out=cl) if l2 else (y.transpose(1, 2).contiguous() if cl else y)
-        assert z.shape == ref.shape and torch.equal(z, ref), (h, float((z - ref).abs().max()))
-        assert torch.equal(ca2, cb2), h
-        if h == 0:
-            full = torch.cat([cb.cpu(), F.elu(x.cpu())], dim=2)                       # [B, K, 5]: cache | activated frame
-            yo = F.conv1d(F.conv1d(full, dw.cpu().view(K, 1, 5), groups=K), w, bias.cpu())
-            zo = yo / yo.norm(dim=1, keepdim=True).clamp_min(1e-12) * M ** 0.5
-            close(z.transpose(1, 2), zo, 2e-5, f"encoder tail vs oracle B{B} K{K}")
-        ca, cb = ca2, cb2
-
-
 def test_resblock_chain_shapes_it_does_not_take(env):
     ops, fold, O, dev = env
     from hilcodec_amd._lib import lib
