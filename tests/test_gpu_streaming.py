@@ -256,11 +256,12 @@ def test_pipelined_hop_equals_eager(groups):
         g.reset()
 
 
-@pytest.mark.parametrize("name,n,hop_frames", [("hil_music", 12, 1), ("hil_speech", 8, 3), ("hil_music", 5, 2)])
+@pytest.mark.parametrize("name,n,hop_frames", [("hil_music", 12, 1), ("hil_speech", 8, 3), ("hil_music", 5, 2), ("hil_speech", 8, 4), ("hil_speech", 3, 5)])
 def test_streaming_vs_oracle_other_configs(name, n, hop_frames):
     """hil_music (Nq = 12) and multi-frame hops (test_onnx.py `num_frames` > 1: 640 / 960 samples per call) against
     the oracle's streaming model; multi-frame hops take the flat-tiled fused block and the whole-clip wide kernels
-    at other T than the single-frame goldens."""
+    at other T than the single-frame goldens (round 6: the wide stage launches at 2 / 4 frames per stream — C = 512 whole-stream tiles of 16 / 32
+    columns, C = 256 / 384 runs of 80 - 200 columns — and their fall-backs at 3 / 5 frames, where a stream does not tile 32 columns)."""
     from oracle import hilcodec_oracle as O
     dev = torch.device("cuda:0")
     model, mk, sd = build_streaming(seed=13, name=name)
