@@ -45,9 +45,9 @@ class ExecOptions:
     wide_blocks: the residual blocks with C >= 256 in the fused kernel (one launch per block or stage); False: two
       depthwise-separable GEMM launches per block with the mid tensor in HBM (round 3's structure).
     decoder_stage_narrow: (with stage_launches) the decoder stages that run ONE long workgroup per CU — C = 192 / 96, and the
-      forms that hold one block behind the up-sampling phase (offline C = 768, a hop's C = 384) — take their up-sampling layer
-      into the launch.  `PipelinedHop` captures with False: beside a second chain those launches leave it nothing to co-reside
-      with (pipelined 4.72 -> 4.82 ms with them, plain graph 5.05 -> 4.90).
+      form that holds one block behind the up-sampling phase (offline C = 768) — take their up-sampling layer into the launch
+      (C = 96: and the closing conv).  False: up-sampling launch + chain (round 4's structure for those stages; `PipelinedHop`
+      captured with it until round 6, when one launch per stage made it the slower choice there too).
     stream_defer_spec: streaming hop: the SpecBlock branches of stages >= 1 computed alone and added by the down-sampling
       epilogue in front (False: in-line, as in round 3)."""
     stage_launches: bool = True

@@ -183,7 +183,8 @@ int hilc_resblock_chain(const float* x, float* y, const hilc_resblock_params* bl
  * pointwise weight, each packed with hilc_resblock_pack_weights_rc(.., C, hilc_resblock_chain_row_classes(C)).
  * Stages: C = 768 with r = 8 (streaming: whole streams per 32-column tile, T in {8, 16, 32}, nblk 1..3; offline: nblk = 1 — the
  * up-sampling layer and the stage's FIRST block, the carry slots of a second do not fit LDS), C = 384 with r = 5 (tr_w = the EXPANDED
- * tap table `[2C][r][8]` of hilc_up_conv_expand_taps; offline: nblk 1..3; streaming: nblk = 1, the halo form of the wide blocks),
+ * tap table `[2C][r][8]` of hilc_up_conv_expand_taps; nblk 1..3; a streaming hop (ABI 15) on 32-column carry tiles, runs of whole
+ * streams, twelve waves — rounds 4-5: nblk = 1 on 64-column halo tiles),
  * C = 192 with r = 4 and C = 96 with r = 2 (streaming hops and, with streaming = 0, the offline model: hist* ignored); nblk 1..3. */
 typedef struct hilc_up_params {
   const float* x; const float* tr_w; const float* w_lo; const float* w_hi; const float* bias;
@@ -222,8 +223,11 @@ int hilc_decoder_stage_post(const hilc_up_params* up, const hilc_resblock_params
  * followed by hilc_dws_conv / hilc_dws_conv_stream (stride r, in_scale, in_elu = 1, `res`) bit for bit; the stage's output
  * `[B][C][T]` never reaches HBM.  w_lo / w_hi: columns [0, C) / [C, 2C) of the k-major `[C][2C]` pointwise weight, each packed
  * like a block's matrix (hilc_resblock_pack_weights_rc with the row classes of the chain form in use).  res (optional): added to
- * the output, e.g. the next stage's SpecBlock branch.  Stages: C = 64 with r = 2, C = 128 with r = 4; offline (streaming = 0) also the
- * wide stages C = 256 with r = 5 and C = 512 with r = 8; nblk 1..2; T % 4 == 0, T % r == 0. */
+ * the output, e.g. the next stage's SpecBlock branch.  Stages: C = 64 with r = 2, C = 128 with r = 4, and the wide stages C = 256 with
+ * r = 5 and C = 512 with r = 8 — offline in the carry form of the narrow-tile shapes; a streaming hop (ABI 15): C = 256 on 32-column carry
+ * tiles (runs of whole streams; T % 40 == 0, i.e. whole frames of the hop), C = 512 on whole-stream tiles (T in {8, 16, 32}); nblk 1..2;
+ * T % 4 == 0, T % r == 0.  hilc_encoder_stage_supported names the shapes; everything else HILC_ERR_UNSUPPORTED (callers launch the
+ * blocks and hilc_dws_conv[_stream] instead). */
 typedef struct hilc_down_params {
   const float* w_lo; const float* w_hi; const float* dw_w; const float* dw_b;
   const float* hist; float* hist_out; const float* res; float* y;
@@ -233,11 +237,14 @@ int hilc_encoder_stage_supported(int C, int T, int nblk, int stride, int streami
 int hilc_encoder_stage(const float* x, const hilc_resblock_params* blocks, int nblk, const hilc_down_params* down, int streaming,
                        int B, int C, int T, void* stream);
 
-/* ---- the encoder's FIRST stage with its input computed in the launch (ABI 14, offline) ----------------------------------------
+/* ---- the encoder's FIRST stage with its input computed in the launch (ABI 14; a streaming hop: ABI 15) ------------------------
  * `seanet.py:280-286` (first conv k = 5, 1 -> 64), `:220-246` (stage 0's SpecBlock: STFT n_fft 64 hop 1 -> log-magnitude -> 1x1 conv),
  * `:316-339` (the stage's residual blocks and down-sampling layer): hilc_spec_block_conv_pre's arithmetic as the opening phase of the
  * hilc_encoder_stage launch for C = 64, r = 2 — equal to the two launches bit for bit; the `[B][64][T]` tensor between them never
- * reaches HBM.  `spec`: the arguments of hilc_spec_block_conv_pre (packed tables from hilc_spec_block_pack); `down->hist` is ignored. */
+ * reaches HBM.  `spec`: the arguments of hilc_spec_block_conv_pre (packed tables from hilc_spec_block_pack).  streaming = 0: the offline
+ * model (`spec->hist`, the blocks' caches and `down->hist` are ignored).  streaming = 1 (ABI 15, `streaming.py:490-511`): a hop on runs of whole
+ * streams, T >= 128 (a 128-column tile then holds at most one stream start: its waveform segment is staged as two pieces, each with the 63
+ * samples in front of it — a stream's history at t = 0), with every cache of hilc_encoder_stage(streaming). */
 typedef struct hilc_spec0_params {
   const float* wav;         /* [B][T] */
   const float* dft_packed; const float* nyq_sin; const float* pw_packed; const float* bias;
