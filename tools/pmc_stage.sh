@@ -11,7 +11,8 @@ i=0
 for CNT in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT" \
          "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" \
-         "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_WAVES GRBM_GUI_ACTIVE"; do
+         "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_WAVES GRBM_GUI_ACTIVE" \
+         "SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VALU_MFMA_F32"; do
   i=$((i+1))
   rocprofv3 --pmc $CNT --output-format csv -d $O/p$i -o p$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-clock-probe \
     --no-launch-timing --no-other-configs "$@" > $O/p$i.log 2>&1
@@ -46,6 +47,11 @@ for k in sorted(agg, key=lambda k: -per(k, "SQ_WAVE_CYCLES") * (n[(k, "SQ_WAVE_C
     print(f"   -> of the wave-cycles: issuing {per(k, 'SQ_ACTIVE_INST_ANY') / wc:.3f}, issue-stalled (WAIT_INST_ANY) {per(k, 'SQ_WAIT_INST_ANY') / wc:.3f}, parked (WAIT_ANY: waitcnt / barrier) {per(k, 'SQ_WAIT_ANY') / wc:.3f}")
     print(f"   -> VALU (non-MFMA) per MFMA {va / mf if mf else float('nan'):.2f}; LDS instr per MFMA {per(k, 'SQ_INSTS_LDS') / mf if mf else float('nan'):.2f}; "
           f"LDS bank-conflict share of LDS-active {per(k, 'SQ_LDS_BANK_CONFLICT') / max(per(k, 'SQ_LDS_IDX_ACTIVE'), 1):.3f}")
+    tr = per(k, "SQ_INSTS_VALU_TRANS_F32")
+    if tr > 0 and mf:
+        print(f"   -> transcendental VALU (v_exp_f32 / v_log_f32) per MFMA {tr / mf:.3f} = {tr / max(va, 1):.3f} of the non-MFMA VALU instructions; "
+              f"wave-cycles waiting on LDS (WAIT_INST_LDS) {per(k, 'SQ_WAIT_INST_LDS') / wc:.3f}; mean LDS / VMEM instructions in flight per wave "
+              f"{per(k, 'SQ_INST_LEVEL_LDS') / wc:.2f} / {per(k, 'SQ_INST_LEVEL_VMEM') / wc:.2f}")
     bc = per(k, "SQ_BUSY_CYCLES")
     if bc > 0:
         print(f"   -> MFMA busy / SQ busy cycles {per(k, 'SQ_VALU_MFMA_BUSY_CYCLES') / bc:.3f} (raw ratio of the two counters; both summed over the same units)")
